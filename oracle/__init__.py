@@ -1,0 +1,222 @@
+"""ctypes binding of the CPU oracle (oracle/mapeval_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package (cloud_map_evaluation_amd) never imports this module.
+
+Pinning status: AWD/CDF/SCS pinned by the reference's own run output (tests/golden/); KD-tree,
+AC/COM/CD and MME are "parity unpinned" by the reference (it ships no tests and cannot be built here)
+and are cross-checked against brute-force numpy / scipy.cKDTree in tests/test_oracle_*.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmapeval_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds). Returns the .so path."""
+    src = os.path.join(_HERE, "mapeval_oracle.cpp")
+    hdr = os.path.join(_HERE, "mapeval_oracle.h")
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+class _RegStats(C.Structure):
+    _fields_ = [
+        ("n_src", C.c_int64),
+        ("n_corr", C.c_int64),
+        ("number", C.c_double * 5),
+        ("mean", C.c_double * 5),
+        ("rmse", C.c_double * 5),
+        ("fitness", C.c_double * 5),
+        ("sigma", C.c_double * 5),
+        ("sum_sqrt_all", C.c_double),
+    ]
+
+
+@dataclass
+class RegStats:
+    n_src: int
+    n_corr: int
+    number: np.ndarray
+    mean: np.ndarray
+    rmse: np.ndarray
+    fitness: np.ndarray
+    sigma: np.ndarray
+    sum_sqrt_all: float
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int32)
+        L.orc_kdtree_build.restype = C.c_void_p
+        L.orc_kdtree_build.argtypes = [dp, C.c_int64]
+        L.orc_kdtree_free.argtypes = [C.c_void_p]
+        L.orc_kdtree_nn1.argtypes = [C.c_void_p, dp, C.c_int64, ip, dp, C.c_int]
+        L.orc_kdtree_radius_count.argtypes = [C.c_void_p, dp, C.c_int64, C.c_double, ip, C.c_int]
+        L.orc_transform.argtypes = [dp, C.c_int64, dp]
+        L.orc_reg_stats_run.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_double, C.c_int, dp,
+                                        C.POINTER(_RegStats), C.c_int]
+        L.orc_chamfer.restype = C.c_double
+        L.orc_chamfer.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_int]
+        L.orc_mme.restype = C.c_double
+        L.orc_mme.argtypes = [dp, C.c_int64, C.c_double, C.c_int, dp, C.POINTER(C.c_uint8),
+                              C.POINTER(C.c_int64), dp, C.c_int, C.c_int]
+        L.orc_voxel_build.restype = C.c_void_p
+        L.orc_voxel_build.argtypes = [dp, C.c_int64, C.c_double]
+        L.orc_voxel_free.argtypes = [C.c_void_p]
+        L.orc_voxel_count.restype = C.c_int64
+        L.orc_voxel_count.argtypes = [C.c_void_p]
+        L.orc_voxel_export.argtypes = [C.c_void_p, ip, ip, dp, dp, dp]
+        L.orc_w2_gaussian.restype = C.c_double
+        L.orc_w2_gaussian.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int]
+        L.orc_awd_scs.restype = C.c_int
+        L.orc_awd_scs.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, dp, dp,
+                                  C.POINTER(C.c_int64), dp, dp, C.POINTER(C.c_int64)]
+        L.orc_scs.restype = C.c_double
+        L.orc_scs.argtypes = [ip, dp, C.c_int64, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _pts(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError("expected an (N,3) array")
+    return a
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def nn1(ref, query, threads: int = 0):
+    """1-NN of every query in ref -> (idx int32[M], d2 float64[M])  (KDTreeFlann::SearchKNN k=1)."""
+    ref, query = _pts(ref), _pts(query)
+    t = lib().orc_kdtree_build(_dp(ref), ref.shape[0])
+    idx = np.empty(query.shape[0], np.int32)
+    d2 = np.empty(query.shape[0], np.float64)
+    lib().orc_kdtree_nn1(t, _dp(query), query.shape[0], _ip(idx), _dp(d2), threads)
+    lib().orc_kdtree_free(t)
+    return idx, d2
+
+
+def radius_count(ref, query, r: float, threads: int = 0):
+    ref, query = _pts(ref), _pts(query)
+    t = lib().orc_kdtree_build(_dp(ref), ref.shape[0])
+    cnt = np.empty(query.shape[0], np.int32)
+    lib().orc_kdtree_radius_count(t, _dp(query), query.shape[0], float(r), _ip(cnt), threads)
+    lib().orc_kdtree_free(t)
+    return cnt
+
+
+def transform(xyz, T) -> np.ndarray:
+    out = _pts(xyz).copy()
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    lib().orc_transform(_dp(out), out.shape[0], _dp(T))
+    return out
+
+
+def reg_stats(src, tgt, gate: float, gate_mode: int, trunc, threads: int = 1) -> RegStats:
+    src, tgt = _pts(src), _pts(tgt)
+    tr = np.ascontiguousarray(trunc, dtype=np.float64)
+    assert tr.shape == (5,)
+    out = _RegStats()
+    lib().orc_reg_stats_run(_dp(src), src.shape[0], _dp(tgt), tgt.shape[0], float(gate), int(gate_mode),
+                            _dp(tr), C.byref(out), threads)
+    f = lambda x: np.array(list(x), dtype=np.float64)
+    return RegStats(out.n_src, out.n_corr, f(out.number), f(out.mean), f(out.rmse), f(out.fitness),
+                    f(out.sigma), out.sum_sqrt_all)
+
+
+def chamfer(a, b, threads: int = 0) -> float:
+    a, b = _pts(a), _pts(b)
+    return lib().orc_chamfer(_dp(a), a.shape[0], _dp(b), b.shape[0], threads)
+
+
+def mme(xyz, radius: float, min_k: int, mode: int = 2, threads: int = 0):
+    """-> (mean_entropy, entropies[N], valid[N] uint8, n_valid, sum_entropy)."""
+    xyz = _pts(xyz)
+    n = xyz.shape[0]
+    ent = np.zeros(n, np.float64)
+    val = np.zeros(n, np.uint8)
+    nv = C.c_int64(0)
+    s = C.c_double(0.0)
+    m = lib().orc_mme(_dp(xyz), n, float(radius), int(min_k), _dp(ent), val.ctypes.data_as(C.POINTER(C.c_uint8)),
+                      C.byref(nv), C.byref(s), mode, threads)
+    return m, ent, val, nv.value, s.value
+
+
+class VoxelMap:
+    def __init__(self, xyz, voxel_size: float):
+        xyz = _pts(xyz)
+        self.voxel_size = float(voxel_size)
+        self._h = lib().orc_voxel_build(_dp(xyz), xyz.shape[0], self.voxel_size)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_voxel_free(self._h)
+            self._h = None
+
+    def __len__(self):
+        return lib().orc_voxel_count(self._h)
+
+    def export(self):
+        """-> keys[V,3] int32, n[V] int32, mu[V,3], sigma[V,3,3] (as stored), entropy[V]; ascending key order."""
+        v = len(self)
+        keys = np.empty((v, 3), np.int32)
+        n = np.empty(v, np.int32)
+        mu = np.empty((v, 3), np.float64)
+        sg = np.empty((v, 9), np.float64)
+        en = np.empty(v, np.float64)
+        lib().orc_voxel_export(self._h, _ip(keys), _ip(n), _dp(mu), _dp(sg), _dp(en))
+        return keys, n, mu, sg.reshape(v, 3, 3), en
+
+
+def w2_gaussian(mu1, sigma1, n1, mu2, sigma2, n2) -> float:
+    a = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in (mu1, sigma1, mu2, sigma2)]
+    return lib().orc_w2_gaussian(_dp(a[0]), _dp(a[1]), int(n1), _dp(a[2]), _dp(a[3]), int(n2))
+
+
+def awd_scs(gt: VoxelMap, est: VoxelMap, min_pts: int = 100, scs_radius: int = 5):
+    """-> dict(awd, scs, rows[n,27], w_sorted[n], counts(active,old,new))."""
+    cap = max(len(est), 1)
+    rows = np.zeros((cap, 27), np.float64)
+    ws = np.zeros(cap, np.float64)
+    n = C.c_int64(cap)
+    awd = C.c_double()
+    scs = C.c_double()
+    counts = (C.c_int64 * 3)()
+    lib().orc_awd_scs(gt._h, est._h, est.voxel_size, min_pts, scs_radius, _dp(rows), _dp(ws), C.byref(n),
+                      C.byref(awd), C.byref(scs), counts)
+    k = n.value
+    return dict(awd=awd.value, scs=scs.value, rows=rows[:k].copy(), w_sorted=ws[:k].copy(),
+                counts=tuple(int(c) for c in counts))
+
+
+def scs(keys, w, radius: int = 5) -> float:
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    return lib().orc_scs(_ip(keys), _dp(w), w.shape[0], radius)

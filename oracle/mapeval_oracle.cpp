@@ -1,0 +1,839 @@
+// mapeval_oracle.cpp — CPU ORACLE (test infrastructure only; see mapeval_oracle.h for the pinning status).
+//
+// Restates, function by function, the metric hot path of the reference
+// (all citations relative to /root/reference/map_eval/src/).  Built with -ffp-contract=off so that the
+// squared distance ((dx*dx + dy*dy) + dz*dz) has one well-defined fp64 value that the HIP engine must match
+// bit for bit (inlier counts depend on it).
+#include "mapeval_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <unordered_map>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+constexpr int kLeafMax = 15;  // Open3D KDTreeFlann -> nanoflann KDTreeSingleIndexAdaptorParams(15) [upstream]
+
+inline double dist2(const double *a, const double *b) {
+    // nanoflann L2_Simple_Adaptor accumulate order for dim 3 [upstream]: ((dx^2 + dy^2) + dz^2)
+    const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// KD-tree: sliding-midpoint split on the widest bbox dimension, leaves of <= 15 points, index
+// indirection (points are not reordered) — the published nanoflann construction.
+// ---------------------------------------------------------------------------------------------
+struct Node {
+    // leaf: left/right = [begin,end) into vind, child1 = -1
+    int32_t child1 = -1, child2 = -1;
+    int32_t left = 0, right = 0;
+    int32_t divfeat = 0;
+    double divlow = 0, divhigh = 0;
+};
+
+}  // namespace
+
+struct orc_kdtree {
+    const double *pts = nullptr;
+    int64_t n = 0;
+    std::vector<int32_t> vind;
+    std::vector<Node> nodes;
+    double bb_lo[3], bb_hi[3];
+    int32_t root = -1;
+
+    int32_t build(int32_t left, int32_t right, double lo[3], double hi[3]) {
+        const int32_t id = (int32_t) nodes.size();
+        nodes.emplace_back();
+        if (right - left <= kLeafMax) {
+            nodes[id].left = left;
+            nodes[id].right = right;
+            for (int d = 0; d < 3; ++d) {
+                double mn = pts[3 * (int64_t) vind[left] + d], mx = mn;
+                for (int32_t k = left + 1; k < right; ++k) {
+                    const double v = pts[3 * (int64_t) vind[k] + d];
+                    mn = std::min(mn, v);
+                    mx = std::max(mx, v);
+                }
+                lo[d] = mn;
+                hi[d] = mx;
+            }
+            return id;
+        }
+        // widest bbox dimension; among near-widest dims pick the one with the largest point spread
+        double max_span = hi[0] - lo[0];
+        for (int d = 1; d < 3; ++d) max_span = std::max(max_span, hi[d] - lo[d]);
+        int cut = 0;
+        double max_spread = -1.0;
+        for (int d = 0; d < 3; ++d) {
+            if (hi[d] - lo[d] > (1.0 - 1e-5) * max_span) {
+                double mn = pts[3 * (int64_t) vind[left] + d], mx = mn;
+                for (int32_t k = left + 1; k < right; ++k) {
+                    const double v = pts[3 * (int64_t) vind[k] + d];
+                    mn = std::min(mn, v);
+                    mx = std::max(mx, v);
+                }
+                if (mx - mn > max_spread) {
+                    max_spread = mx - mn;
+                    cut = d;
+                }
+            }
+        }
+        double mn = pts[3 * (int64_t) vind[left] + cut], mx = mn;
+        for (int32_t k = left + 1; k < right; ++k) {
+            const double v = pts[3 * (int64_t) vind[k] + cut];
+            mn = std::min(mn, v);
+            mx = std::max(mx, v);
+        }
+        double cutval = 0.5 * (lo[cut] + hi[cut]);
+        cutval = std::min(std::max(cutval, mn), mx);
+        // three-way partition: [< cutval | == cutval | > cutval]
+        int32_t l = left, r = right - 1;
+        for (;;) {
+            while (l <= r && pts[3 * (int64_t) vind[l] + cut] < cutval) ++l;
+            while (l <= r && pts[3 * (int64_t) vind[r] + cut] >= cutval) --r;
+            if (l > r) break;
+            std::swap(vind[l], vind[r]);
+            ++l;
+            --r;
+        }
+        const int32_t lim1 = l;
+        r = right - 1;
+        for (;;) {
+            while (l <= r && pts[3 * (int64_t) vind[l] + cut] <= cutval) ++l;
+            while (l <= r && pts[3 * (int64_t) vind[r] + cut] > cutval) --r;
+            if (l > r) break;
+            std::swap(vind[l], vind[r]);
+            ++l;
+            --r;
+        }
+        const int32_t lim2 = l;
+        const int32_t half = (right - left) / 2;
+        int32_t idx;
+        if (lim1 - left > half) idx = lim1;
+        else if (lim2 - left < half) idx = lim2;
+        else idx = left + half;
+        if (idx == left) idx = left + 1;  // cannot happen unless all points coincide on `cut`
+        if (idx == right) idx = right - 1;
+
+        double lo1[3] = {lo[0], lo[1], lo[2]}, hi1[3] = {hi[0], hi[1], hi[2]};
+        double lo2[3] = {lo[0], lo[1], lo[2]}, hi2[3] = {hi[0], hi[1], hi[2]};
+        hi1[cut] = cutval;
+        lo2[cut] = cutval;
+        const int32_t c1 = build(left, idx, lo1, hi1);
+        const int32_t c2 = build(idx, right, lo2, hi2);
+        nodes[id].child1 = c1;
+        nodes[id].child2 = c2;
+        nodes[id].divfeat = cut;
+        nodes[id].divlow = hi1[cut];
+        nodes[id].divhigh = lo2[cut];
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = std::min(lo1[d], lo2[d]);
+            hi[d] = std::max(hi1[d], hi2[d]);
+        }
+        return id;
+    }
+
+    // A subtree whose lower bound exceeds `worst` by more than this relative slack cannot hold a point
+    // whose *computed* d2 is below `worst` (the incremental bound carries a few ulps of rounding).
+    static constexpr double kSlack = 1.0 + 1e-13;
+
+    void nn_rec(int32_t id, const double *q, double mindist, double dists[3], int32_t &best_i,
+                double &best_d) const {
+        const Node &nd = nodes[id];
+        if (nd.child1 < 0) {
+            for (int32_t k = nd.left; k < nd.right; ++k) {
+                const int32_t pi = vind[k];
+                const double d = dist2(q, pts + 3 * (int64_t) pi);
+                if (d < best_d || (d == best_d && pi < best_i)) {
+                    best_d = d;
+                    best_i = pi;
+                }
+            }
+            return;
+        }
+        const int f = nd.divfeat;
+        const double val = q[f];
+        const double diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+        int32_t first, other;
+        double cut;
+        if (diff1 + diff2 < 0) {
+            first = nd.child1;
+            other = nd.child2;
+            cut = diff2 * diff2;
+        } else {
+            first = nd.child2;
+            other = nd.child1;
+            cut = diff1 * diff1;
+        }
+        nn_rec(first, q, mindist, dists, best_i, best_d);
+        const double saved = dists[f];
+        const double md = mindist + cut - saved;
+        dists[f] = cut;
+        if (md <= best_d * kSlack) nn_rec(other, q, md, dists, best_i, best_d);
+        dists[f] = saved;
+    }
+
+    template <class F>
+    void radius_rec(int32_t id, const double *q, double r2, double mindist, double dists[3], F &&emit) const {
+        const Node &nd = nodes[id];
+        if (nd.child1 < 0) {
+            for (int32_t k = nd.left; k < nd.right; ++k) {
+                const int32_t pi = vind[k];
+                const double d = dist2(q, pts + 3 * (int64_t) pi);
+                if (d < r2) emit(pi, d);  // nanoflann RadiusResultSet::addPoint: dist < radius [upstream]
+            }
+            return;
+        }
+        const int f = nd.divfeat;
+        const double val = q[f];
+        const double diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+        int32_t first, other;
+        double cut;
+        if (diff1 + diff2 < 0) {
+            first = nd.child1;
+            other = nd.child2;
+            cut = diff2 * diff2;
+        } else {
+            first = nd.child2;
+            other = nd.child1;
+            cut = diff1 * diff1;
+        }
+        radius_rec(first, q, r2, mindist, dists, emit);
+        const double saved = dists[f];
+        const double md = mindist + cut - saved;
+        dists[f] = cut;
+        if (md <= r2 * kSlack) radius_rec(other, q, r2, md, dists, emit);
+        dists[f] = saved;
+    }
+
+    double init_dists(const double *q, double dists[3]) const {
+        double s = 0;
+        for (int d = 0; d < 3; ++d) {
+            dists[d] = 0;
+            if (q[d] < bb_lo[d]) dists[d] = (q[d] - bb_lo[d]) * (q[d] - bb_lo[d]);
+            if (q[d] > bb_hi[d]) dists[d] = (q[d] - bb_hi[d]) * (q[d] - bb_hi[d]);
+            s += dists[d];
+        }
+        return s;
+    }
+
+    void nn1(const double *q, int32_t &best_i, double &best_d) const {
+        best_i = -1;
+        best_d = std::numeric_limits<double>::infinity();
+        if (n == 0) return;
+        double dists[3];
+        const double md = init_dists(q, dists);
+        nn_rec(root, q, md, dists, best_i, best_d);
+    }
+
+    template <class F>
+    void radius(const double *q, double r2, F &&emit) const {
+        if (n == 0) return;
+        double dists[3];
+        const double md = init_dists(q, dists);
+        radius_rec(root, q, r2, md, dists, emit);
+    }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// small 3x3 linear algebra (Eigen restated)
+// ---------------------------------------------------------------------------------------------
+inline double det3(const double m[9]) {
+    // Eigen determinant_impl<Derived,3>: m00*(m11*m22-m12*m21) - m01*(m10*m22-m12*m20) + m02*(m10*m21-m11*m20)
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+           m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// Cyclic Jacobi eigen-decomposition of a symmetric 3x3 (stands in for SelfAdjointEigenSolver<Matrix3d>;
+// the clamped reconstruction V*max(L,1e-6)*V^T does not depend on the solver beyond rounding).
+void jacobi_eig3(const double a_in[9], double evals[3], double V[9]) {
+    double a[9];
+    std::memcpy(a, a_in, sizeof(a));
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+        const double diag = a[0] * a[0] + a[4] * a[4] + a[8] * a[8];
+        if (off <= 1e-32 * diag || off == 0.0) break;
+        for (int p = 0; p < 2; ++p) {
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = a[3 * p + q];
+                if (apq == 0.0) continue;
+                const double app = a[3 * p + p], aqq = a[3 * q + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                // A <- J^T A J
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = a[3 * k + p], akq = a[3 * k + q];
+                    a[3 * k + p] = c * akp - s * akq;
+                    a[3 * k + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = a[3 * p + k], aqk = a[3 * q + k];
+                    a[3 * p + k] = c * apk - s * aqk;
+                    a[3 * q + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[3 * k + p], vkq = V[3 * k + q];
+                    V[3 * k + p] = c * vkp - s * vkq;
+                    V[3 * k + q] = s * vkp + c * vkq;
+                }
+            }
+        }
+    }
+    evals[0] = a[0];
+    evals[1] = a[4];
+    evals[2] = a[8];
+}
+
+// Lower Cholesky factor (Eigen LLT, no pivoting, info() unchecked as in voxel_calculator.cpp:136-137).
+void chol3(const double a[9], double L[9]) {
+    for (int i = 0; i < 9; ++i) L[i] = 0.0;
+    L[0] = std::sqrt(a[0]);
+    L[3] = a[3] / L[0];
+    L[6] = a[6] / L[0];
+    L[4] = std::sqrt(a[4] - L[3] * L[3]);
+    L[7] = (a[7] - L[6] * L[3]) / L[4];
+    L[8] = std::sqrt(a[8] - L[6] * L[6] - L[7] * L[7]);
+}
+
+// voxel_calculator.cpp:119-125 / :127-133
+void regularize_sigma(const double sigma_stored[9], int n, double out[9]) {
+    if (n > 1) {
+        double s[9];
+        for (int i = 0; i < 9; ++i) s[i] = sigma_stored[i] / (double) (n - 1);  // third division (:120)
+        double sym[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) sym[3 * r + c] = (s[3 * r + c] + s[3 * c + r]) / 2;  // (:121)
+        double ev[3], V[9];
+        jacobi_eig3(sym, ev, V);
+        for (int k = 0; k < 3; ++k) ev[k] = std::max(ev[k], 1e-6);  // cwiseMax(1e-6) (:123)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += V[3 * r + k] * ev[k] * V[3 * c + k];
+                out[3 * r + c] = acc;
+            }
+    } else {
+        for (int i = 0; i < 9; ++i) out[i] = (i % 4 == 0) ? 1.0 : 0.0;  // Identity (:118,:126)
+    }
+}
+
+struct VoxelInfo {  // voxel_calculator.hpp:25-38
+    double mu[3] = {0, 0, 0};
+    double sigma[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int num_points = 0;
+    double entropy = 0, energy = 0;
+    int active = 0;
+    double entropy_old = 0;
+};
+
+struct Key3 {
+    int32_t v[3];
+    bool operator==(const Key3 &o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2]; }
+};
+struct KeyHash {  // voxel_calculator.hpp:18-22 / map_eval.h:53-58: XOR of std::hash<int>
+    size_t operator()(const Key3 &k) const {
+        return std::hash<int>()(k.v[0]) ^ std::hash<int>()(k.v[1]) ^ std::hash<int>()(k.v[2]);
+    }
+};
+inline bool key_less(const Key3 &a, const Key3 &b) {
+    if (a.v[0] != b.v[0]) return a.v[0] < b.v[0];
+    if (a.v[1] != b.v[1]) return a.v[1] < b.v[1];
+    return a.v[2] < b.v[2];
+}
+
+using VoxelMap = std::unordered_map<Key3, VoxelInfo, KeyHash>;
+
+void compute_voxel_entropy(VoxelInfo &v) {  // voxel_calculator.cpp:97-113
+    if (v.num_points < 2) {
+        v.entropy = 0;
+        v.energy = 0;
+    } else {
+        for (int i = 0; i < 9; ++i) v.sigma[i] /= (double) (v.num_points - 1);  // second division (:102)
+        const double det = det3(v.sigma);
+        if (det <= 0) {
+            v.entropy = 0;
+            v.energy = 0;
+        } else {
+            constexpr double PI = 3.141592653589793238463;
+            v.entropy = 0.5 * std::log(std::pow(2 * PI * std::exp(1), 3) * det);
+            v.energy = v.sigma[0] + v.sigma[4] + v.sigma[8];
+        }
+    }
+}
+
+double w2_gaussian(const VoxelInfo &v1, const VoxelInfo &v2) {  // voxel_calculator.cpp:115-140
+    double s1[9], s2[9];
+    regularize_sigma(v1.sigma, v1.num_points, s1);
+    regularize_sigma(v2.sigma, v2.num_points, s2);
+    double md = 0;
+    for (int d = 0; d < 3; ++d) md += (v1.mu[d] - v2.mu[d]) * (v1.mu[d] - v2.mu[d]);
+    const double tr_sum = (s1[0] + s2[0]) + (s1[4] + s2[4]) + (s1[8] + s2[8]);
+    double L1[9];
+    chol3(s1, L1);
+    // M = L1 * sigma2 * L1^T  (:136)
+    double T[9], M[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += L1[3 * r + k] * s2[3 * k + c];
+            T[3 * r + c] = acc;
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += T[3 * r + k] * L1[3 * c + k];
+            M[3 * r + c] = acc;
+        }
+    double L[9];
+    chol3(M, L);  // (:137)
+    const double distance = md + tr_sum - 2 * (L[0] + L[4] + L[8]);  // (:138)
+    return std::sqrt(std::max(0.0, distance));                        // (:139)
+}
+
+inline int32_t voxel_index(double x, double vs) { return (int32_t) std::floor(x / vs); }  // :241-245
+
+std::vector<std::pair<Key3, const VoxelInfo *>> sorted_entries(const VoxelMap &m) {
+    std::vector<std::pair<Key3, const VoxelInfo *>> v;
+    v.reserve(m.size());
+    for (const auto &kv : m) v.emplace_back(kv.first, &kv.second);
+    std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return key_less(a.first, b.first); });
+    return v;
+}
+
+double scs_from_map(const std::unordered_map<Key3, double, KeyHash> &wd, int radius) {  // map_eval.cpp:347-389
+    double total_scs = 0.0;
+    int64_t scs_count = 0;
+    std::vector<double> nb;
+    for (const auto &kv : wd) {
+        nb.clear();
+        for (int dx = -radius; dx <= radius; ++dx)       // getNeighborIndices, voxel_calculator.cpp:7-19
+            for (int dy = -radius; dy <= radius; ++dy)
+                for (int dz = -radius; dz <= radius; ++dz) {
+                    if (dx == 0 && dy == 0 && dz == 0) continue;
+                    Key3 k{{kv.first.v[0] + dx, kv.first.v[1] + dy, kv.first.v[2] + dz}};
+                    auto it = wd.find(k);
+                    if (it != wd.end()) nb.push_back(it->second);
+                }
+        if (!nb.empty()) {
+            const double mean = std::accumulate(nb.begin(), nb.end(), 0.0) / nb.size();
+            double var = 0.0;
+            for (double w : nb) var += (w - mean) * (w - mean);
+            var /= nb.size();
+            total_scs += std::sqrt(var) / mean;
+            scs_count++;
+        }
+    }
+    return total_scs / (double) scs_count;  // NaN when scs_count == 0, as the reference (:387)
+}
+
+int resolve_threads(int threads) {
+#ifdef _OPENMP
+    if (threads <= 0) return omp_get_max_threads();
+    return threads;
+#else
+    (void) threads;
+    return 1;
+#endif
+}
+
+// one MME point (map_eval.cpp:1666-1701): returns true and sets H if the point is valid
+bool mme_point(const orc_kdtree &t, int64_t i, double r2, int min_k, std::vector<std::pair<double, int32_t>> &nb,
+               double &H) {
+    const double *q = t.pts + 3 * i;
+    nb.clear();
+    t.radius(q, r2, [&](int32_t pi, double d) { nb.emplace_back(d, pi); });
+    if (nb.empty()) return false;              // SearchRadius(...) > 0 (:1670)
+    std::sort(nb.begin(), nb.end());           // nanoflann SearchParams(sorted = true) [upstream]
+    nb.erase(nb.begin());                      // drop the query itself (:1672-1673)
+    const size_t k = nb.size();
+    if ((int) k < min_k) return false;         // (:1675 / :1458)
+    double mean[3] = {0, 0, 0};
+    for (size_t j = 0; j < k; ++j)
+        for (int d = 0; d < 3; ++d) mean[d] += t.pts[3 * (int64_t) nb[j].second + d];
+    for (int d = 0; d < 3; ++d) mean[d] /= (double) k;  // rowwise().mean() (:1684)
+    double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t j = 0; j < k; ++j) {
+        const double *p = t.pts + 3 * (int64_t) nb[j].second;
+        const double c[3] = {p[0] - mean[0], p[1] - mean[1], p[2] - mean[2]};  // (:1685)
+        for (int r = 0; r < 3; ++r)
+            for (int cc = 0; cc < 3; ++cc) cov[3 * r + cc] += c[r] * c[cc];
+    }
+    for (int e = 0; e < 9; ++e) cov[e] /= (double) (k - 1);                    // (:1688-1689)
+    H = 0.5 * std::log(2 * M_PI * M_E * det3(cov));                             // (:1656)
+    return !std::isnan(H) && !std::isinf(H);                                    // (:1692)
+}
+
+}  // namespace
+
+struct orc_voxelmap {
+    VoxelMap map;
+    double voxel_size = 0;
+    double total_entropy = 0, total_energy = 0;
+};
+
+extern "C" {
+
+orc_kdtree *orc_kdtree_build(const double *xyz, int64_t n) {
+    auto *t = new orc_kdtree();
+    t->pts = xyz;
+    t->n = n;
+    t->vind.resize((size_t) n);
+    std::iota(t->vind.begin(), t->vind.end(), 0);
+    if (n > 0) {
+        for (int d = 0; d < 3; ++d) {
+            double mn = xyz[d], mx = mn;
+            for (int64_t i = 1; i < n; ++i) {
+                mn = std::min(mn, xyz[3 * i + d]);
+                mx = std::max(mx, xyz[3 * i + d]);
+            }
+            t->bb_lo[d] = mn;
+            t->bb_hi[d] = mx;
+        }
+        t->nodes.reserve((size_t) (n / 4 + 16));
+        double lo[3] = {t->bb_lo[0], t->bb_lo[1], t->bb_lo[2]}, hi[3] = {t->bb_hi[0], t->bb_hi[1], t->bb_hi[2]};
+        t->root = t->build(0, (int32_t) n, lo, hi);
+    }
+    return t;
+}
+
+void orc_kdtree_free(orc_kdtree *t) { delete t; }
+
+void orc_kdtree_nn1(const orc_kdtree *t, const double *q, int64_t m, int32_t *idx, double *d2, int threads) {
+    const int nt = resolve_threads(threads);  // 1 = serial, 0 = all cores
+#pragma omp parallel for schedule(static) num_threads(nt) if (nt > 1)
+    for (int64_t i = 0; i < m; ++i) {
+        int32_t bi;
+        double bd;
+        t->nn1(q + 3 * i, bi, bd);
+        if (idx) idx[i] = bi;
+        if (d2) d2[i] = bd;
+    }
+}
+
+void orc_kdtree_radius_count(const orc_kdtree *t, const double *q, int64_t m, double r, int32_t *count,
+                             int threads) {
+    const int nt = resolve_threads(threads);  // 1 = serial, 0 = all cores
+    const double r2 = r * r;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nt) if (nt > 1)
+    for (int64_t i = 0; i < m; ++i) {
+        int32_t c = 0;
+        t->radius(q + 3 * i, r2, [&](int32_t, double) { ++c; });
+        count[i] = c;
+    }
+}
+
+void orc_transform(double *xyz, int64_t n, const double T[16]) {
+    // Open3D PointCloud::Transform [upstream]: new = T * (x,y,z,1); p = new.head<3>() / new(3).
+    // Column-major accumulation order of Eigen's 4x4 * 4x1 product: ((c0*x + c1*y) + c2*z) + c3*1.
+    for (int64_t i = 0; i < n; ++i) {
+        const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        double h[4];
+        for (int r = 0; r < 4; ++r) h[r] = ((T[4 * r] * x + T[4 * r + 1] * y) + T[4 * r + 2] * z) + T[4 * r + 3];
+        xyz[3 * i] = h[0] / h[3];
+        xyz[3 * i + 1] = h[1] / h[3];
+        xyz[3 * i + 2] = h[2] / h[3];
+    }
+}
+
+void orc_reg_stats_run(const double *src, int64_t ns, const double *tgt, int64_t nt_, double gate, int gate_mode,
+                       const double trunc[5], orc_reg_stats *out, int threads) {
+    orc_kdtree *tree = orc_kdtree_build(tgt, nt_);
+    std::vector<double> d2((size_t) ns);
+    std::vector<int32_t> idx((size_t) ns);
+    orc_kdtree_nn1(tree, src, ns, idx.data(), d2.data(), threads);  // (:1215-1223), serial in the reference
+    orc_kdtree_free(tree);
+
+    std::memset(out, 0, sizeof(*out));
+    out->n_src = ns;
+    std::vector<double> dis;  // est_gt_dis (:1076)
+    dis.reserve((size_t) ns);
+    double number[5] = {0}, mean[5] = {0}, rmse[5] = {0};
+    double sum_sqrt_all = 0;
+    for (int64_t i = 0; i < ns; ++i) {
+        if (idx[i] < 0) continue;  // SearchKNN(...) > 0
+        sum_sqrt_all += std::sqrt(d2[i]);  // computeChamferDistance (:1416), ungated
+        bool keep;
+        if (gate < 0) keep = true;
+        else if (gate_mode == 0) keep = d2[i] <= gate;          // (:1219) squared vs un-squared, sic
+        else keep = d2[i] < gate * gate;                         // Open3D hybrid search [upstream]
+        if (!keep) continue;
+        const double norm_dis = std::sqrt(d2[i]);  // (map_pt - gt_pt).norm() (:1095)
+        const double squre_dis = d2[i];            // squaredNorm (:1096)
+        dis.push_back(norm_dis);
+        for (int k = 0; k < 5; ++k)
+            if (norm_dis <= trunc[k]) {  // (:1099-1123)
+                mean[k] += norm_dis;
+                rmse[k] += squre_dis;
+                number[k] += 1.0;
+            }
+    }
+    const double C = (double) dis.size();
+    out->n_corr = (int64_t) dis.size();
+    out->sum_sqrt_all = sum_sqrt_all;
+    for (int k = 0; k < 5; ++k) {
+        mean[k] /= C;  // (:1125)  NaN when C == 0, as the reference
+        rmse[k] /= C;  // (:1126)
+        out->number[k] = number[k];
+        out->mean[k] = mean[k];
+        out->fitness[k] = number[k] * 1.0 / (double) ns;  // (:1130) denominator = source.size()
+        out->rmse[k] = std::sqrt(rmse[k]);                // (:1131)
+        double sigma = 0.0;
+        for (size_t j = 0; j < dis.size(); ++j) {
+            const double e = dis[j] - mean[k];
+            sigma += e * e;  // std::pow(error_dis, 2) (:1135)
+        }
+        sigma /= C;                       // (:1137)
+        out->sigma[k] = std::sqrt(sigma);  // (:1138)
+    }
+}
+
+double orc_chamfer(const double *a, int64_t na, const double *b, int64_t nb, int threads) {
+    // map_eval.cpp:1398-1431
+    orc_kdtree *ta = orc_kdtree_build(a, na);
+    orc_kdtree *tb = orc_kdtree_build(b, nb);
+    const int nt = resolve_threads(threads);
+    double sum_p_to_q = 0.0, sum_q_to_p = 0.0;
+#pragma omp parallel for reduction(+ : sum_p_to_q) num_threads(nt)
+    for (int64_t i = 0; i < na; ++i) {
+        int32_t bi;
+        double bd;
+        tb->nn1(a + 3 * i, bi, bd);
+        if (bi >= 0) sum_p_to_q += std::sqrt(bd);
+    }
+#pragma omp parallel for reduction(+ : sum_q_to_p) num_threads(nt)
+    for (int64_t i = 0; i < nb; ++i) {
+        int32_t bi;
+        double bd;
+        ta->nn1(b + 3 * i, bi, bd);
+        if (bi >= 0) sum_q_to_p += std::sqrt(bd);
+    }
+    orc_kdtree_free(ta);
+    orc_kdtree_free(tb);
+    return sum_p_to_q / (double) na + sum_q_to_p / (double) nb;  // (:1429)
+}
+
+double orc_mme(const double *xyz, int64_t n, double radius, int min_k, double *entropies, uint8_t *valid,
+               int64_t *n_valid, double *sum_entropy, int mode, int threads) {
+    orc_kdtree *tree = orc_kdtree_build(xyz, n);  // (:1618-1619)
+    const double r2 = radius * radius;            // Open3D SearchRadius -> radiusSearch(q, r*r) [upstream]
+    if (entropies) std::fill(entropies, entropies + n, 0.0);  // (:1614)
+    if (valid) std::fill(valid, valid + n, (uint8_t) 0);      // (:1615)
+    double sum = 0.0;
+    int64_t count = 0;
+    const int nt = (mode == 0) ? 1 : resolve_threads(threads);
+    if (mode == 0 || nt == 1) {
+        std::vector<std::pair<double, int32_t>> nb;
+        for (int64_t i = 0; i < n; ++i) {
+            double H;
+            if (mme_point(*tree, i, r2, min_k, nb, H)) {
+                sum += H;
+                if (entropies) entropies[i] = H;
+                if (valid) valid[i] = 1;
+                ++count;
+            }
+        }
+    } else if (mode == 1) {
+        // ComputeMeanMapEntropyUsingNormal (:1553): #pragma omp parallel for reduction(+)
+#pragma omp parallel num_threads(nt) reduction(+ : sum, count)
+        {
+            std::vector<std::pair<double, int32_t>> nb;
+#pragma omp for
+            for (int64_t i = 0; i < n; ++i) {
+                double H;
+                if (mme_point(*tree, i, r2, min_k, nb, H)) {
+                    sum += H;
+                    if (entropies) entropies[i] = H;
+                    if (valid) valid[i] = 1;
+                    ++count;
+                }
+            }
+        }
+    } else {
+        // tbb::parallel_reduce over blocked_range(0, N, grain), grain = max(1, N/(8*hw_threads)) (:1716-1717):
+        // independent per-range partial sums joined afterwards (:1704-1708).
+        const int64_t grain = std::max<int64_t>(1, n / (8 * (int64_t) nt));
+        const int64_t nblocks = (n + grain - 1) / grain;
+        std::vector<double> psum((size_t) nblocks, 0.0);
+        std::vector<int64_t> pcnt((size_t) nblocks, 0);
+#pragma omp parallel num_threads(nt)
+        {
+            std::vector<std::pair<double, int32_t>> nb;
+            nb.reserve(100);  // (:1663)
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t b = 0; b < nblocks; ++b) {
+                const int64_t lo = b * grain, hi = std::min(n, lo + grain);
+                double s = 0.0;
+                int64_t c = 0;
+                for (int64_t i = lo; i < hi; ++i) {
+                    double H;
+                    if (mme_point(*tree, i, r2, min_k, nb, H)) {
+                        s += H;
+                        if (entropies) entropies[i] = H;
+                        if (valid) valid[i] = 1;
+                        ++c;
+                    }
+                }
+                psum[(size_t) b] = s;
+                pcnt[(size_t) b] = c;
+            }
+        }
+        for (int64_t b = 0; b < nblocks; ++b) {
+            sum += psum[(size_t) b];
+            count += pcnt[(size_t) b];
+        }
+    }
+    orc_kdtree_free(tree);
+    if (n_valid) *n_valid = count;
+    if (sum_entropy) *sum_entropy = sum;
+    return count > 0 ? sum / (double) count : 0.0;  // (:1720-1724)
+}
+
+orc_voxelmap *orc_voxel_build(const double *xyz, int64_t n, double voxel_size) {
+    // VoxelCalculator::buildVoxelMap(open3d) voxel_calculator.cpp:21-56
+    auto *vm = new orc_voxelmap();
+    vm->voxel_size = voxel_size;
+    VoxelMap &map = vm->map;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *p = xyz + 3 * i;
+        Key3 key{{voxel_index(p[0], voxel_size), voxel_index(p[1], voxel_size), voxel_index(p[2], voxel_size)}};
+        auto it = map.find(key);
+        if (it == map.end()) {
+            VoxelInfo v;
+            v.num_points = 1;
+            v.mu[0] = p[0];
+            v.mu[1] = p[1];
+            v.mu[2] = p[2];
+            v.active = 1;
+            map.emplace(key, v);
+        } else {
+            VoxelInfo &v = it->second;
+            v.num_points++;
+            const double delta[3] = {p[0] - v.mu[0], p[1] - v.mu[1], p[2] - v.mu[2]};  // (:39)
+            for (int d = 0; d < 3; ++d) v.mu[d] += delta[d] / v.num_points;             // (:40)
+            const double d2[3] = {p[0] - v.mu[0], p[1] - v.mu[1], p[2] - v.mu[2]};
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) v.sigma[3 * r + c] += delta[r] * d2[c];     // (:41)
+            v.energy = v.sigma[0] + v.sigma[4] + v.sigma[8];
+        }
+    }
+    for (auto &kv : map) {
+        VoxelInfo &v = kv.second;
+        if (v.num_points > 10) {                                                         // (:47)
+            for (int e = 0; e < 9; ++e) v.sigma[e] /= (double) (v.num_points - 1);       // first division (:48)
+            compute_voxel_entropy(v);                                                    // second division
+            v.entropy_old = v.entropy;
+            vm->total_entropy += v.entropy;
+            vm->total_energy += v.energy;
+        }
+    }
+    return vm;
+}
+
+void orc_voxel_free(orc_voxelmap *m) { delete m; }
+int64_t orc_voxel_count(const orc_voxelmap *m) { return (int64_t) m->map.size(); }
+
+void orc_voxel_export(const orc_voxelmap *m, int32_t *keys, int32_t *npts, double *mu, double *sigma,
+                      double *entropy) {
+    const auto ent = sorted_entries(m->map);
+    for (size_t i = 0; i < ent.size(); ++i) {
+        const VoxelInfo &v = *ent[i].second;
+        if (keys)
+            for (int d = 0; d < 3; ++d) keys[3 * i + d] = ent[i].first.v[d];
+        if (npts) npts[i] = v.num_points;
+        if (mu)
+            for (int d = 0; d < 3; ++d) mu[3 * i + d] = v.mu[d];
+        if (sigma)
+            for (int e = 0; e < 9; ++e) sigma[9 * i + e] = v.sigma[e];
+        if (entropy) entropy[i] = v.entropy;
+    }
+}
+
+double orc_w2_gaussian(const double mu1[3], const double sigma1[9], int n1, const double mu2[3],
+                       const double sigma2[9], int n2) {
+    VoxelInfo a, b;
+    std::memcpy(a.mu, mu1, sizeof(a.mu));
+    std::memcpy(a.sigma, sigma1, sizeof(a.sigma));
+    a.num_points = n1;
+    std::memcpy(b.mu, mu2, sizeof(b.mu));
+    std::memcpy(b.sigma, sigma2, sizeof(b.sigma));
+    b.num_points = n2;
+    return w2_gaussian(a, b);
+}
+
+int orc_awd_scs(const orc_voxelmap *gt, const orc_voxelmap *est, double voxel_size, int min_pts, int scs_radius,
+                double *rows, double *w_sorted, int64_t *n_rows, double *awd, double *scs, int64_t counts[3]) {
+    // updateVoxelMap(gt_map) voxel_calculator.cpp:142-172 — labels only (the est map itself is not mutated here;
+    // inserted empty "old" voxels never reach the W loop because they have num_points 0 < 100).
+    int64_t active = 0, old_area = 0, new_area = 0;
+    for (const auto &kv : gt->map) {
+        if (est->map.find(kv.first) != est->map.end()) active++;
+        else old_area++;
+    }
+    new_area = (int64_t) est->map.size() - active;
+    if (counts) {
+        counts[0] = active;
+        counts[1] = old_area;
+        counts[2] = new_area;
+    }
+    std::unordered_map<Key3, double, KeyHash> wd;  // wasserstein_distances (map_eval.cpp:266)
+    const auto ent = sorted_entries(est->map);
+    const int64_t cap = n_rows ? *n_rows : 0;
+    int64_t nr = 0;
+    std::vector<double> ws;
+    for (const auto &e : ent) {
+        const VoxelInfo &ev = *e.second;
+        auto git = gt->map.find(e.first);  // active == 1 <=> key in gt map (:274-276)
+        if (git == gt->map.end()) continue;
+        const VoxelInfo &gv = git->second;
+        if (ev.num_points < min_pts || gv.num_points < min_pts) continue;  // (:280)
+        const double w = w2_gaussian(gv, ev);                              // (:284) (gt, est) order
+        wd[e.first] = w;
+        ws.push_back(w);
+        if (rows && nr < cap) {
+            double *r = rows + 27 * nr;  // column order of voxel_errors.txt (:292-302)
+            for (int d = 0; d < 3; ++d) r[d] = (double) e.first.v[d] * voxel_size;
+            for (int d = 0; d < 3; ++d) r[3 + d] = ((double) e.first.v[d] + 1.0) * voxel_size;
+            for (int d = 0; d < 3; ++d) r[6 + d] = ev.mu[d];
+            r[9] = w;
+            r[10] = gv.num_points;
+            r[11] = ev.num_points;
+            r[12] = ev.sigma[0]; r[13] = ev.sigma[1]; r[14] = ev.sigma[2];
+            r[15] = ev.sigma[4]; r[16] = ev.sigma[5]; r[17] = ev.sigma[8];
+            for (int d = 0; d < 3; ++d) r[18 + d] = gv.mu[d];
+            r[21] = gv.sigma[0]; r[22] = gv.sigma[1]; r[23] = gv.sigma[2];
+            r[24] = gv.sigma[4]; r[25] = gv.sigma[5]; r[26] = gv.sigma[8];
+        }
+        ++nr;
+    }
+    if (n_rows) *n_rows = nr;
+    const double mean_ws = std::accumulate(ws.begin(), ws.end(), 0.0) / (double) ws.size();  // (:324) NaN if empty
+    if (awd) *awd = mean_ws;
+    if (w_sorted) {
+        std::sort(ws.begin(), ws.end());  // (:330)
+        for (int64_t i = 0; i < std::min<int64_t>(cap, (int64_t) ws.size()); ++i) w_sorted[i] = ws[(size_t) i];
+    }
+    if (scs) *scs = scs_from_map(wd, scs_radius);
+    return 0;
+}
+
+double orc_scs(const int32_t *keys, const double *w, int64_t n, int radius) {
+    std::unordered_map<Key3, double, KeyHash> wd;
+    for (int64_t i = 0; i < n; ++i) wd[Key3{{keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]}}] = w[i];
+    return scs_from_map(wd, radius);
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+/*
+ * mapeval_oracle.h — CPU ORACLE for the MapEval metric hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a dependency-free restatement of the reference's CPU algorithm
+ * (JokerJohn/Cloud_Map_Evaluation, map_eval/src/map_eval.cpp and voxel_calculator.cpp).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call it.
+ * The product (libmapeval_hip.so) never does.
+ *
+ * PARITY PINNING: the reference ships no tests.  The AWD / CDF / SCS legs are pinned against the
+ * reference's own run output (map_eval/scripts/voxel_errors.txt, voxel_wasserstein_cdf.txt, and the
+ * README screenshot VMD 0.35303 / SCS 0.78121) -> tests/golden/.  The KD-tree, AC/COM/CD and MME
+ * legs are "parity unpinned" by the reference (no golden vectors exist, and the reference cannot be
+ * built here: Open3D/PCL/TBB/yaml-cpp are absent); they are cross-checked against brute-force numpy
+ * and scipy.spatial.cKDTree in tests/test_oracle_*.py.
+ *
+ * Third-party arithmetic restated here (sources not vendored in the reference tree):
+ *   Open3D geometry::KDTreeFlann (stated 0.15.1, CI 0.17.0) -> nanoflann KD-tree, L2, leaf 15:
+ *     SearchKNN(k=1) returns the SQUARED distance ((dx*dx + dy*dy) + dz*dz) in fp64,
+ *     SearchRadius(q, r) returns all points with d2 < r*r sorted ascending.
+ *   Eigen 3.3.7: Matrix3d::determinant (cofactor expansion along row 0),
+ *     SelfAdjointEigenSolver<Matrix3d> (restated as cyclic Jacobi), LLT (Cholesky, no pivoting).
+ */
+#ifndef MAPEVAL_ORACLE_H
+#define MAPEVAL_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_kdtree orc_kdtree;
+typedef struct orc_voxelmap orc_voxelmap;
+
+/* Result block of getDiffRegResultWithCorrespondence (map_eval.cpp:1069-1145). */
+typedef struct orc_reg_stats {
+    int64_t n_src;        /* source.points_.size()                                 */
+    int64_t n_corr;       /* C = points_set.size()                                 */
+    double number[5];     /* number_vec  (:1102 ...)                               */
+    double mean[5];       /* mean_vec / C                 (:1125)                  */
+    double rmse[5];       /* sqrt(rmse_vec / C)           (:1126,:1131)            */
+    double fitness[5];    /* number / source.size()       (:1128-1130)             */
+    double sigma[5];      /* sqrt(sum_all (d-mean_k)^2/C) (:1132-1138)             */
+    double sum_sqrt_all;  /* sum over ALL source points of sqrt(d2) (CD, :1416)    */
+} orc_reg_stats;
+
+/* ---- KD-tree (map_eval.cpp:1213-1214 SetGeometry; :1218 SearchKNN; :1670 SearchRadius) ---- */
+orc_kdtree *orc_kdtree_build(const double *xyz, int64_t n);
+void orc_kdtree_free(orc_kdtree *t);
+/* 1-NN for m queries; idx/d2 may be NULL. threads 1 -> serial (as :1215), 0 -> all cores, n -> n (OpenMP, as :1411). */
+void orc_kdtree_nn1(const orc_kdtree *t, const double *q, int64_t m, int32_t *idx, double *d2, int threads);
+/* number of points with d2 < r*r (includes the query itself if it is a tree point). */
+void orc_kdtree_radius_count(const orc_kdtree *t, const double *q, int64_t m, double r, int32_t *count,
+                             int threads);
+
+/* ---- Transform (map_eval.cpp:1206; Open3D PointCloud::Transform, homogeneous divide) ---- */
+void orc_transform(double *xyz, int64_t n, const double T_rowmajor[16]);
+
+/* ---- AC / COM (map_eval.cpp:1204-1260 + :1069-1145); gate_mode 0: d2 <= gate (sic, :1219),
+ *      gate_mode 1: d2 < gate*gate (Open3D EvaluateRegistration, :1168); gate < 0: no gate. ---- */
+void orc_reg_stats_run(const double *src, int64_t ns, const double *tgt, int64_t nt, double gate,
+                       int gate_mode, const double trunc[5], orc_reg_stats *out, int threads);
+
+/* ---- Chamfer distance (map_eval.cpp:1398-1431) ---- */
+double orc_chamfer(const double *a, int64_t na, const double *b, int64_t nb, int threads);
+
+/* ---- MME (map_eval.cpp:1608-1737 est / k>=10; :1438-1535 gt / k>=5, serial) ----
+ * mode 0: serial loop (:1451); mode 1: OpenMP parallel-for reduction (:1553);
+ * mode 2: block-range reduction with grain N/(8*threads) (stand-in for tbb::parallel_reduce, :1716).
+ * entropies[N] (0.0 where invalid) and valid[N] may be NULL. Returns mean entropy (0 if none valid). */
+double orc_mme(const double *xyz, int64_t n, double radius, int min_k, double *entropies, uint8_t *valid,
+               int64_t *n_valid, double *sum_entropy, int mode, int threads);
+
+/* ---- Voxel Gaussians (voxel_calculator.cpp:21-56, :97-113, :241-245) ---- */
+orc_voxelmap *orc_voxel_build(const double *xyz, int64_t n, double voxel_size);
+void orc_voxel_free(orc_voxelmap *m);
+int64_t orc_voxel_count(const orc_voxelmap *m);
+/* export in ascending (ix,iy,iz) key order: keys[V][3], npts[V], mu[V][3], sigma[V][9] AS STORED
+ * (i.e. M2/(n-1)^2 for n>10, raw M2 otherwise), entropy[V]; any pointer may be NULL. */
+void orc_voxel_export(const orc_voxelmap *m, int32_t *keys, int32_t *npts, double *mu, double *sigma,
+                      double *entropy);
+
+/* ---- Gaussian "Wasserstein" (voxel_calculator.cpp:115-140); sigma = stored 3x3 row-major ---- */
+double orc_w2_gaussian(const double mu1[3], const double sigma1[9], int n1, const double mu2[3],
+                       const double sigma2[9], int n2);
+
+/* ---- AWD + CDF + SCS driver (map_eval.cpp:240-390). rows: n_rows x 27 doubles in the column order
+ * of voxel_errors.txt (:292-302), ascending key order; w_sorted: ascending W (CDF, :330).
+ * *n_rows in: capacity, out: count. Returns 0. counts[3] = active/old/new (voxel_calculator.cpp:142-172). */
+int orc_awd_scs(const orc_voxelmap *gt, const orc_voxelmap *est, double voxel_size, int min_pts,
+                int scs_radius, double *rows, double *w_sorted, int64_t *n_rows, double *awd, double *scs,
+                int64_t counts[3]);
+
+/* SCS alone from a sparse W table (map_eval.cpp:347-389): keys[n][3], w[n]. */
+double orc_scs(const int32_t *keys, const double *w, int64_t n, int radius);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
