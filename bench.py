@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json metric: Mpts/s for the full metric suite (AC/COM/CD + MME + AWD/SCS) on a map pair.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run,
+one rank per GPU over RCCL.  One "step" = one pass of the whole hot path over the synthetic pair, starting from the
+two clouds RESIDENT IN HBM (raw, unsorted fp64 AoS) and ending with every scalar on the host: Morton sort + index
+build, both 1-NN passes + AC/COM/CD statistics, est-MME (+ GT-MME), voxel Gaussians, AWD, CDF sort, SCS.
+Strong scaling: every rank holds the pair, processes its Morton slab of the per-point passes, and the partial sums
+are all-reduced (RCCL); value = (N_est + N_gt) / max-over-ranks step time.
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed inside this process) and
+"cpu_baseline" (the CPU oracle = port of the reference's CPU path, timed on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# algorithmic (compulsory) bytes per unit of work
+BYTES_PER_NN_QUERY = 60.0   # 24 B query + 24 B reference point + 12 B result (M = N)
+BYTES_PER_MME_QUERY = 33.0  # 24 B point + 8 B entropy + 1 B valid
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=50_000_000, help="GT points (est is ~15 %% thinner)")
+    ap.add_argument("--density", type=float, default=2500.0, help="surface density, points / m^2")
+    ap.add_argument("--nn-radius", type=float, default=0.1)
+    ap.add_argument("--voxel", type=float, default=3.0)
+    ap.add_argument("--no-gt-mme", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="GT points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme):
+    """One full pass; returns the scalars.  All ranks run it; per-point passes are slab-sharded."""
+    import numpy as np
+
+    from cloud_map_evaluation_amd.engine import ME_GATE_LE_UNSQUARED, ME_SLOT_EST, ME_SLOT_GT
+
+    eng.upload(ME_SLOT_EST, est_d, T=np.eye(4), cell_size=P.nn_radius_)  # initial_matrix (identity) + index
+    eng.upload(ME_SLOT_GT, gt_d, cell_size=P.nn_radius_)
+    # --- MME (map_eval.cpp:56) ---
+    m_e = eng.mme(ME_SLOT_EST, P.nn_radius_, 10, per_point=False)
+    m_g = eng.mme(ME_SLOT_GT, P.nn_radius_, 5, per_point=False) if evaluate_gt_mme else (0.0, None, None, 0, 0.0)
+    # --- AC / COM / CD (map_eval.cpp:76, :1194) ---
+    parts = []
+    for q, r in ((ME_SLOT_EST, ME_SLOT_GT), (ME_SLOT_GT, ME_SLOT_EST)):
+        eng.nn1(q, r, fetch=False)
+        parts.append(eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_))
+    vec = []
+    for pp in parts:
+        vec += [pp.n_corr] + list(pp.n_inl) + list(pp.sum_d) + list(pp.sum_d2) + [pp.sum_sqrt_all]
+    vec += [m_e[4], m_e[3], m_g[4], m_g[3]]
+    vec = np.array(vec, dtype=np.float64)  # counts < 2^53: exact in fp64
+    if world > 1:
+        import torch
+
+        t = torch.from_numpy(vec).cuda()
+        dist.all_reduce(t)  # RCCL sum of the shard partials
+        vec = t.cpu().numpy()
+    stats = []
+    for i, (q, n_src) in enumerate(((ME_SLOT_EST, n_e), (ME_SLOT_GT, n_g))):
+        o = i * 17
+        C = vec[o]
+        mean = vec[o + 6:o + 11] / C if C > 0 else np.full(5, np.nan)
+        sig = eng.nn_sigma_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, mean)
+        if world > 1:
+            import torch
+
+            t = torch.from_numpy(sig).cuda()
+            dist.all_reduce(t)
+            sig = t.cpu().numpy()
+        stats.append(dict(n_corr=int(C), number=vec[o + 1:o + 6].copy(), mean=mean,
+                          rmse=np.sqrt(vec[o + 11:o + 16] / C) if C > 0 else np.full(5, np.nan),
+                          fitness=vec[o + 1:o + 6] / n_src, sigma=np.sqrt(sig / C) if C > 0 else np.full(5, np.nan),
+                          mean_nn=vec[o + 16] / n_src))
+    cd = stats[0]["mean_nn"] + stats[1]["mean_nn"]
+    mme_est = vec[34] / vec[35] if vec[35] > 0 else 0.0
+    mme_gt = vec[36] / vec[37] if vec[37] > 0 else 0.0
+    # --- AWD / SCS (map_eval.cpp:85) — voxel tables are small; every rank computes them (no exchange needed) ---
+    v = eng.calculateVMD(P.vmd_voxel_size_, rows=False)
+    return dict(ac=stats[0]["rmse"], com=stats[0]["fitness"], cd=cd, mme_est=mme_est, mme_gt=mme_gt, awd=v["awd"],
+                scs=v["scs"], n_w=v["n_rows"], mme_valid=int(vec[35]))
+
+
+def cpu_baseline(args, P, evaluate_gt_mme):
+    """The oracle (port of the reference CPU path, same parallel structure: OpenMP CD, block-range MME, serial
+    AC/COM loops, serial GT-MME, serial voxel build) on a bounded sample of the same scene generator."""
+    import oracle
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.campus_pair(args.cpu_sample, density=args.density, seed=100)
+    est, gt = est.numpy(), gt.numpy()
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    oracle.mme(est, P.nn_radius_, 10, mode=2, threads=0)                       # TBB-like (map_eval.cpp:1717)
+    if evaluate_gt_mme:
+        oracle.mme(gt, P.nn_radius_, 5, mode=0, threads=1)                     # serial (map_eval.cpp:1451)
+    oracle.reg_stats(est, gt, P.icp_max_distance_, 0, P.trunc_dist_, threads=1)  # serial (map_eval.cpp:1215)
+    oracle.reg_stats(gt, est, P.icp_max_distance_, 0, P.trunc_dist_, threads=1)  # serial (map_eval.cpp:1228)
+    oracle.chamfer(est, gt, threads=0)                                         # OpenMP (map_eval.cpp:1411)
+    g, e = oracle.VoxelMap(gt, P.vmd_voxel_size_), oracle.VoxelMap(est, P.vmd_voxel_size_)  # serial (voxel_calculator.cpp:25)
+    oracle.awd_scs(g, e)
+    dt = time.perf_counter() - t0
+    n = len(est) + len(gt)
+    return {"value": n / 1e6 / dt, "unit": "Mpts/s", "cores": cores, "kind": "port",
+            "sample": f"campus_pair GT={len(gt)} est={len(est)} pts, same density/radius/voxel, full suite, {dt:.1f} s wall"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from cloud_map_evaluation_amd import synth
+    from cloud_map_evaluation_amd.engine import Engine, Param
+
+    evaluate_gt_mme = not args.no_gt_mme
+    P = Param(icp_max_distance_=1.0, nn_radius_=args.nn_radius, vmd_voxel_size_=args.voxel,
+              evaluate_gt_mme_=evaluate_gt_mme)
+    # synthetic, seeded, generated directly in HBM (identical on every rank)
+    est_d, gt_d = synth.campus_pair(args.points, density=args.density, seed=100, device=dev)
+    n_e, n_g = est_d.shape[0], gt_d.shape[0]
+    torch.cuda.synchronize()
+
+    eng = Engine(local_rank)
+    eng.set_shard(rank, world)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / max(1, args.steps) * 1e3
+    value = (n_e + n_g) / 1e6 / (ms_per_step / 1e3)
+
+    line = {
+        "metric": "Mpts/sec full metric suite (CD+MME+AWD) on 50M-pt pair",
+        "value": value, "unit": "Mpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"campus_pair GT={n_g} est={n_e} pts @ {args.density:g} pts/m^2 (seed 100): AC/COM/CD + "
+                               f"est-MME{'+GT-MME' if evaluate_gt_mme else ''} (r={args.nn_radius}) + voxel Gaussians/AWD/CDF/SCS "
+                               f"(voxel={args.voxel}), clouds resident in HBM, index build included",
+                   "n_est": n_e, "n_gt": n_g, "nn_radius": args.nn_radius, "vmd_voxel_size": args.voxel,
+                   "parallelism": f"morton-slab x{world} (replicated reference, all-reduced partial sums)"},
+        "results": {"AC": [float(x) for x in res["ac"]], "COM": [float(x) for x in res["com"]], "CD": float(res["cd"]),
+                    "MME_est": float(res["mme_est"]), "MME_gt": float(res["mme_gt"]), "AWD": float(res["awd"]),
+                    "SCS": float(res["scs"]), "W_voxels": int(res["n_w"]), "MME_valid": res["mme_valid"]},
+    }
+
+    # ---- roofline of the dominant kernel: HIP events on the library's own stream, one extra (untimed) step ----
+    if not args.no_roofline:
+        eng.timers_enable(True)
+        eng.timers_reset()
+        suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme)
+        fam = {}
+        for name in ("nn1", "mme", "sort", "morton", "gather", "bvh", "cells", "nn_stats", "voxel_keys", "voxel", "w2", "scs"):
+            ms, cnt = eng.timer(name)
+            if cnt:
+                fam[name] = (ms, cnt)
+        eng.timers_enable(False)
+        if rank == 0 and fam:
+            dom = max(fam, key=lambda k: fam[k][0])
+            ms, cnt = fam[dom]
+            avg_ms = ms / cnt
+            shard = 1.0 / world
+            if dom == "mme":
+                units = (n_e + (n_g if evaluate_gt_mme else 0)) * shard / cnt
+                alg_bytes = BYTES_PER_MME_QUERY * units
+            elif dom == "nn1":
+                units = (n_e + n_g) * shard / cnt
+                alg_bytes = BYTES_PER_NN_QUERY * units
+            else:
+                units = (n_e + n_g) / cnt
+                alg_bytes = 24.0 * units
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(dom)
+                except Exception:
+                    traffic = None
+            line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                                "units_per_launch": units, "algorithmic_bytes_per_launch": alg_bytes,
+                                "kernel_ms_per_step": {k: v[0] for k, v in fam.items()},
+                                "queries_per_s": {"nn1": (n_e + n_g) * shard / (fam["nn1"][0] * 1e-3) if "nn1" in fam else None,
+                                                  "mme": (n_e + (n_g if evaluate_gt_mme else 0)) * shard / (fam["mme"][0] * 1e-3)
+                                                  if "mme" in fam else None}}
+
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        line["cpu_baseline"] = cpu_baseline(args, P, evaluate_gt_mme)
+
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,282 @@
+// me_api.hip — the extern "C" surface declared in include/mapeval_hip.h (context, timers, call sequencing).
+#include <cmath>
+#include <cstring>
+
+#include "me_internal.hpp"
+
+static std::string g_create_error;
+
+hipEvent_t me_ctx::get_event() {
+    if (!event_pool.empty()) {
+        hipEvent_t e = event_pool.back();
+        event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void) hipEventCreate(&e);
+    return e;
+}
+
+void me_ctx::timer_begin(const char *name) {
+    if (!timers_on) return;
+    Pending p;
+    p.name = name;
+    p.a = get_event();
+    p.b = get_event();
+    (void) hipEventRecord(p.a, stream);
+    pending.push_back(p);
+}
+
+void me_ctx::timer_end() {
+    if (!timers_on || pending.empty()) return;
+    // the most recent un-closed scope (scopes do not nest)
+    (void) hipEventRecord(pending.back().b, stream);
+}
+
+void me_ctx::timers_collect() {
+    if (pending.empty()) return;
+    (void) hipStreamSynchronize(stream);
+    for (auto &p : pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &t = timers[p.name];
+            t.total_ms += ms;
+            t.launches += 1;
+        }
+        event_pool.push_back(p.a);
+        event_pool.push_back(p.b);
+    }
+    pending.clear();
+}
+
+extern "C" {
+
+int me_version(void) { return 100; }
+
+me_ctx *me_create(int device, int flags) {
+    (void) flags;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("me_create: no HIP device available (") + hipGetErrorString(e) +
+                         "); libmapeval_hip has no CPU fallback";
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        g_create_error = "me_create: device ordinal out of range";
+        return nullptr;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        g_create_error = std::string("me_create: hipSetDevice: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    me_ctx *ctx = new me_ctx();
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_create_error = std::string("me_create: hipStreamCreate: ") + hipGetErrorString(e);
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void me_destroy(me_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending) {
+        (void) hipEventDestroy(p.a);
+        (void) hipEventDestroy(p.b);
+    }
+    for (auto e : ctx->event_pool) (void) hipEventDestroy(e);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *me_last_error(me_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int me_set_shard(me_ctx *ctx, int rank, int world) {
+    if (!ctx) return ME_ERR_ARG;
+    if (world < 1 || rank < 0 || rank >= world) return ctx->fail(ME_ERR_ARG, "me_set_shard: need 0 <= rank < world");
+    ctx->shard_rank = rank;
+    ctx->shard_world = world;
+    return ME_OK;
+}
+
+int me_upload_cloud(me_ctx *ctx, int slot, const double *xyz_host, int64_t n, const double *T, double cell_size) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::cloud_upload(ctx, slot, xyz_host, false, n, T, cell_size);
+}
+
+int me_upload_cloud_device(me_ctx *ctx, int slot, const double *xyz_device, int64_t n, const double *T, double cell_size) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::cloud_upload(ctx, slot, xyz_device, true, n, T, cell_size);
+}
+
+int64_t me_cloud_size(me_ctx *ctx, int slot) {
+    if (!ctx || slot < 0 || slot > 1 || !ctx->cloud[slot].uploaded) return -1;
+    return ctx->cloud[slot].n;
+}
+
+int me_download_cloud(me_ctx *ctx, int slot, double *xyz_host) {
+    if (!ctx) return ME_ERR_ARG;
+    if (slot < 0 || slot > 1 || !xyz_host) return ctx->fail(ME_ERR_ARG, "me_download_cloud: bad argument");
+    me::Cloud &c = ctx->cloud[slot];
+    if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "cloud not uploaded");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    ME_CHECK(ctx, hipMemcpyAsync(xyz_host, c.xyz.p, (size_t) c.n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
+int me_nn1(me_ctx *ctx, int query_slot, int ref_slot, int32_t *idx, double *d2) {
+    if (!ctx) return ME_ERR_ARG;
+    ME_TRY(me::nn_search(ctx, query_slot, ref_slot));
+    if (idx || d2) return me::nn_fetch(ctx, query_slot, idx, d2);
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
+int me_nn_partial_sums(me_ctx *ctx, int query_slot, double gate, int gate_mode, const double trunc[5], me_nn_partial *out) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::nn_partial(ctx, query_slot, gate, gate_mode, trunc, out);
+}
+
+int me_nn_sigma_sums(me_ctx *ctx, int query_slot, double gate, int gate_mode, const double mean[5], double sigma_num[5]) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::nn_sigma(ctx, query_slot, gate, gate_mode, mean, sigma_num);
+}
+
+void me_nn_finalize(const me_nn_partial *t, const double sigma_num[5], int64_t n_src_total, me_nn_stats_out *out) {
+    // map_eval.cpp:1125-1144.  C == 0 gives 0/0 = NaN for mean / rmse / sigma, exactly as the reference.
+    const double C = (double) t->n_corr;
+    out->n_src = n_src_total;
+    out->n_corr = t->n_corr;
+    for (int k = 0; k < 5; ++k) {
+        out->mean[k] = t->sum_d[k] / C;                                // mean_vec /= points_set.size()   (:1125)
+        out->rmse[k] = std::sqrt(t->sum_d2[k] / C);                    // sqrt(rmse_vec / size)           (:1126,:1131)
+        out->fitness[k] = (double) t->n_inl[k] * 1.0 / (double) n_src_total;  // number / source.size()   (:1130)
+        out->sigma[k] = std::sqrt(sigma_num[k] / C);                   // (:1137-1138)
+        out->number[k] = (double) t->n_inl[k];
+    }
+    out->mean_nn_dist = t->sum_sqrt_all / (double) n_src_total;        // sum / N (:1429)
+}
+
+int me_nn_stats(me_ctx *ctx, int query_slot, double gate, int gate_mode, const double trunc[5], me_nn_stats_out *out) {
+    if (!ctx) return ME_ERR_ARG;
+    if (!out) return ctx->fail(ME_ERR_ARG, "me_nn_stats: out is NULL");
+    if (ctx->shard_world != 1)
+        return ctx->fail(ME_ERR_STATE, "me_nn_stats is the single-GPU one-shot; use me_nn_partial_sums / me_nn_sigma_sums when sharded");
+    me_nn_partial p;
+    ME_TRY(me::nn_partial(ctx, query_slot, gate, gate_mode, trunc, &p));
+    double mean[5], sig[5];
+    for (int k = 0; k < 5; ++k) mean[k] = p.sum_d[k] / (double) p.n_corr;
+    ME_TRY(me::nn_sigma(ctx, query_slot, gate, gate_mode, mean, sig));
+    me_nn_finalize(&p, sig, ctx->cloud[query_slot].n, out);
+    return ME_OK;
+}
+
+int me_chamfer(me_ctx *ctx, double *cd) {
+    if (!ctx) return ME_ERR_ARG;
+    if (!cd) return ctx->fail(ME_ERR_ARG, "me_chamfer: cd is NULL");
+    if (ctx->shard_world != 1) return ctx->fail(ME_ERR_STATE, "me_chamfer is single-GPU; use the partial-sum calls when sharded");
+    const double tr[5] = {0, 0, 0, 0, 0};
+    me_nn_partial a, b;
+    ME_TRY(me::nn_search(ctx, ME_SLOT_EST, ME_SLOT_GT));
+    ME_TRY(me::nn_partial(ctx, ME_SLOT_EST, -1.0, 0, tr, &a));
+    ME_TRY(me::nn_search(ctx, ME_SLOT_GT, ME_SLOT_EST));
+    ME_TRY(me::nn_partial(ctx, ME_SLOT_GT, -1.0, 0, tr, &b));
+    *cd = a.sum_sqrt_all / (double) ctx->cloud[ME_SLOT_EST].n + b.sum_sqrt_all / (double) ctx->cloud[ME_SLOT_GT].n;  // (:1429)
+    return ME_OK;
+}
+
+int me_mme(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, uint8_t *valid, double *sum_H, int64_t *n_valid) {
+    if (!ctx) return ME_ERR_ARG;
+    long long nv = 0;
+    const int rc = me::mme_run(ctx, slot, radius, min_k, entropies, valid, sum_H, &nv);
+    if (n_valid) *n_valid = nv;
+    return rc;
+}
+
+int me_voxel_gaussians(me_ctx *ctx, int slot, double voxel_size, int32_t *keys, int32_t *npts, double *mu, double *sigma,
+                       double *entropy, int64_t *n_voxels) {
+    if (!ctx) return ME_ERR_ARG;
+    ME_TRY(me::voxel_build(ctx, slot, voxel_size));
+    return me::voxel_export(ctx, slot, keys, npts, mu, sigma, entropy, n_voxels);
+}
+
+int me_awd_scs(me_ctx *ctx, double voxel_size, int min_pts, int scs_radius, double *rows, double *w_sorted, int64_t *n_rows,
+               double *awd, double *scs, int64_t counts[3]) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::awd_scs(ctx, voxel_size, min_pts, scs_radius, rows, w_sorted, n_rows, awd, scs, counts);
+}
+
+int me_w2_batch(me_ctx *ctx, const double *mu1, const double *sigma1, const int32_t *n1, const double *mu2,
+                const double *sigma2, const int32_t *n2, int64_t count, double *w) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::w2_batch(ctx, mu1, sigma1, n1, mu2, sigma2, n2, count, w);
+}
+
+int me_scs_table(me_ctx *ctx, const int32_t *keys, const double *w, int64_t n, int scs_radius, double *scs) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::scs_table(ctx, keys, w, n, scs_radius, scs);
+}
+
+int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out) {
+    if (!ctx) return ME_ERR_ARG;
+    if (!p || !out) return ctx->fail(ME_ERR_ARG, "me_run_suite: NULL argument");
+    if (ctx->shard_world != 1) return ctx->fail(ME_ERR_STATE, "me_run_suite is single-GPU; drive the partial calls when sharded");
+    std::memset(out, 0, sizeof(*out));
+    // MME first, as MapEval::process (map_eval.cpp:52-66)
+    if (p->evaluate_mme) {
+        double s = 0;
+        int64_t nv = 0;
+        ME_TRY(me_mme(ctx, ME_SLOT_EST, p->nn_radius, 10, nullptr, nullptr, &s, &nv));  // k >= 10 (:1675)
+        out->mme_est = nv > 0 ? s / (double) nv : 0.0;
+        out->mme_est_valid = nv;
+        if (p->evaluate_gt_mme) {
+            ME_TRY(me_mme(ctx, ME_SLOT_GT, p->nn_radius, 5, nullptr, nullptr, &s, &nv));  // k >= 5 (:1458)
+            out->mme_gt = nv > 0 ? s / (double) nv : 0.0;
+            out->mme_gt_valid = nv;
+        }
+    }
+    // AC / COM both directions (:1213-1242) + full CD (:1398-1431) from the same two searches
+    ME_TRY(me::nn_search(ctx, ME_SLOT_EST, ME_SLOT_GT));
+    ME_TRY(me_nn_stats(ctx, ME_SLOT_EST, p->icp_max_distance, p->gate_mode, p->trunc, &out->est_gt));
+    ME_TRY(me::nn_search(ctx, ME_SLOT_GT, ME_SLOT_EST));
+    ME_TRY(me_nn_stats(ctx, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &out->gt_est));
+    out->full_chamfer = out->est_gt.mean_nn_dist + out->gt_est.mean_nn_dist;
+    // AWD / SCS (:85, :240-390)
+    int64_t n_rows = 0;
+    ME_TRY(me_awd_scs(ctx, p->vmd_voxel_size, p->min_pts > 0 ? p->min_pts : 100, p->scs_radius > 0 ? p->scs_radius : 5, nullptr,
+                      nullptr, &n_rows, &out->awd, &out->scs, nullptr));
+    out->n_w_voxels = n_rows;
+    return ME_OK;
+}
+
+int me_timers_enable(me_ctx *ctx, int on) {
+    if (!ctx) return ME_ERR_ARG;
+    ctx->timers_collect();
+    ctx->timers_on = on != 0;
+    return ME_OK;
+}
+
+int me_timers_reset(me_ctx *ctx) {
+    if (!ctx) return ME_ERR_ARG;
+    ctx->timers_collect();
+    ctx->timers.clear();
+    return ME_OK;
+}
+
+int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launches) {
+    if (!ctx || !name) return ME_ERR_ARG;
+    ctx->timers_collect();
+    auto it = ctx->timers.find(name);
+    if (total_ms) *total_ms = it == ctx->timers.end() ? 0.0 : it->second.total_ms;
+    if (launches) *launches = it == ctx->timers.end() ? 0 : it->second.launches;
+    return ME_OK;
+}
+
+}  // extern "C"

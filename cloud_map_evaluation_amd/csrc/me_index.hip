@@ -1,0 +1,344 @@
+// me_index.hip — cloud upload + spatial index build.
+//
+// Replaces every KDTreeFlann::SetGeometry of the reference (map_eval.cpp:1214,1227,1401-1402,1449,1551,1619 —
+// 5-7 single-threaded KD-tree builds per run) with ONE index per cloud:
+//   1. optional rigid/homogeneous transform (map_eval.cpp:1206) + bbox reduction,
+//   2. 63-bit Morton codes on a grid nested in the radius-search cell (cell = code >> 3*shift),
+//   3. radix sort (rocPRIM) and gather into 32-byte SPoint records -> every later pass streams coalesced,
+//   4. an implicit 8-ary BVH over consecutive 16-point blocks of the sorted array (fp32 boxes rounded outward),
+//   5. the table of occupied radius cells + an open-addressing hash (cell Morton code -> cell index).
+#include <cmath>
+#include <cstring>
+
+#include "me_internal.hpp"
+
+namespace me {
+
+// ------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------
+struct Mat4 {
+    double m[16];
+};
+
+__global__ void k_transform(double *__restrict__ xyz, long long n, Mat4 T) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    // Open3D PointCloud::Transform [upstream]: h = T*(x,y,z,1), p = h.xyz / h.w — column-major accumulation
+    // order ((c0*x + c1*y) + c2*z) + c3, no FMA (must match the CPU path bit for bit).
+    double h[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = ((T.m[4 * r] * x + T.m[4 * r + 1] * y) + T.m[4 * r + 2] * z) + T.m[4 * r + 3];
+    xyz[3 * i] = h[0] / h[3];
+    xyz[3 * i + 1] = h[1] / h[3];
+    xyz[3 * i + 2] = h[2] / h[3];
+}
+
+__global__ void __launch_bounds__(256) k_bbox(const double *__restrict__ xyz, long long n, double *__restrict__ part) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double v = xyz[3 * i + d];
+            lo[d] = fmin(lo[d], v);
+            hi[d] = fmax(hi[d], v);
+        }
+    }
+    __shared__ double sm[4][6];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[d] = fmin(lo[d], __shfl_down(lo[d], o, 64));
+            hi[d] = fmax(hi[d], __shfl_down(hi[d], o, 64));
+        }
+        if (lane == 0) {
+            sm[w][d] = lo[d];
+            sm[w][3 + d] = hi[d];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        part[6 * blockIdx.x + d] = fmin(fmin(sm[0][d], sm[1][d]), fmin(sm[2][d], sm[3][d]));
+        part[6 * blockIdx.x + 3 + d] = fmax(fmax(sm[0][3 + d], sm[1][3 + d]), fmax(sm[2][3 + d], sm[3][3 + d]));
+    }
+}
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long x) {
+    x &= 0x1fffffULL;
+    x = (x | x << 32) & 0x1f00000000ffffULL;
+    x = (x | x << 16) & 0x1f0000ff0000ffULL;
+    x = (x | x << 8) & 0x100f00f00f00f00fULL;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+    x = (x | x << 2) & 0x1249249249249249ULL;
+    return x;
+}
+
+__global__ void k_morton(const double *__restrict__ xyz, long long n, double ox, double oy, double oz, double fine_h,
+                         unsigned long long *__restrict__ codes, unsigned int *__restrict__ iota) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double lim = 2097151.0;
+    // division (not multiply-by-reciprocal): (p-o)/(h*2^-s) == ((p-o)/h)*2^s exactly, so the radius cell
+    // floor((p-o)/h) is exactly the top bits of the fine coordinate.
+    const double fx = fmin(fmax(floor((xyz[3 * i] - ox) / fine_h), 0.0), lim);
+    const double fy = fmin(fmax(floor((xyz[3 * i + 1] - oy) / fine_h), 0.0), lim);
+    const double fz = fmin(fmax(floor((xyz[3 * i + 2] - oz) / fine_h), 0.0), lim);
+    codes[i] = spread21((unsigned long long) fx) | (spread21((unsigned long long) fy) << 1) |
+               (spread21((unsigned long long) fz) << 2);
+    iota[i] = (unsigned int) i;
+}
+
+__global__ void k_gather(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, long long n,
+                         SPoint *__restrict__ sp) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int s = perm[i];
+    SPoint p;
+    p.x = xyz[3 * (long long) s];
+    p.y = xyz[3 * (long long) s + 1];
+    p.z = xyz[3 * (long long) s + 2];
+    p.idx = (long long) s;
+    sp[i] = p;
+}
+
+__global__ void k_bvh_leaves(const SPoint *__restrict__ sp, long long n, long long n_leaf, float *__restrict__ boxes) {
+    const long long l = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_leaf) return;
+    const long long b = l * kLeaf, e = (b + kLeaf < n) ? b + kLeaf : n;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long long j = b; j < e; ++j) {
+        const SPoint p = sp[j];
+        lo[0] = fmin(lo[0], p.x); hi[0] = fmax(hi[0], p.x);
+        lo[1] = fmin(lo[1], p.y); hi[1] = fmax(hi[1], p.y);
+        lo[2] = fmin(lo[2], p.z); hi[2] = fmax(hi[2], p.z);
+    }
+    float *o = boxes + 6 * l;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        o[d] = __double2float_rd(lo[d]);      // outward rounding keeps the fp32 box a superset of the fp64 one
+        o[3 + d] = __double2float_ru(hi[d]);
+    }
+}
+
+__global__ void k_bvh_up(const float *__restrict__ child, long long n_child, float *__restrict__ parent, long long n_parent) {
+    const long long p = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parent) return;
+    const long long b = p * kFan, e = (b + kFan < n_child) ? b + kFan : n_child;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long long c = b; c < e; ++c) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fminf(lo[d], child[6 * c + d]);
+            hi[d] = fmaxf(hi[d], child[6 * c + 3 + d]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        parent[6 * p + d] = lo[d];
+        parent[6 * p + 3 + d] = hi[d];
+    }
+}
+
+__global__ void k_cell_flags(const unsigned long long *__restrict__ codes, long long n, int shift3,
+                             unsigned int *__restrict__ flags) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = (i == 0 || (codes[i] >> shift3) != (codes[i - 1] >> shift3)) ? 1u : 0u;
+}
+
+__global__ void k_cell_scatter(const unsigned long long *__restrict__ codes, const unsigned int *__restrict__ flags,
+                               const unsigned int *__restrict__ pos, long long n, int shift3,
+                               unsigned long long *__restrict__ cell_code, unsigned int *__restrict__ cell_start) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i]) {
+        cell_code[pos[i]] = codes[i] >> shift3;
+        cell_start[pos[i]] = (unsigned int) i;
+    }
+}
+
+__global__ void k_hash_insert(const unsigned long long *__restrict__ cell_code, long long n_cells,
+                              unsigned long long *__restrict__ hkeys, unsigned int *__restrict__ hvals,
+                              unsigned int mask) {
+    const long long c = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const unsigned long long key = cell_code[c];
+    unsigned int s = (unsigned int) hash_u64(key) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&hkeys[s], kEmptyKey, key);
+        if (prev == kEmptyKey || prev == key) {
+            hvals[s] = (unsigned int) c;
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+__global__ void k_set_u32(unsigned int *p, long long i, unsigned int v) { p[i] = v; }
+
+static inline unsigned int grid_for(long long n, int block = 256) { return (unsigned int) ((n + block - 1) / block); }
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, long long n, const double *T,
+                 double cell_size) {
+    if (slot < 0 || slot > 1) return ctx->fail(ME_ERR_ARG, "slot must be ME_SLOT_EST (0) or ME_SLOT_GT (1)");
+    if (!src) return ctx->fail(ME_ERR_ARG, "xyz is NULL");
+    if (n <= 0) return ctx->fail(ME_ERR_ARG, "point cloud is empty");  // map_eval.cpp:32-35 returns -1
+    if (n >= (1LL << 31)) return ctx->fail(ME_ERR_ARG, "point count must be < 2^31 (the reference indexes with int)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    Cloud &c = ctx->cloud[slot];
+    c.uploaded = false;
+    c.index_valid = false;
+    c.nn_ref_slot = -1;
+    c.n_vox = 0;
+    c.vox_size = 0;
+    // any result that used this cloud as the reference is stale now
+    ctx->cloud[1 - slot].nn_ref_slot = -1;
+    c.n = n;
+    ME_CHECK(ctx, c.xyz.ensure((size_t) n * 3 * sizeof(double)));
+    ME_CHECK(ctx, hipMemcpyAsync(c.xyz.p, src, (size_t) n * 3 * sizeof(double),
+                                 src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    if (T) {
+        Mat4 m;
+        std::memcpy(m.m, T, sizeof(m.m));
+        hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, m);
+    }
+    // bbox
+    const unsigned int nb = (unsigned int) std::min<long long>(1024, (n + 255) / 256);
+    ME_CHECK(ctx, ctx->red.ensure((size_t) nb * 6 * sizeof(double)));
+    hipLaunchKernelGGL(k_bbox, dim3(nb), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, ctx->red.as<double>());
+    std::vector<double> part((size_t) nb * 6);
+    ME_CHECK(ctx, hipMemcpyAsync(part.data(), ctx->red.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int d = 0; d < 3; ++d) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (unsigned int b = 0; b < nb; ++b) {
+            lo = std::fmin(lo, part[6 * b + d]);
+            hi = std::fmax(hi, part[6 * b + 3 + d]);
+        }
+        if (!std::isfinite(lo) || !std::isfinite(hi))
+            return ctx->fail(ME_ERR_ARG, "cloud contains NaN/inf coordinates (the reference strips them at load, map_eval.cpp:6)");
+        c.bbox_lo[d] = lo;
+        c.bbox_hi[d] = hi;
+    }
+    c.uploaded = true;
+    return cloud_build_index(ctx, slot, cell_size);
+}
+
+int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
+    Cloud &c = ctx->cloud[slot];
+    if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "cloud not uploaded");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    const long long n = c.n;
+    double extent = 0;
+    for (int d = 0; d < 3; ++d) extent = std::fmax(extent, c.bbox_hi[d] - c.bbox_lo[d]);
+    if (!(cell_size > 0)) cell_size = (extent > 0 ? extent / 128.0 : 1.0);
+    // a hair larger than the radius so that |p-q| < r can never straddle two cell boundaries through rounding
+    const double cell_h = cell_size * (1.0 + 0x1p-20);
+    const double ncell = std::floor(extent / cell_h) + 1.0;
+    int bits_cell = 1;
+    while ((double) (1LL << bits_cell) < ncell && bits_cell <= kMortonBits) ++bits_cell;
+    if (bits_cell > kMortonBits)
+        return ctx->fail(ME_ERR_ARG, "cell size too small for the cloud extent (needs > 2^21 cells per axis)");
+    c.shift = kMortonBits - bits_cell;
+    c.cell_h = cell_h;
+    c.fine_h = std::ldexp(cell_h, -c.shift);
+    for (int d = 0; d < 3; ++d) c.origin[d] = c.bbox_lo[d];
+    c.index_valid = false;
+    c.nn_ref_slot = -1;
+    ctx->cloud[1 - slot].nn_ref_slot = -1;
+
+    // --- Morton codes + sort ---
+    DevBuf &codes_in = ctx->tmp[0], &iota = ctx->tmp[1], &perm = ctx->tmp[2];
+    ME_CHECK(ctx, codes_in.ensure((size_t) n * 8));
+    ME_CHECK(ctx, iota.ensure((size_t) n * 4));
+    ME_CHECK(ctx, perm.ensure((size_t) n * 4));
+    ME_CHECK(ctx, c.codes.ensure((size_t) n * 8));
+    ME_CHECK(ctx, c.sp.ensure((size_t) n * sizeof(SPoint)));
+    {
+        TimerScope ts(ctx, "morton");
+        hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, c.origin[0],
+                           c.origin[1], c.origin[2], c.fine_h, codes_in.as<unsigned long long>(), iota.as<unsigned int>());
+    }
+    ME_TRY(sort_pairs_u64_u32(ctx, codes_in.as<unsigned long long>(), c.codes.as<unsigned long long>(),
+                              iota.as<unsigned int>(), perm.as<unsigned int>(), n, 0, 63));
+    {
+        TimerScope ts(ctx, "gather");
+        hipLaunchKernelGGL(k_gather, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
+                           perm.as<unsigned int>(), n, c.sp.as<SPoint>());
+    }
+    // --- BVH ---
+    {
+        BvhView &v = c.bvh;
+        long long cnt = (n + kLeaf - 1) / kLeaf, off = 0;
+        int L = 0;
+        for (;;) {
+            if (L >= kMaxLevels) return ctx->fail(ME_ERR_ARG, "cloud too large for the BVH level table");
+            v.count[L] = cnt;
+            v.off[L] = off;
+            off += cnt;
+            ++L;
+            if (cnt == 1) break;
+            cnt = (cnt + kFan - 1) / kFan;
+        }
+        v.n_levels = L;
+        ME_CHECK(ctx, c.boxes.ensure((size_t) off * 6 * sizeof(float)));
+        v.boxes = c.boxes.as<float>();
+        TimerScope ts(ctx, "bvh");
+        hipLaunchKernelGGL(k_bvh_leaves, dim3(grid_for(v.count[0])), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), n,
+                           v.count[0], c.boxes.as<float>());
+        for (int l = 1; l < L; ++l)
+            hipLaunchKernelGGL(k_bvh_up, dim3(grid_for(v.count[l])), dim3(256), 0, ctx->stream,
+                               c.boxes.as<float>() + 6 * v.off[l - 1], v.count[l - 1],
+                               c.boxes.as<float>() + 6 * v.off[l], v.count[l]);
+    }
+    // --- occupied radius cells + hash ---
+    {
+        const int shift3 = 3 * c.shift;
+        DevBuf &flags = ctx->tmp[0], &pos = ctx->tmp[1];  // codes_in / iota are dead now
+        ME_CHECK(ctx, flags.ensure((size_t) n * 4));
+        ME_CHECK(ctx, pos.ensure((size_t) n * 4));
+        TimerScope ts(ctx, "cells");
+        hipLaunchKernelGGL(k_cell_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(), n,
+                           shift3, flags.as<unsigned int>());
+        ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), n));
+        unsigned int last_pos = 0, last_flag = 0;
+        ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const long long n_cells = (long long) last_pos + last_flag;
+        ME_CHECK(ctx, c.cell_code.ensure((size_t) n_cells * 8));
+        ME_CHECK(ctx, c.cell_start.ensure((size_t) (n_cells + 1) * 4));
+        hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(),
+                           flags.as<unsigned int>(), pos.as<unsigned int>(), n, shift3,
+                           c.cell_code.as<unsigned long long>(), c.cell_start.as<unsigned int>());
+        hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, ctx->stream, c.cell_start.as<unsigned int>(), n_cells,
+                           (unsigned int) n);
+        unsigned long long hsize = 64;
+        while (hsize < 2ULL * (unsigned long long) n_cells) hsize <<= 1;
+        ME_CHECK(ctx, c.hkeys.ensure((size_t) hsize * 8));
+        ME_CHECK(ctx, c.hvals.ensure((size_t) hsize * 4));
+        ME_CHECK(ctx, hipMemsetAsync(c.hkeys.p, 0xFF, (size_t) hsize * 8, ctx->stream));
+        hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n_cells)), dim3(256), 0, ctx->stream,
+                           c.cell_code.as<unsigned long long>(), n_cells, c.hkeys.as<unsigned long long>(),
+                           c.hvals.as<unsigned int>(), (unsigned int) (hsize - 1));
+        GridView &g = c.grid;
+        g.cell_code = c.cell_code.as<unsigned long long>();
+        g.cell_start = c.cell_start.as<unsigned int>();
+        g.hkeys = c.hkeys.as<unsigned long long>();
+        g.hvals = c.hvals.as<unsigned int>();
+        g.hmask = (unsigned int) (hsize - 1);
+        g.n_cells = n_cells;
+        g.shift = c.shift;
+    }
+    ME_CHECK(ctx, hipGetLastError());
+    c.index_valid = true;
+    return ME_OK;
+}
+
+}  // namespace me

@@ -1,0 +1,260 @@
+// me_internal.hpp — shared declarations of libmapeval_hip.so (gfx950 only; no CPU fallback anywhere).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mapeval_hip.h"
+
+namespace me {
+
+constexpr int kLeaf = 16;      // points per BVH leaf (consecutive Morton-sorted points)
+constexpr int kFan = 8;        // children per internal BVH node
+constexpr int kMaxLevels = 12; // 16 * 8^11 points
+constexpr int kMortonBits = 21;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    hipError_t ensure(size_t b) {
+        if (b <= bytes && p) return hipSuccess;
+        release();
+        if (b == 0) b = 16;
+        hipError_t e = hipMalloc(&p, b);
+        if (e == hipSuccess) bytes = b;
+        else p = nullptr;
+        return e;
+    }
+    void release() {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Sorted point: xyz in fp64 + original index (bit pattern of an int64 in w).
+struct alignas(32) SPoint {
+    double x, y, z;
+    long long idx;
+};
+
+struct BvhView {
+    const float *boxes;  // 6 floats per node: lo xyz, hi xyz (rounded outward from the fp64 extent)
+    int n_levels;        // level 0 = leaves ... level n_levels-1 = root (1 node)
+    long long count[kMaxLevels];
+    long long off[kMaxLevels];  // node offset of each level inside `boxes`
+};
+
+struct GridView {
+    const unsigned long long *cell_code;  // unique cell Morton codes, ascending [n_cells]
+    const unsigned int *cell_start;       // [n_cells + 1] offsets into the sorted points
+    const unsigned long long *hkeys;      // open-addressing table, EMPTY = ~0ull
+    const unsigned int *hvals;            // cell index
+    unsigned int hmask;
+    long long n_cells;
+    int shift;                            // fine Morton code >> (3*shift) = cell code
+};
+
+struct Cloud {
+    long long n = 0;
+    bool uploaded = false;
+    DevBuf xyz;  // double[n][3] original order, after the optional transform
+    // Morton frame
+    double origin[3] = {0, 0, 0};
+    double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
+    double cell_h = 0;   // radius-grid cell edge
+    double fine_h = 0;   // cell_h / 2^shift
+    int shift = 0;
+    bool index_valid = false;
+    DevBuf codes;  // uint64[n] sorted fine Morton codes
+    DevBuf sp;     // SPoint[n] sorted
+    // BVH
+    BvhView bvh{};
+    DevBuf boxes;
+    // cell table
+    GridView grid{};
+    DevBuf cell_code, cell_start, hkeys, hvals;
+    // last NN result with this cloud as the query (Morton-sorted query order)
+    DevBuf nn_d2, nn_idx;
+    int nn_ref_slot = -1;
+    // voxel table (ascending key order)
+    double vox_size = 0;
+    long long n_vox = 0;
+    DevBuf vox_key;    // uint64[V] packed key
+    DevBuf vox_n;      // int32[V]
+    DevBuf vox_mu;     // double[V][3]
+    DevBuf vox_sigma;  // double[V][9] as stored by the reference
+    DevBuf vox_entropy;
+};
+
+struct TimerRec {
+    double total_ms = 0;
+    long long launches = 0;
+};
+
+}  // namespace me
+
+struct me_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    me::Cloud cloud[2];
+    me::DevBuf tmp[6];  // scratch
+    me::DevBuf red;     // reduction partials
+    void *host_pinned = nullptr;
+    size_t host_pinned_bytes = 0;
+    int shard_rank = 0, shard_world = 1;
+    // instrumentation
+    bool timers_on = false;
+    std::map<std::string, me::TimerRec> timers;
+    struct Pending {
+        std::string name;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+
+    int fail(int code, const std::string &msg) {
+        err = msg;
+        return code;
+    }
+    void shard_range(long long n, long long &b, long long &e) const {
+        b = n * shard_rank / shard_world;
+        e = n * (shard_rank + 1) / shard_world;
+    }
+    hipEvent_t get_event();
+    void timer_begin(const char *name);
+    void timer_end();
+    void timers_collect();
+};
+
+#define ME_CHECK(ctx, expr)                                                                             \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return (ctx)->fail(ME_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__) + " at " + \
+                                               __FILE__ + ":" + std::to_string(__LINE__));              \
+    } while (0)
+
+#define ME_TRY(expr)              \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != ME_OK) return rc__; \
+    } while (0)
+
+namespace me {
+
+// RAII scope for a named kernel-family timer
+struct TimerScope {
+    me_ctx *c;
+    TimerScope(me_ctx *ctx, const char *name) : c(ctx) { c->timer_begin(name); }
+    ~TimerScope() { c->timer_end(); }
+};
+
+// ---- me_prims.hip (rocPRIM-backed primitives) ----
+int sort_pairs_u64_u32(me_ctx *ctx, const unsigned long long *k_in, unsigned long long *k_out,
+                       const unsigned int *v_in, unsigned int *v_out, long long n, int begin_bit, int end_bit);
+int exclusive_scan_u32(me_ctx *ctx, const unsigned int *in, unsigned int *out, long long n);
+int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n);
+
+// ---- me_index.hip ----
+int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, long long n, const double *T,
+                 double cell_size);
+int cloud_build_index(me_ctx *ctx, int slot, double cell_size);
+
+// ---- me_nn.hip ----
+int nn_search(me_ctx *ctx, int qslot, int rslot);
+int nn_fetch(me_ctx *ctx, int qslot, int32_t *idx, double *d2);
+int nn_partial(me_ctx *ctx, int qslot, double gate, int gate_mode, const double trunc[5], me_nn_partial *out);
+int nn_sigma(me_ctx *ctx, int qslot, double gate, int gate_mode, const double mean[5], double sigma_num[5]);
+
+// ---- me_mme.hip ----
+int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, uint8_t *valid, double *sum_H,
+            long long *n_valid);
+
+// ---- me_voxel.hip ----
+int voxel_build(me_ctx *ctx, int slot, double voxel_size);
+int voxel_export(me_ctx *ctx, int slot, int32_t *keys, int32_t *npts, double *mu, double *sigma, double *entropy,
+                 int64_t *n_voxels);
+int awd_scs(me_ctx *ctx, double voxel_size, int min_pts, int scs_radius, double *rows, double *w_sorted,
+            int64_t *n_rows, double *awd, double *scs, int64_t counts[3]);
+int w2_batch(me_ctx *ctx, const double *mu1, const double *sigma1, const int32_t *n1, const double *mu2,
+             const double *sigma2, const int32_t *n2, long long count, double *w);
+int scs_table(me_ctx *ctx, const int32_t *keys, const double *w, long long n, int scs_radius, double *scs);
+
+// ---- shared device helpers ----
+#ifdef __HIPCC__
+__device__ __forceinline__ double dist2_exact(double ax, double ay, double az, double bx, double by, double bz) {
+    // ((dx*dx + dy*dy) + dz*dz) without FMA contraction (file compiled with -ffp-contract=off):
+    // this expression must be bit-identical to the CPU path (nanoflann L2 adaptor order).
+    const double dx = ax - bx, dy = ay - by, dz = az - bz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in thread 0. `sm` holds >= 4 doubles.
+__device__ __forceinline__ double block_sum_256(double v, double *sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0) r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    return r;
+}
+__device__ __forceinline__ long long block_sum_256_ll(long long v, long long *sm) {
+    v = wave_sum_ll(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    long long r = 0;
+    if (threadIdx.x == 0) r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long hash_u64(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+constexpr unsigned long long kEmptyKey = ~0ULL;
+
+__device__ __forceinline__ int hash_lookup(const unsigned long long *__restrict__ keys,
+                                           const unsigned int *__restrict__ vals, unsigned int mask,
+                                           unsigned long long key) {
+    unsigned int s = (unsigned int) hash_u64(key) & mask;
+    for (;;) {
+        const unsigned long long k = keys[s];
+        if (k == key) return (int) vals[s];
+        if (k == kEmptyKey) return -1;
+        s = (s + 1) & mask;
+    }
+}
+#endif
+
+}  // namespace me

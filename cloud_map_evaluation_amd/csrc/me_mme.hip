@@ -1,0 +1,242 @@
+// me_mme.hip — Mean Map Entropy: radius neighbourhood -> covariance -> 0.5*ln(2*pi*e*det)
+// (ComputeMeanMapEntropyUsingNormalTBB map_eval.cpp:1608-1737; the OpenMP and serial variants :1538-1606,
+//  :1438-1535 compute the same thing with k >= 10 / k >= 5).
+//
+// Mapping.  Points are Morton-sorted on a grid whose cell edge is (a hair above) the search radius, so the
+// neighbours of every point of a cell lie in the 3x3x3 block around it, and each cell is one contiguous run of
+// the sorted array.  A wavefront owns 64 consecutive sorted points.  For each distinct cell among its lanes it
+//   * resolves the 27 neighbour runs with one hash probe per lane (lanes 0..26),
+//   * streams those runs with WAVE-UNIFORM addresses (one fetch feeds all 64 lanes; the compiler turns it into
+//     scalar loads), every lane of the current cell testing the candidate against its own query in fp64.
+// The reference materialises index/distance vectors per query and gathers a 3xk matrix; here nothing is
+// materialised: k, sum(p-q) and sum((p-q)(p-q)^T) are accumulated in registers about the QUERY as origin
+// (|p-q| < r, so the one-pass covariance is as well conditioned as the reference's two-pass one).
+// The query itself (d2 == 0, the element the reference erases at :1672-1673) contributes zero to both sums, so
+// dropping it is `k - 1`.
+#include <cmath>
+
+#include "me_internal.hpp"
+
+namespace me {
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long x) {
+    x &= 0x1fffffULL;
+    x = (x | x << 32) & 0x1f00000000ffffULL;
+    x = (x | x << 16) & 0x1f0000ff0000ffULL;
+    x = (x | x << 8) & 0x100f00f00f00f00fULL;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+    x = (x | x << 2) & 0x1249249249249249ULL;
+    return x;
+}
+__device__ __forceinline__ unsigned int compact21(unsigned long long x) {
+    x &= 0x1249249249249249ULL;
+    x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ULL;
+    x = (x ^ (x >> 4)) & 0x100f00f00f00f00fULL;
+    x = (x ^ (x >> 8)) & 0x1f0000ff0000ffULL;
+    x = (x ^ (x >> 16)) & 0x1f00000000ffffULL;
+    x = (x ^ (x >> 32)) & 0x1fffffULL;
+    return (unsigned int) x;
+}
+
+__device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
+    const unsigned int lo = (unsigned int) __builtin_amdgcn_readlane((int) (unsigned int) v, lane);
+    const unsigned int hi = (unsigned int) __builtin_amdgcn_readlane((int) (unsigned int) (v >> 32), lane);
+    return ((unsigned long long) hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(256)
+k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
+      GridView g, double r2, int min_k, double *__restrict__ ent_s, unsigned char *__restrict__ valid_s,
+      double *__restrict__ part_sum, long long *__restrict__ part_cnt) {
+    const int lane = threadIdx.x & 63;
+    // XCD-aware chunking (see k_nn1): gridDim.x is a multiple of 8
+    const unsigned int per = gridDim.x / 8;
+    const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const long long i = i_begin + (long long) vb * blockDim.x + threadIdx.x;
+    const bool active = i < i_end;
+    const int shift3 = 3 * g.shift;
+    const int cell_lim = 1 << (kMortonBits - g.shift);
+
+    double qx = 0, qy = 0, qz = 0;
+    unsigned long long mycell = ~0ULL;
+    if (active) {
+        const SPoint q = sp[i];
+        qx = q.x;
+        qy = q.y;
+        qz = q.z;
+        mycell = codes[i] >> shift3;
+    }
+    int k = 0;
+    double s1x = 0, s1y = 0, s1z = 0;
+    double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    bool done = !active;
+
+    for (;;) {
+        const unsigned long long pending = __ballot(!done);
+        if (pending == 0) break;
+        const int leader = __ffsll((long long) pending) - 1;
+        const unsigned long long cur = readlane_u64(mycell, leader);
+        const int cx = (int) compact21(cur), cy = (int) compact21(cur >> 1), cz = (int) compact21(cur >> 2);
+        // lanes 0..26 resolve one neighbour cell each
+        int nb_start = 0, nb_cnt = 0;
+        if (lane < 27) {
+            const int nx = cx + (lane % 3) - 1, ny = cy + ((lane / 3) % 3) - 1, nz = cz + (lane / 9) - 1;
+            if (nx >= 0 && ny >= 0 && nz >= 0 && nx < cell_lim && ny < cell_lim && nz < cell_lim) {
+                const unsigned long long key = spread21((unsigned long long) nx) | (spread21((unsigned long long) ny) << 1) |
+                                               (spread21((unsigned long long) nz) << 2);
+                const int ci = hash_lookup(g.hkeys, g.hvals, g.hmask, key);
+                if (ci >= 0) {
+                    nb_start = (int) g.cell_start[ci];
+                    nb_cnt = (int) g.cell_start[ci + 1] - nb_start;
+                }
+            }
+        }
+        const bool in = !done && (mycell == cur);
+        for (int n = 0; n < 27; ++n) {
+            const int cs = readlane_i(nb_start, n);
+            const int ce = cs + readlane_i(nb_cnt, n);
+            for (int j = cs; j < ce; ++j) {
+                const SPoint p = sp[j];  // wave-uniform address
+                if (in) {
+                    const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;  // bit-identical to the CPU path (no FMA)
+                    if (d2 < r2) {                                    // strict, nanoflann RadiusResultSet [upstream]
+                        ++k;
+                        s1x += dx;
+                        s1y += dy;
+                        s1z += dz;
+                        sxx = fma(dx, dx, sxx);
+                        sxy = fma(dx, dy, sxy);
+                        sxz = fma(dx, dz, sxz);
+                        syy = fma(dy, dy, syy);
+                        syz = fma(dy, dz, syz);
+                        szz = fma(dz, dz, szz);
+                    }
+                }
+            }
+        }
+        if (in) done = true;
+    }
+
+    double H = 0.0;
+    bool ok = false;
+    if (active) {
+        const int kk = k - 1;  // drop the query itself (map_eval.cpp:1672-1673)
+        if (kk >= min_k) {     // (:1675 k >= 10, :1458 k >= 5)
+            const double inv_k = 1.0 / (double) kk, inv_km1 = 1.0 / (double) (kk - 1);
+            const double cxx = (sxx - s1x * s1x * inv_k) * inv_km1;
+            const double cxy = (sxy - s1x * s1y * inv_k) * inv_km1;
+            const double cxz = (sxz - s1x * s1z * inv_k) * inv_km1;
+            const double cyy = (syy - s1y * s1y * inv_k) * inv_km1;
+            const double cyz = (syz - s1y * s1z * inv_k) * inv_km1;
+            const double czz = (szz - s1z * s1z * inv_k) * inv_km1;
+            // Eigen 3x3 determinant (cofactor expansion along row 0)
+            const double det = cxx * (cyy * czz - cyz * cyz) - cxy * (cxy * czz - cyz * cxz) + cxz * (cxy * cyz - cyy * cxz);
+            const double h = 0.5 * log(2.0 * M_PI * M_E * det);  // ComputeEntropy (:1656)
+            if (!isnan(h) && !isinf(h)) {                         // (:1692)
+                H = h;
+                ok = true;
+            }
+        }
+        ent_s[i] = H;                       // 0.0 where invalid (:1614)
+        valid_s[i] = ok ? 1 : 0;
+    }
+    __shared__ double smd[4];
+    __shared__ long long smi[4];
+    const double bs = block_sum_256(H, smd);
+    const long long bc = block_sum_256_ll(ok ? 1LL : 0LL, smi);
+    if (threadIdx.x == 0) {
+        part_sum[blockIdx.x] = bs;
+        part_cnt[blockIdx.x] = bc;
+    }
+}
+
+__global__ void k_mme_unpermute(const SPoint *__restrict__ sp, long long i_begin, long long i_end,
+                                const double *__restrict__ ent_s, const unsigned char *__restrict__ valid_s,
+                                double *__restrict__ ent_o, unsigned char *__restrict__ valid_o) {
+    const long long i = i_begin + (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= i_end) return;
+    const long long o = sp[i].idx;
+    if (ent_o) ent_o[o] = ent_s[i];
+    if (valid_o) valid_o[o] = valid_s[i];
+}
+
+// deterministic final reduction over block partials (fixed tree inside one 256-thread block)
+__global__ void __launch_bounds__(256)
+k_mme_final(const double *__restrict__ ps, const long long *__restrict__ pc, int nb, double *__restrict__ out_s,
+            long long *__restrict__ out_c) {
+    double s = 0;
+    long long c = 0;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        s += ps[b];
+        c += pc[b];
+    }
+    __shared__ double smd[4];
+    __shared__ long long smi[4];
+    const double rs = block_sum_256(s, smd);
+    const long long rc = block_sum_256_ll(c, smi);
+    if (threadIdx.x == 0) {
+        *out_s = rs;
+        *out_c = rc;
+    }
+}
+
+int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, uint8_t *valid, double *sum_H,
+            long long *n_valid) {
+    if (slot < 0 || slot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
+    if (!(radius > 0)) return ctx->fail(ME_ERR_ARG, "me_mme: radius must be > 0");
+    if (min_k < 2) return ctx->fail(ME_ERR_ARG, "me_mme: min_k must be >= 2 (covariance divides by k-1)");
+    Cloud &c = ctx->cloud[slot];
+    if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "me_mme: cloud not uploaded");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    // the 27-cell stencil is exact only when cell edge >= radius; rebuild when it is not, or when the cells are
+    // needlessly coarse (more candidates per query than necessary)
+    const double want_h = radius * (1.0 + 0x1p-20);
+    if (!c.index_valid || c.cell_h < want_h || c.cell_h > 1.5 * want_h) ME_TRY(cloud_build_index(ctx, slot, radius));
+    const long long n = c.n;
+    long long b, e;
+    ctx->shard_range(n, b, e);
+    DevBuf &ent_s = ctx->tmp[0], &val_s = ctx->tmp[1];
+    ME_CHECK(ctx, ent_s.ensure((size_t) n * 8));
+    ME_CHECK(ctx, val_s.ensure((size_t) n));
+    const unsigned int nb = (unsigned int) std::max<long long>(8, ((e - b + 255) / 256 + 7) / 8 * 8);
+    ME_CHECK(ctx, ctx->red.ensure((size_t) nb * 16 + 64));
+    double *ps = ctx->red.as<double>();
+    long long *pc = reinterpret_cast<long long *>(ps + nb);
+    double *outs = reinterpret_cast<double *>(pc + nb);
+    long long *outc = reinterpret_cast<long long *>(outs + 1);
+    const double r2 = radius * radius;  // Open3D SearchRadius -> nanoflann radiusSearch(q, r*r) [upstream]
+    {
+        TimerScope ts(ctx, "mme");
+        hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(),
+                           b, e, c.grid, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc);
+    }
+    hipLaunchKernelGGL(k_mme_final, dim3(1), dim3(256), 0, ctx->stream, ps, pc, (int) nb, outs, outc);
+    double hs = 0;
+    long long hc = 0;
+    ME_CHECK(ctx, hipMemcpyAsync(&hs, outs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(&hc, outc, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (entropies || valid) {
+        DevBuf &eo = ctx->tmp[2], &vo = ctx->tmp[3];
+        ME_CHECK(ctx, eo.ensure((size_t) n * 8));
+        ME_CHECK(ctx, vo.ensure((size_t) n));
+        if (ctx->shard_world > 1) {
+            ME_CHECK(ctx, hipMemsetAsync(eo.p, 0, (size_t) n * 8, ctx->stream));
+            ME_CHECK(ctx, hipMemsetAsync(vo.p, 0, (size_t) n, ctx->stream));
+        }
+        if (e > b)
+            hipLaunchKernelGGL(k_mme_unpermute, dim3((unsigned int) ((e - b + 255) / 256)), dim3(256), 0, ctx->stream,
+                               c.sp.as<SPoint>(), b, e, ent_s.as<double>(), val_s.as<unsigned char>(),
+                               entropies ? eo.as<double>() : nullptr, valid ? vo.as<unsigned char>() : nullptr);
+        if (entropies) ME_CHECK(ctx, hipMemcpyAsync(entropies, eo.p, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (valid) ME_CHECK(ctx, hipMemcpyAsync(valid, vo.p, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_CHECK(ctx, hipGetLastError());
+    if (sum_H) *sum_H = hs;
+    if (n_valid) *n_valid = hc;
+    return ME_OK;
+}
+
+}  // namespace me

@@ -1,0 +1,358 @@
+// me_nn.hip — batched exact 1-NN (KDTreeFlann::SearchKNN k=1, map_eval.cpp:1218,1231,1415,1424) and the
+// threshold statistics of getDiffRegResultWithCorrespondence (map_eval.cpp:1069-1145).
+//
+// One lane per query, queries in Morton order (neighbouring lanes walk neighbouring nodes, so node and leaf
+// fetches hit L1/L2).  Traversal of the implicit 8-ary BVH is stackless:
+//   (1) greedy descent (closest child box per level) to a first leaf  -> a tight initial bound,
+//   (2) pruned depth-first walk in Morton order; a subtree is skipped when its box lower bound exceeds the
+//       current best.  The bound is computed in fp64 from fp32 boxes rounded outward and every operation is
+//       monotone, so it never exceeds the *computed* distance of a point inside: the result is the exact
+//       brute-force minimum of ((dx*dx + dy*dy) + dz*dz), bit-identical to the CPU path.
+#include <cmath>
+
+#include "me_internal.hpp"
+
+namespace me {
+
+__device__ __forceinline__ double box_lower_bound(const float *__restrict__ b, double qx, double qy, double qz) {
+    const double dx = fmax(fmax((double) b[0] - qx, qx - (double) b[3]), 0.0);
+    const double dy = fmax(fmax((double) b[1] - qy, qy - (double) b[4]), 0.0);
+    const double dz = fmax(fmax((double) b[2] - qz, qz - (double) b[5]), 0.0);
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+__device__ __forceinline__ void scan_leaf(const SPoint *__restrict__ rsp, long long nr, long long leaf, double qx,
+                                          double qy, double qz, double &best, long long &best_i) {
+    const long long b = leaf * kLeaf;
+    const long long e = (b + kLeaf < nr) ? b + kLeaf : nr;
+    for (long long j = b; j < e; ++j) {
+        const SPoint p = rsp[j];
+        const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
+        if (d < best || (d == best && p.idx < best_i)) {  // ties -> smallest reference index (as the oracle)
+            best = d;
+            best_i = p.idx;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
+      BvhView bvh, double *__restrict__ d2_out, int *__restrict__ idx_out) {
+    __shared__ long long s_count[kMaxLevels], s_off[kMaxLevels];
+    if (threadIdx.x < kMaxLevels) {
+        s_count[threadIdx.x] = bvh.count[threadIdx.x];
+        s_off[threadIdx.x] = bvh.off[threadIdx.x];
+    }
+    __syncthreads();
+    // XCD-aware chunking: block b runs on XCD b % 8; give each XCD one contiguous eighth of the (Morton-ordered)
+    // queries so the BVH nodes / leaves it touches stay in that XCD's private L2.
+    // (gridDim.x is a multiple of 8.)
+    const unsigned int per = gridDim.x / 8;
+    const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const long long i = q_begin + (long long) vb * blockDim.x + threadIdx.x;
+    if (i >= q_end) return;
+
+    const SPoint q = qsp[i];
+    const double qx = q.x, qy = q.y, qz = q.z;
+    const int L = bvh.n_levels - 1;
+    const float *__restrict__ boxes = bvh.boxes;
+    double best = INFINITY;
+    long long best_i = 0x7fffffffffffffffLL;
+
+    // (1) greedy descent
+    {
+        long long node = 0;
+        for (int l = L; l > 0; --l) {
+            const long long c0 = node * kFan;
+            const long long cn = s_count[l - 1];
+            const long long c1 = (c0 + kFan < cn) ? c0 + kFan : cn;
+            const float *bp = boxes + 6 * (s_off[l - 1] + c0);
+            double bd = INFINITY;
+            long long bc = c0;
+            for (long long c = c0; c < c1; ++c, bp += 6) {
+                const double d = box_lower_bound(bp, qx, qy, qz);
+                if (d < bd) {
+                    bd = d;
+                    bc = c;
+                }
+            }
+            node = bc;
+        }
+        scan_leaf(rsp, nr, node, qx, qy, qz, best, best_i);
+    }
+    // (2) pruned stackless DFS
+    {
+        int l = L;
+        long long n = 0;
+        for (;;) {
+            const double lb = box_lower_bound(boxes + 6 * (s_off[l] + n), qx, qy, qz);
+            if (lb <= best) {
+                if (l == 0) {
+                    scan_leaf(rsp, nr, n, qx, qy, qz, best, best_i);
+                } else {
+                    --l;
+                    n *= kFan;
+                    continue;
+                }
+            }
+            // advance to the next sibling, climbing while we are the last child
+            bool done = false;
+            for (;;) {
+                if (l == L) {
+                    done = true;
+                    break;
+                }
+                if ((n & (kFan - 1)) != (kFan - 1) && n + 1 < s_count[l]) {
+                    ++n;
+                    break;
+                }
+                n >>= 3;
+                ++l;
+            }
+            if (done) break;
+        }
+    }
+    d2_out[i] = best;
+    idx_out[i] = (int) best_i;
+}
+
+// ---- un-permute results to the caller's (original) query order ----
+__global__ void k_nn_unpermute(const SPoint *__restrict__ qsp, long long q_begin, long long q_end,
+                               const double *__restrict__ d2s, const int *__restrict__ idxs, double *__restrict__ d2o,
+                               int *__restrict__ idxo) {
+    const long long i = q_begin + (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q_end) return;
+    const long long o = qsp[i].idx;
+    if (d2o) d2o[o] = d2s[i];
+    if (idxo) idxo[o] = idxs[i];
+}
+
+// ---- statistics ----
+struct StatParams {
+    double gate;      // threshold on d2 (already squared if the mode says so); < 0 = no gate
+    int gate_strict;  // 1: d2 < gate, 0: d2 <= gate
+    double t2max[5];  // largest d2 whose correctly rounded sqrt is <= trunc[k]
+};
+
+constexpr int kStatD = 11;  // sum_d[5], sum_d2[5], sum_sqrt_all
+constexpr int kStatI = 6;   // n_corr, n_inl[5]
+
+__device__ __forceinline__ bool gate_pass(const StatParams &sp, double d2) {
+    if (sp.gate < 0) return true;
+    return sp.gate_strict ? (d2 < sp.gate) : (d2 <= sp.gate);
+}
+
+__global__ void __launch_bounds__(256)
+k_nn_partial(const double *__restrict__ d2s, long long q_begin, long long q_end, StatParams sp,
+             double *__restrict__ pd, long long *__restrict__ pi) {
+    double sd[kStatD];
+    long long si[kStatI];
+#pragma unroll
+    for (int k = 0; k < kStatD; ++k) sd[k] = 0;
+#pragma unroll
+    for (int k = 0; k < kStatI; ++k) si[k] = 0;
+    for (long long i = q_begin + (long long) blockIdx.x * blockDim.x + threadIdx.x; i < q_end;
+         i += (long long) gridDim.x * blockDim.x) {
+        const double d2 = d2s[i];
+        const double d = sqrt(d2);  // (map_pt - gt_pt).norm(), map_eval.cpp:1095
+        sd[10] += d;                // computeChamferDistance, ungated (map_eval.cpp:1416)
+        if (gate_pass(sp, d2)) {
+            si[0] += 1;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (d2 <= sp.t2max[k]) {  // <=> norm_dis <= trunc_dist_[k] (map_eval.cpp:1099-1123)
+                    sd[k] += d;
+                    sd[5 + k] += d2;
+                    si[1 + k] += 1;
+                }
+        }
+    }
+    __shared__ double smd[4];
+    __shared__ long long smi[4];
+#pragma unroll
+    for (int k = 0; k < kStatD; ++k) {
+        const double r = block_sum_256(sd[k], smd);
+        if (threadIdx.x == 0) pd[(long long) blockIdx.x * kStatD + k] = r;
+    }
+#pragma unroll
+    for (int k = 0; k < kStatI; ++k) {
+        const long long r = block_sum_256_ll(si[k], smi);
+        if (threadIdx.x == 0) pi[(long long) blockIdx.x * kStatI + k] = r;
+    }
+}
+
+struct Mean5 {
+    double m[5];
+};
+
+__global__ void __launch_bounds__(256)
+k_nn_sigma(const double *__restrict__ d2s, long long q_begin, long long q_end, StatParams sp, Mean5 mean,
+           double *__restrict__ pd) {
+    double s[5] = {0, 0, 0, 0, 0};
+    for (long long i = q_begin + (long long) blockIdx.x * blockDim.x + threadIdx.x; i < q_end;
+         i += (long long) gridDim.x * blockDim.x) {
+        const double d2 = d2s[i];
+        if (gate_pass(sp, d2)) {
+            const double d = sqrt(d2);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const double e = d - mean.m[k];  // every correspondence, not only the inliers (map_eval.cpp:1133-1136)
+                s[k] += e * e;
+            }
+        }
+    }
+    __shared__ double smd[4];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double r = block_sum_256(s[k], smd);
+        if (threadIdx.x == 0) pd[(long long) blockIdx.x * 5 + k] = r;
+    }
+}
+
+// deterministic final reduction: component k is summed over the blocks in block order by one lane
+__global__ void k_final_sum_d(const double *__restrict__ part, int nblocks, int ncomp, double *__restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= ncomp) return;
+    double s = 0;
+    for (int b = 0; b < nblocks; ++b) s += part[(long long) b * ncomp + k];
+    out[k] = s;
+}
+__global__ void k_final_sum_i(const long long *__restrict__ part, int nblocks, int ncomp, long long *__restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= ncomp) return;
+    long long s = 0;
+    for (int b = 0; b < nblocks; ++b) s += part[(long long) b * ncomp + k];
+    out[k] = s;
+}
+
+static StatParams make_params(double gate, int gate_mode, const double trunc[5]) {
+    StatParams sp;
+    if (gate < 0) {
+        sp.gate = -1.0;
+        sp.gate_strict = 0;
+    } else if (gate_mode == ME_GATE_LT_SQUARED) {
+        sp.gate = gate * gate;
+        sp.gate_strict = 1;
+    } else {
+        sp.gate = gate;
+        sp.gate_strict = 0;
+    }
+    for (int k = 0; k < 5; ++k) {
+        // largest double x with sqrt_rn(x) <= t, so the device compares d2 against it and the inlier count does
+        // not depend on the device's sqrt rounding
+        const double t = trunc ? trunc[k] : 0.0;
+        if (!(t >= 0)) {
+            sp.t2max[k] = -1.0;
+            continue;
+        }
+        double x = t * t;
+        while (std::sqrt(std::nextafter(x, INFINITY)) <= t) x = std::nextafter(x, INFINITY);
+        while (x > 0 && std::sqrt(x) > t) x = std::nextafter(x, -INFINITY);
+        sp.t2max[k] = x;
+    }
+    return sp;
+}
+
+int nn_search(me_ctx *ctx, int qslot, int rslot) {
+    if (qslot < 0 || qslot > 1 || rslot < 0 || rslot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
+    Cloud &q = ctx->cloud[qslot];
+    Cloud &r = ctx->cloud[rslot];
+    if (!q.index_valid || !r.index_valid) return ctx->fail(ME_ERR_STATE, "me_nn1: upload both clouds first");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    ME_CHECK(ctx, q.nn_d2.ensure((size_t) q.n * 8));
+    ME_CHECK(ctx, q.nn_idx.ensure((size_t) q.n * 4));
+    long long b, e;
+    ctx->shard_range(q.n, b, e);
+    if (e > b) {
+        const unsigned int nb = (unsigned int) (((e - b + 255) / 256 + 7) / 8 * 8);  // multiple of 8 (XCD chunking)
+        TimerScope ts(ctx, "nn1");
+        hipLaunchKernelGGL(k_nn1, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
+                           r.bvh, q.nn_d2.as<double>(), q.nn_idx.as<int>());
+    }
+    ME_CHECK(ctx, hipGetLastError());
+    q.nn_ref_slot = rslot;
+    return ME_OK;
+}
+
+int nn_fetch(me_ctx *ctx, int qslot, int32_t *idx, double *d2) {
+    Cloud &q = ctx->cloud[qslot];
+    if (q.nn_ref_slot < 0) return ctx->fail(ME_ERR_STATE, "no NN result for this slot (call me_nn1 first)");
+    if (!idx && !d2) return ME_OK;
+    long long b, e;
+    ctx->shard_range(q.n, b, e);
+    DevBuf &od = ctx->tmp[0], &oi = ctx->tmp[1];
+    ME_CHECK(ctx, od.ensure((size_t) q.n * 8));
+    ME_CHECK(ctx, oi.ensure((size_t) q.n * 4));
+    if (ctx->shard_world > 1) {  // entries outside the shard read as 0 / -1
+        ME_CHECK(ctx, hipMemsetAsync(od.p, 0, (size_t) q.n * 8, ctx->stream));
+        ME_CHECK(ctx, hipMemsetAsync(oi.p, 0xFF, (size_t) q.n * 4, ctx->stream));
+    }
+    if (e > b)
+        hipLaunchKernelGGL(k_nn_unpermute, dim3((unsigned int) ((e - b + 255) / 256)), dim3(256), 0, ctx->stream,
+                           q.sp.as<SPoint>(), b, e, q.nn_d2.as<double>(), q.nn_idx.as<int>(), od.as<double>(), oi.as<int>());
+    if (d2) ME_CHECK(ctx, hipMemcpyAsync(d2, od.p, (size_t) q.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (idx) ME_CHECK(ctx, hipMemcpyAsync(idx, oi.p, (size_t) q.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
+int nn_partial(me_ctx *ctx, int qslot, double gate, int gate_mode, const double trunc[5], me_nn_partial *out) {
+    if (qslot < 0 || qslot > 1 || !out || !trunc) return ctx->fail(ME_ERR_ARG, "me_nn_partial_sums: bad argument");
+    Cloud &q = ctx->cloud[qslot];
+    if (q.nn_ref_slot < 0) return ctx->fail(ME_ERR_STATE, "no NN result for this slot (call me_nn1 first)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    long long b, e;
+    ctx->shard_range(q.n, b, e);
+    const StatParams sp = make_params(gate, gate_mode, trunc);
+    const int nb = (int) std::max<long long>(1, std::min<long long>(1024, (e - b + 255) / 256));
+    const size_t bytes_d = (size_t) (nb + 1) * kStatD * 8, bytes_i = (size_t) (nb + 1) * kStatI * 8;
+    ME_CHECK(ctx, ctx->red.ensure(bytes_d + bytes_i));
+    double *pd = ctx->red.as<double>();
+    long long *pi = reinterpret_cast<long long *>(ctx->red.as<char>() + bytes_d);
+    {
+        TimerScope ts(ctx, "nn_stats");
+        hipLaunchKernelGGL(k_nn_partial, dim3(nb), dim3(256), 0, ctx->stream, q.nn_d2.as<double>(), b, e, sp, pd, pi);
+        hipLaunchKernelGGL(k_final_sum_d, dim3(1), dim3(64), 0, ctx->stream, pd, nb, kStatD, pd + (size_t) nb * kStatD);
+        hipLaunchKernelGGL(k_final_sum_i, dim3(1), dim3(64), 0, ctx->stream, pi, nb, kStatI, pi + (size_t) nb * kStatI);
+    }
+    double hd[kStatD];
+    long long hi[kStatI];
+    ME_CHECK(ctx, hipMemcpyAsync(hd, pd + (size_t) nb * kStatD, sizeof(hd), hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(hi, pi + (size_t) nb * kStatI, sizeof(hi), hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    out->n_query = e - b;
+    out->n_corr = hi[0];
+    for (int k = 0; k < 5; ++k) {
+        out->n_inl[k] = hi[1 + k];
+        out->sum_d[k] = hd[k];
+        out->sum_d2[k] = hd[5 + k];
+    }
+    out->sum_sqrt_all = hd[10];
+    return ME_OK;
+}
+
+int nn_sigma(me_ctx *ctx, int qslot, double gate, int gate_mode, const double mean[5], double sigma_num[5]) {
+    if (qslot < 0 || qslot > 1 || !mean || !sigma_num) return ctx->fail(ME_ERR_ARG, "me_nn_sigma_sums: bad argument");
+    Cloud &q = ctx->cloud[qslot];
+    if (q.nn_ref_slot < 0) return ctx->fail(ME_ERR_STATE, "no NN result for this slot (call me_nn1 first)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    long long b, e;
+    ctx->shard_range(q.n, b, e);
+    const double zeros[5] = {0, 0, 0, 0, 0};
+    const StatParams sp = make_params(gate, gate_mode, zeros);
+    Mean5 m;
+    for (int k = 0; k < 5; ++k) m.m[k] = mean[k];
+    const int nb = (int) std::max<long long>(1, std::min<long long>(1024, (e - b + 255) / 256));
+    ME_CHECK(ctx, ctx->red.ensure((size_t) (nb + 1) * 5 * 8));
+    double *pd = ctx->red.as<double>();
+    {
+        TimerScope ts(ctx, "nn_stats");
+        hipLaunchKernelGGL(k_nn_sigma, dim3(nb), dim3(256), 0, ctx->stream, q.nn_d2.as<double>(), b, e, sp, m, pd);
+        hipLaunchKernelGGL(k_final_sum_d, dim3(1), dim3(64), 0, ctx->stream, pd, nb, 5, pd + (size_t) nb * 5);
+    }
+    ME_CHECK(ctx, hipMemcpyAsync(sigma_num, pd + (size_t) nb * 5, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
+}  // namespace me

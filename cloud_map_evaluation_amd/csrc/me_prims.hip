@@ -1,0 +1,45 @@
+// me_prims.hip — device-wide sort / scan primitives (rocPRIM) behind plain functions, so that the slow-to-compile
+// rocPRIM templates are instantiated in exactly one translation unit.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "me_internal.hpp"
+
+namespace me {
+
+int sort_pairs_u64_u32(me_ctx *ctx, const unsigned long long *k_in, unsigned long long *k_out,
+                       const unsigned int *v_in, unsigned int *v_out, long long n, int begin_bit, int end_bit) {
+    if (n <= 0) return ME_OK;
+    size_t bytes = 0;
+    ME_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, bytes, k_in, k_out, v_in, v_out, (size_t) n,
+                                            (unsigned) begin_bit, (unsigned) end_bit, ctx->stream));
+    ME_CHECK(ctx, ctx->tmp[5].ensure(bytes));
+    TimerScope ts(ctx, "sort");
+    ME_CHECK(ctx, rocprim::radix_sort_pairs(ctx->tmp[5].p, bytes, k_in, k_out, v_in, v_out, (size_t) n,
+                                            (unsigned) begin_bit, (unsigned) end_bit, ctx->stream));
+    return ME_OK;
+}
+
+int exclusive_scan_u32(me_ctx *ctx, const unsigned int *in, unsigned int *out, long long n) {
+    if (n <= 0) return ME_OK;
+    size_t bytes = 0;
+    ME_CHECK(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, (size_t) n, rocprim::plus<unsigned int>(),
+                                          ctx->stream));
+    ME_CHECK(ctx, ctx->tmp[5].ensure(bytes));
+    ME_CHECK(ctx, rocprim::exclusive_scan(ctx->tmp[5].p, bytes, in, out, 0u, (size_t) n,
+                                          rocprim::plus<unsigned int>(), ctx->stream));
+    return ME_OK;
+}
+
+int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n) {
+    if (n <= 0) return ME_OK;
+    size_t bytes = 0;
+    ME_CHECK(ctx, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t) n, 0u, 64u, ctx->stream));
+    ME_CHECK(ctx, ctx->tmp[5].ensure(bytes));
+    ME_CHECK(ctx, rocprim::radix_sort_keys(ctx->tmp[5].p, bytes, in, out, (size_t) n, 0u, 64u, ctx->stream));
+    return ME_OK;
+}
+
+}  // namespace me

@@ -1,0 +1,273 @@
+"""Python face of the C ABI: numpy / torch-tensor in, numpy / dataclasses out.
+
+`Engine` owns one me_ctx (one GPU).  Method names follow the reference's MapEval members they stand in for
+(map_eval/src/map_eval.h:196-312): computeMME, calculateMetricsWithInitialMatrix, computeChamferDistance,
+calculateVMD.  The C++ host (cloud_map_evaluation_amd/host/) is the drop-in for the reference executable; this
+module is what tests/ and bench.py drive.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import ME_GATE_LE_UNSQUARED, ME_GATE_LT_SQUARED, ME_SLOT_EST, ME_SLOT_GT  # noqa: F401
+
+
+class MapEvalError(RuntimeError):
+    pass
+
+
+@dataclass
+class Param:
+    """Hot-path fields of the reference's Param (map_eval.h:60-116), same names and defaults."""
+    icp_max_distance_: float = 2.5
+    nn_radius_: float = 0.2
+    trunc_dist_: tuple = (0.2, 0.1, 0.08, 0.05, 0.01)  # accuracy_level (config.yaml)
+    initial_matrix_: np.ndarray = field(default_factory=lambda: np.eye(4))
+    vmd_voxel_size_: float = 3.0
+    evaluate_mme_: bool = True
+    evaluate_gt_mme_: bool = True
+    evaluate_using_initial_: bool = True
+    use_tbb_mme: bool = True  # accepted for compatibility; the GPU path has one implementation
+
+
+@dataclass
+class RegStats:
+    """One getDiffRegResultWithCorrespondence result block (map_eval.cpp:1140-1144)."""
+    n_src: int
+    n_corr: int
+    mean: np.ndarray
+    rmse: np.ndarray
+    fitness: np.ndarray
+    sigma: np.ndarray
+    number: np.ndarray
+    mean_nn_dist: float
+
+    @staticmethod
+    def from_c(o: _lib.NNStatsOut) -> "RegStats":
+        f = lambda x: np.array(list(x), dtype=np.float64)
+        return RegStats(o.n_src, o.n_corr, f(o.mean), f(o.rmse), f(o.fitness), f(o.sigma), f(o.number), o.mean_nn_dist)
+
+
+def _addr(a) -> int:
+    """Raw address of a numpy array (host) or a torch tensor (host or device)."""
+    if a is None:
+        return 0
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()  # torch.Tensor
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        self._ctx = self._L.me_create(int(device), 0)
+        if not self._ctx:
+            raise MapEvalError(self._L.me_last_error(None).decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.me_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise MapEvalError(f"[{rc}] " + self._L.me_last_error(self._ctx).decode())
+
+    # ---- clouds ----
+    def set_shard(self, rank: int, world: int):
+        self._ck(self._L.me_set_shard(self._ctx, rank, world))
+
+    def upload(self, slot: int, xyz, T=None, cell_size: float = 0.0):
+        """xyz: (N,3) float64 numpy array (host) or torch tensor (CPU or cuda, contiguous)."""
+        Tm = None if T is None else np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        on_device = False
+        if isinstance(xyz, np.ndarray):
+            xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        else:  # torch tensor
+            import torch
+
+            if xyz.dtype != torch.float64 or not xyz.is_contiguous():
+                xyz = xyz.to(torch.float64).contiguous()
+            on_device = xyz.is_cuda
+            if on_device:
+                torch.cuda.current_stream(xyz.device).synchronize()  # producer stream -> library stream hand-over
+        if xyz.ndim != 2 or xyz.shape[1] != 3:
+            raise ValueError("expected an (N,3) array")
+        fn = self._L.me_upload_cloud_device if on_device else self._L.me_upload_cloud
+        self._ck(fn(self._ctx, slot, _addr(xyz), int(xyz.shape[0]), _addr(Tm), float(cell_size)))
+        self._keepalive = xyz
+
+    def size(self, slot: int) -> int:
+        return int(self._L.me_cloud_size(self._ctx, slot))
+
+    def download(self, slot: int) -> np.ndarray:
+        out = np.empty((self.size(slot), 3), np.float64)
+        self._ck(self._L.me_download_cloud(self._ctx, slot, _addr(out)))
+        return out
+
+    # ---- 1-NN + AC/COM/CD ----
+    def nn1(self, query_slot: int, ref_slot: int, fetch: bool = True):
+        n = self.size(query_slot)
+        if not fetch:
+            self._ck(self._L.me_nn1(self._ctx, query_slot, ref_slot, 0, 0))
+            return None, None
+        idx = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float64)
+        self._ck(self._L.me_nn1(self._ctx, query_slot, ref_slot, _addr(idx), _addr(d2)))
+        return idx, d2
+
+    def nn_stats(self, query_slot: int, gate: float, gate_mode: int, trunc) -> RegStats:
+        tr = np.ascontiguousarray(trunc, dtype=np.float64)
+        out = _lib.NNStatsOut()
+        self._ck(self._L.me_nn_stats(self._ctx, query_slot, float(gate), int(gate_mode), _addr(tr), C.byref(out)))
+        return RegStats.from_c(out)
+
+    def nn_partial_sums(self, query_slot: int, gate: float, gate_mode: int, trunc) -> _lib.NNPartial:
+        tr = np.ascontiguousarray(trunc, dtype=np.float64)
+        out = _lib.NNPartial()
+        self._ck(self._L.me_nn_partial_sums(self._ctx, query_slot, float(gate), int(gate_mode), _addr(tr), C.byref(out)))
+        return out
+
+    def nn_sigma_sums(self, query_slot: int, gate: float, gate_mode: int, mean) -> np.ndarray:
+        m = np.ascontiguousarray(mean, dtype=np.float64)
+        out = np.zeros(5, np.float64)
+        self._ck(self._L.me_nn_sigma_sums(self._ctx, query_slot, float(gate), int(gate_mode), _addr(m), _addr(out)))
+        return out
+
+    def nn_finalize(self, total: _lib.NNPartial, sigma_num, n_src_total: int) -> RegStats:
+        s = np.ascontiguousarray(sigma_num, dtype=np.float64)
+        out = _lib.NNStatsOut()
+        self._L.me_nn_finalize(C.byref(total), _addr(s), int(n_src_total), C.byref(out))
+        return RegStats.from_c(out)
+
+    def computeChamferDistance(self) -> float:
+        """map_eval.cpp:1398-1431 on the uploaded pair."""
+        cd = C.c_double()
+        self._ck(self._L.me_chamfer(self._ctx, C.byref(cd)))
+        return cd.value
+
+    def calculateMetricsWithInitialMatrix(self, p: Param):
+        """map_eval.cpp:1204-1260 (clouds already uploaded, est with initial_matrix_) -> (est_gt, gt_est, cd_vec)."""
+        self.nn1(ME_SLOT_EST, ME_SLOT_GT, fetch=False)
+        est_gt = self.nn_stats(ME_SLOT_EST, p.icp_max_distance_, ME_GATE_LE_UNSQUARED, p.trunc_dist_)
+        self.nn1(ME_SLOT_GT, ME_SLOT_EST, fetch=False)
+        gt_est = self.nn_stats(ME_SLOT_GT, p.icp_max_distance_, ME_GATE_LE_UNSQUARED, p.trunc_dist_)
+        return est_gt, gt_est, est_gt.rmse + gt_est.rmse  # cd_vec (:1245)
+
+    # ---- MME ----
+    def mme(self, slot: int, radius: float, min_k: int, per_point: bool = True):
+        """-> (mean, entropies[N] | None, valid[N] | None, n_valid, sum_H)."""
+        n = self.size(slot)
+        ent = np.zeros(n, np.float64) if per_point else None
+        val = np.zeros(n, np.uint8) if per_point else None
+        s = C.c_double()
+        nv = C.c_int64()
+        self._ck(self._L.me_mme(self._ctx, slot, float(radius), int(min_k), _addr(ent), _addr(val), C.byref(s), C.byref(nv)))
+        mean = s.value / nv.value if nv.value > 0 else 0.0
+        return mean, ent, val, nv.value, s.value
+
+    def computeMME(self, p: Param):
+        """map_eval.cpp:149-189 -> (mme_est, mme_gt)."""
+        mme_est = self.mme(ME_SLOT_EST, p.nn_radius_, 10, per_point=False)[0]
+        mme_gt = self.mme(ME_SLOT_GT, p.nn_radius_, 5, per_point=False)[0] if p.evaluate_gt_mme_ else 0.0
+        return mme_est, mme_gt
+
+    # ---- voxels ----
+    def voxel_gaussians(self, slot: int, voxel_size: float):
+        nv = C.c_int64(0)
+        self._ck(self._L.me_voxel_gaussians(self._ctx, slot, float(voxel_size), 0, 0, 0, 0, 0, C.byref(nv)))
+        v = nv.value
+        keys = np.empty((v, 3), np.int32)
+        n = np.empty(v, np.int32)
+        mu = np.empty((v, 3), np.float64)
+        sg = np.empty((v, 9), np.float64)
+        en = np.empty(v, np.float64)
+        nv = C.c_int64(v)
+        self._ck(self._L.me_voxel_gaussians(self._ctx, slot, float(voxel_size), _addr(keys), _addr(n), _addr(mu), _addr(sg),
+                                            _addr(en), C.byref(nv)))
+        return keys, n, mu, sg.reshape(v, 3, 3), en
+
+    def calculateVMD(self, voxel_size: float, min_pts: int = 100, scs_radius: int = 5, rows: bool = True):
+        """map_eval.cpp:240-390 -> dict(awd, scs, rows, w_sorted, counts)."""
+        n = C.c_int64(0)
+        awd, scs = C.c_double(), C.c_double()
+        counts = np.zeros(3, np.int64)
+        self._ck(self._L.me_awd_scs(self._ctx, float(voxel_size), min_pts, scs_radius, 0, 0, C.byref(n), C.byref(awd),
+                                    C.byref(scs), _addr(counts)))
+        res = dict(awd=awd.value, scs=scs.value, counts=tuple(int(c) for c in counts), n_rows=n.value)
+        if rows and n.value > 0:
+            r = np.empty((n.value, 27), np.float64)
+            ws = np.empty(n.value, np.float64)
+            cap = C.c_int64(n.value)
+            self._ck(self._L.me_awd_scs(self._ctx, float(voxel_size), min_pts, scs_radius, _addr(r), _addr(ws), C.byref(cap),
+                                        C.byref(awd), C.byref(scs), _addr(counts)))
+            res.update(rows=r, w_sorted=ws)
+        elif rows:
+            res.update(rows=np.empty((0, 27)), w_sorted=np.empty(0))
+        return res
+
+    def w2_batch(self, mu1, sigma1, n1, mu2, sigma2, n2) -> np.ndarray:
+        """Batched computeWassersteinDistanceGaussian(voxel1, voxel2) (voxel_calculator.cpp:115-140)."""
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (mu1, sigma1, mu2, sigma2)]
+        n1 = np.ascontiguousarray(n1, dtype=np.int32)
+        n2 = np.ascontiguousarray(n2, dtype=np.int32)
+        cnt = n1.shape[0]
+        w = np.empty(cnt, np.float64)
+        self._ck(self._L.me_w2_batch(self._ctx, _addr(a[0]), _addr(a[1]), _addr(n1), _addr(a[2]), _addr(a[3]), _addr(n2), cnt,
+                                     _addr(w)))
+        return w
+
+    def scs_table(self, keys, w, radius: int = 5) -> float:
+        """SCS (map_eval.cpp:347-389) of a sparse W table."""
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        out = C.c_double()
+        self._ck(self._L.me_scs_table(self._ctx, _addr(keys), _addr(w), w.shape[0], radius, C.byref(out)))
+        return out.value
+
+    # ---- whole suite ----
+    def run_suite(self, p: Param, gate_mode: int = ME_GATE_LE_UNSQUARED) -> _lib.SuiteOut:
+        sp = _lib.SuiteParams()
+        sp.icp_max_distance = p.icp_max_distance_
+        sp.gate_mode = gate_mode
+        for k in range(5):
+            sp.trunc[k] = p.trunc_dist_[k]
+        sp.nn_radius = p.nn_radius_
+        sp.vmd_voxel_size = p.vmd_voxel_size_
+        sp.evaluate_mme = int(p.evaluate_mme_)
+        sp.evaluate_gt_mme = int(p.evaluate_gt_mme_)
+        sp.min_pts = 100
+        sp.scs_radius = 5
+        out = _lib.SuiteOut()
+        self._ck(self._L.me_run_suite(self._ctx, C.byref(sp), C.byref(out)))
+        return out
+
+    # ---- instrumentation ----
+    def timers_enable(self, on: bool = True):
+        self._ck(self._L.me_timers_enable(self._ctx, int(on)))
+
+    def timers_reset(self):
+        self._ck(self._L.me_timers_reset(self._ctx))
+
+    def timer(self, name: str):
+        ms, cnt = C.c_double(), C.c_int64()
+        self._ck(self._L.me_timer_get(self._ctx, name.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

@@ -1,0 +1,187 @@
+/*
+ * mapeval_hip.h — C ABI of libmapeval_hip.so: MapEval's metric hot path on AMD MI355X (gfx950).
+ *
+ * The reference (JokerJohn/Cloud_Map_Evaluation) has no plugin / FFI layer: its seam is the set of MapEval member
+ * calls made by MapEval::process() (map_eval/src/map_eval.cpp:52-85).  Each entry point below replaces one of
+ * those calls (or the Open3D / VoxelCalculator operator it loops over) with ONE batched device call; the
+ * reference file:line it stands in for is cited per function.  Plain pointers and sizes only — no C++ or torch
+ * types cross this boundary.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - clouds are AoS fp64 `double[N][3]`, exactly open3d::geometry::PointCloud::points_.data() (map_eval.h:45);
+ *     host pointers unless the function name ends in _device.
+ *   - the caller owns every host buffer; the library owns all device memory inside me_ctx.
+ *   - every call is synchronous on return and returns ME_OK (0) or a negative ME_ERR_*; me_last_error() has text.
+ *   - nullable outputs may be NULL (skips the D2H copy).
+ *   - one me_ctx = one GPU = one host thread at a time (MapEval::process is single-threaded, map_eval.cpp:4).
+ *   - results follow the reference's arithmetic, quirks included (squared-vs-unsquared gate :1219, triple
+ *     division of sigma voxel_calculator.cpp:48/102/120, Cholesky-trace "W2" :136-138, k>=10 / k>=5 MME gates).
+ *     Inlier / valid / voxel point counts are bit-exact; floating-point sums agree to ~1e-12 relative
+ *     (summation order differs, as it already does between two runs of the TBB/OpenMP reference).
+ */
+#ifndef MAPEVAL_HIP_H
+#define MAPEVAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ME_OK 0
+#define ME_ERR_ARG (-1)      /* bad argument (null pointer, bad slot, n out of range, ...)          */
+#define ME_ERR_HIP (-2)      /* a HIP runtime call failed (no device, OOM, ...)                     */
+#define ME_ERR_STATE (-3)    /* call order violated (cloud not uploaded, search not run, ...)       */
+#define ME_ERR_CAPACITY (-4) /* caller-provided output capacity too small (count still returned)    */
+
+#define ME_SLOT_EST 0 /* map_3d_  (map_eval.h:322) */
+#define ME_SLOT_GT 1  /* gt_3d_   (map_eval.h:322) */
+
+#define ME_GATE_LE_UNSQUARED 0 /* keep iff d2 <= gate        — calculateMetricsWithInitialMatrix, map_eval.cpp:1219 (sic) */
+#define ME_GATE_LT_SQUARED 1   /* keep iff d2 <  gate*gate   — Open3D EvaluateRegistration / ICP, map_eval.cpp:1168        */
+
+typedef struct me_ctx me_ctx;
+
+/* Raw (shard-local, all-reduce-able) sums of one direction of the AC/COM/CD pass.
+ * Every field is a plain sum over the query points this context owns, so partials from several GPUs add. */
+typedef struct me_nn_partial {
+    int64_t n_query;     /* queries processed (shard size)                                  */
+    int64_t n_corr;      /* correspondences that passed the gate  (points_set.size(), :1076) */
+    int64_t n_inl[5];    /* number_vec   (map_eval.cpp:1102,1107,...)                        */
+    double sum_d[5];     /* mean_vec before /C  (:1100)                                      */
+    double sum_d2[5];    /* rmse_vec before /C  (:1101)                                      */
+    double sum_sqrt_all; /* sum of sqrt(d2) over ALL queries, ungated (computeChamferDistance :1416) */
+} me_nn_partial;
+
+/* Finished result block of getDiffRegResultWithCorrespondence (map_eval.cpp:1140-1144):
+ * the five Vector5d pushed into est_gt_results / gt_est_results, plus the CD term. */
+typedef struct me_nn_stats_out {
+    int64_t n_src;       /* source.points_.size() (whole cloud)                              */
+    int64_t n_corr;      /* C                                                                */
+    double mean[5];      /* result[0] */
+    double rmse[5];      /* result[1]  -> "RMSE/AC:"  (map_eval.cpp:439)                     */
+    double fitness[5];   /* result[2]  -> "Comp:"     (map_eval.cpp:445)                     */
+    double sigma[5];     /* result[3] */
+    double number[5];    /* result[4] */
+    double mean_nn_dist; /* sum_sqrt_all / n_src : one half of computeChamferDistance (:1429) */
+} me_nn_stats_out;
+
+/* ---- lifetime ---------------------------------------------------------------------------------------------- */
+/* device: HIP device ordinal (one context per GPU).  flags: reserved, pass 0.  NULL on failure. */
+me_ctx *me_create(int device, int flags);
+void me_destroy(me_ctx *ctx);
+const char *me_last_error(me_ctx *ctx); /* ctx may be NULL: returns the last me_create error */
+int me_version(void);
+
+/* Multi-GPU slab sharding (no reference counterpart; the reference is single-process).  After this call every
+ * per-point pass (NN, MME) only processes the `rank`-th of `world` equal slabs of the Morton-sorted query order,
+ * and the voxel passes only own voxels whose key index falls in the rank's slab; partial sums are returned for
+ * the caller to all-reduce (RCCL).  Default (0,1) = whole job. */
+int me_set_shard(me_ctx *ctx, int rank, int world);
+
+/* ---- clouds ------------------------------------------------------------------------------------------------ */
+/* Replaces: *map_3d_ = map_3d_->Transform(initial_matrix) (map_eval.cpp:1206) + every KDTreeFlann::SetGeometry
+ * (map_eval.cpp:1214,1227,1401-1402,1449,1551,1619): uploads the cloud, applies T (row-major 4x4, NULL = none;
+ * homogeneous divide as Open3D), Morton-sorts it and builds the search index ONCE.
+ * cell_size: edge of the radius-search grid cell (pass nn_radius; <= 0 = automatic, rebuilt lazily by me_mme). */
+int me_upload_cloud(me_ctx *ctx, int slot, const double *xyz_host, int64_t n, const double *T_rowmajor4x4,
+                    double cell_size);
+int me_upload_cloud_device(me_ctx *ctx, int slot, const double *xyz_device, int64_t n,
+                           const double *T_rowmajor4x4, double cell_size);
+int64_t me_cloud_size(me_ctx *ctx, int slot);
+/* transformed points back to the host (N x 3), original order — what map_3d_->points_ holds after :1206 */
+int me_download_cloud(me_ctx *ctx, int slot, double *xyz_host);
+
+/* ---- 1-NN: KDTreeFlann::SearchKNN(q, 1, idx, d2) over a whole cloud (map_eval.cpp:1218,1231,1415,1424,579) --- */
+/* Searches every point of query_slot in ref_slot; results stay on the device for the me_nn_* calls below.
+ * idx / d2 (query-cloud order, length N_query; nullable) receive the neighbour index in ref cloud order and the
+ * SQUARED distance ((dx*dx + dy*dy) + dz*dz), bit-identical to the CPU path.  Ties -> smallest ref index. */
+int me_nn1(me_ctx *ctx, int query_slot, int ref_slot, int32_t *idx, double *d2);
+
+/* getDiffRegResultWithCorrespondence / getDiffRegResult (map_eval.cpp:1069-1145, 828-897, 990-1067) on the
+ * correspondences of the last me_nn1(query_slot, ...): gate (negative = none) + 5 thresholds.  One-shot,
+ * single GPU. */
+int me_nn_stats(me_ctx *ctx, int query_slot, double gate, int gate_mode, const double trunc[5],
+                me_nn_stats_out *out);
+/* The same, split for multi-GPU: raw partial sums -> (all-reduce) -> second pass for sigma -> finalize. */
+int me_nn_partial_sums(me_ctx *ctx, int query_slot, double gate, int gate_mode, const double trunc[5],
+                       me_nn_partial *out);
+int me_nn_sigma_sums(me_ctx *ctx, int query_slot, double gate, int gate_mode, const double mean[5],
+                     double sigma_num[5]);
+void me_nn_finalize(const me_nn_partial *total, const double sigma_num[5], int64_t n_src_total,
+                    me_nn_stats_out *out);
+
+/* computeChamferDistance (map_eval.cpp:1398-1431): both directions, no gate.  Runs me_nn1 both ways. */
+int me_chamfer(me_ctx *ctx, double *cd);
+
+/* ---- MME: ComputeMeanMapEntropyUsingNormalTBB / UsingNormal / ComputeMeanMapEntropy
+ *      (map_eval.cpp:1608-1737, 1538-1606, 1438-1535) ------------------------------------------------------------ */
+/* min_k: 10 for the estimated cloud (:1675), 5 for the GT cloud (:1458).  entropies[N] (0.0 where invalid) and
+ * valid[N] are in cloud order, nullable.  sum_H / n_valid are shard-local partial sums; the mean entropy is
+ * sum_H / n_valid (0 when n_valid == 0, :1720-1724). */
+int me_mme(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, uint8_t *valid, double *sum_H,
+           int64_t *n_valid);
+
+/* ---- voxel Gaussians: VoxelCalculator::buildVoxelMap + computeVoxelEntropy (voxel_calculator.cpp:21-56,97-113) */
+/* Output rows are in ascending (ix,iy,iz) order.  sigma is AS STORED by the reference after buildVoxelMap, i.e.
+ * M2/(n-1)^2 for n > 10 and raw M2 otherwise (row-major 3x3).  *n_voxels in: capacity, out: count
+ * (ME_ERR_CAPACITY if too small; pass all-NULL arrays to query the count). */
+int me_voxel_gaussians(me_ctx *ctx, int slot, double voxel_size, int32_t *keys /*V x 3*/, int32_t *npts /*V*/,
+                       double *mu /*V x 3*/, double *sigma /*V x 9*/, double *entropy /*V*/, int64_t *n_voxels);
+
+/* ---- AWD + CDF + SCS: MapEval::calculateVMD (map_eval.cpp:240-390) with updateVoxelMap (voxel_calculator.cpp:
+ *      142-172) and computeWassersteinDistanceGaussian (:115-140) ------------------------------------------------ */
+/* rows: n x 27 doubles in the column order of voxel_errors.txt (map_eval.cpp:292-302), ascending key order;
+ * w_sorted: ascending W (the CDF file's first column, :330-340); both nullable.  *n_rows in: capacity, out: count.
+ * awd = mean W (NaN if no voxel qualifies, :324), scs as :347-389 (NaN if no voxel has a neighbour).
+ * counts[3] = active / old / new voxel counts (voxel_calculator.cpp:170), nullable. */
+int me_awd_scs(me_ctx *ctx, double voxel_size, int min_pts /*100, :280*/, int scs_radius /*5, :353*/,
+               double *rows, double *w_sorted, int64_t *n_rows, double *awd, double *scs, int64_t counts[3]);
+
+/* Batched VoxelCalculator::computeWassersteinDistanceGaussian(voxel1, voxel2) (voxel_calculator.hpp:69,
+ * voxel_calculator.cpp:115-140) on caller-provided Gaussians: mu*[count][3], sigma*[count][9] (row-major, AS STORED
+ * in VoxelInfo::sigma), n*[count] -> w[count].  Host pointers.  Lets the reference's own voxel_errors.txt be replayed
+ * through the device kernel. */
+int me_w2_batch(me_ctx *ctx, const double *mu1, const double *sigma1, const int32_t *n1, const double *mu2,
+                const double *sigma2, const int32_t *n2, int64_t count, double *w);
+
+/* SCS of a caller-provided sparse W table (map_eval.cpp:347-389): keys[n][3] voxel indices, w[n].  Host pointers. */
+int me_scs_table(me_ctx *ctx, const int32_t *keys, const double *w, int64_t n, int scs_radius, double *scs);
+
+/* ---- whole suite in one call (what MapEval::process runs between load and save, map_eval.cpp:52-85) -------- */
+typedef struct me_suite_params {
+    double icp_max_distance; /* Param::icp_max_distance_ */
+    int gate_mode;           /* ME_GATE_* */
+    double trunc[5];         /* Param::trunc_dist_ */
+    double nn_radius;        /* Param::nn_radius_ */
+    double vmd_voxel_size;   /* Param::vmd_voxel_size_ */
+    int evaluate_mme;        /* Param::evaluate_mme_ */
+    int evaluate_gt_mme;     /* Param::evaluate_gt_mme_ */
+    int min_pts;             /* 100 */
+    int scs_radius;          /* 5 */
+} me_suite_params;
+
+typedef struct me_suite_out {
+    me_nn_stats_out est_gt; /* est_gt_results */
+    me_nn_stats_out gt_est; /* gt_est_results (intended (gt_i, map_nn) pairing; see DESIGN.md deviation #4) */
+    double full_chamfer;    /* full_chamfer_dist */
+    double mme_est, mme_gt; /* mme_est / mme_gt */
+    int64_t mme_est_valid, mme_gt_valid;
+    double awd, scs;        /* vmd / scs_overall */
+    int64_t n_w_voxels;
+    double stage_ms[8];     /* device-side stage timers: index, nn e->g, nn g->e, stats, mme est, mme gt, voxel+awd, scs */
+} me_suite_out;
+
+int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out);
+
+/* ---- instrumentation (bench.py roofline leg) ------------------------------------------------------------- */
+/* Average device time (ms, HIP events on the context's stream) and launch count of a named kernel family since
+ * the last me_timers_reset: "nn1", "mme", "sort", "bvh", "voxel", "w2", "scs".  Enabled by me_timers_enable(1). */
+int me_timers_enable(me_ctx *ctx, int on);
+int me_timers_reset(me_ctx *ctx);
+int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
