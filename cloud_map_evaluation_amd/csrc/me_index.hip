@@ -281,13 +281,13 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
             if (L >= kMaxLevels) return ctx->fail(ME_ERR_ARG, "cloud too large for the BVH level table");
             v.count[L] = cnt;
             v.off[L] = off;
-            off += cnt;
+            off += (cnt + 1) & ~1LL;  // even level offsets: a group of 8 sibling boxes (192 B) is 16-byte aligned
             ++L;
             if (cnt == 1) break;
             cnt = (cnt + kFan - 1) / kFan;
         }
         v.n_levels = L;
-        ME_CHECK(ctx, c.boxes.ensure((size_t) off * 6 * sizeof(float)));
+        ME_CHECK(ctx, c.boxes.ensure((size_t) (off + kFan) * 6 * sizeof(float)));  // + one group of slack for the burst read
         v.boxes = c.boxes.as<float>();
         TimerScope ts(ctx, "bvh");
         hipLaunchKernelGGL(k_bvh_leaves, dim3(grid_for(v.count[0])), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), n,

@@ -2,12 +2,16 @@
 // threshold statistics of getDiffRegResultWithCorrespondence (map_eval.cpp:1069-1145).
 //
 // One lane per query, queries in Morton order (neighbouring lanes walk neighbouring nodes, so node and leaf
-// fetches hit L1/L2).  Traversal of the implicit 8-ary BVH is stackless:
-//   (1) greedy descent (closest child box per level) to a first leaf  -> a tight initial bound,
-//   (2) pruned depth-first walk in Morton order; a subtree is skipped when its box lower bound exceeds the
-//       current best.  The bound is computed in fp64 from fp32 boxes rounded outward and every operation is
-//       monotone, so it never exceeds the *computed* distance of a point inside: the result is the exact
-//       brute-force minimum of ((dx*dx + dy*dy) + dz*dz), bit-identical to the CPU path.
+// fetches hit L1/L2).  Traversal of the implicit 8-ary BVH is stackless AND nearest-first:
+//   state = (level, node, 64-bit mask: one byte of "children already taken" per level).
+//   At a node the 8 child boxes (192 contiguous bytes, one burst of loads) are bounded at once; the closest
+//   not-yet-taken child whose lower bound does not exceed the current best is entered; when none is left the
+//   walk returns to the parent (whose child bounds are simply recomputed).  Nearest-first order makes the
+//   first leaf reached almost always the right one, so far-away queries (outliers, non-overlapping regions;
+//   the README run has FULL CD = 102 m) stay cheap instead of sweeping every node inside a loose bound.
+//   The bound is computed in fp64 from fp32 boxes rounded outward and every operation is monotone, so it
+//   never exceeds the *computed* distance of a point inside: the result is the exact brute-force minimum of
+//   ((dx*dx + dy*dy) + dz*dz), bit-identical to the CPU path.
 #include <cmath>
 
 #include "me_internal.hpp"
@@ -59,57 +63,59 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
     double best = INFINITY;
     long long best_i = 0x7fffffffffffffffLL;
 
-    // (1) greedy descent
-    {
-        long long node = 0;
-        for (int l = L; l > 0; --l) {
-            const long long c0 = node * kFan;
-            const long long cn = s_count[l - 1];
-            const long long c1 = (c0 + kFan < cn) ? c0 + kFan : cn;
-            const float *bp = boxes + 6 * (s_off[l - 1] + c0);
+    if (L == 0) {
+        scan_leaf(rsp, nr, 0, qx, qy, qz, best, best_i);  // the whole cloud is one leaf
+    } else {
+        int l = L;                     // current internal node = (l, n); its children live on level l-1
+        long long n = 0;
+        // "children already entered" of the current node of every level on the path: one byte per level
+        // (levels 1..8 in taken_lo, 9..11 in taken_hi; 16 * 8^9 points > 2^31, so this covers every cloud)
+        unsigned long long taken_lo = 0;
+        unsigned int taken_hi = 0;
+        for (;;) {
+            const long long c0 = n * kFan;
+            const long long rem = s_count[l - 1] - c0;  // >= 1 children exist
+            // one burst: 8 child boxes = 12 x 16 B (level offsets are even, so the group is 16-byte aligned;
+            // the buffer is padded, lanes of a short last group are masked below)
+            const float4 *__restrict__ g = reinterpret_cast<const float4 *>(boxes + 6 * (s_off[l - 1] + c0));
+            float f[48];
+#pragma unroll
+            for (int v = 0; v < 12; ++v) {
+                const float4 t = g[v];
+                f[4 * v] = t.x;
+                f[4 * v + 1] = t.y;
+                f[4 * v + 2] = t.z;
+                f[4 * v + 3] = t.w;
+            }
+            const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
+                                             : (taken_hi >> (8 * (l - 9))) & 0xffu;
             double bd = INFINITY;
-            long long bc = c0;
-            for (long long c = c0; c < c1; ++c, bp += 6) {
-                const double d = box_lower_bound(bp, qx, qy, qz);
-                if (d < bd) {
-                    bd = d;
+            int bc = -1;
+#pragma unroll
+            for (int c = 0; c < kFan; ++c) {
+                const double lb = box_lower_bound(&f[6 * c], qx, qy, qz);
+                const bool ok = (c < rem) && !((tk >> c) & 1u) && lb <= best;  // <=: ties may hold a smaller index
+                if (ok && lb < bd) {
+                    bd = lb;
                     bc = c;
                 }
             }
-            node = bc;
-        }
-        scan_leaf(rsp, nr, node, qx, qy, qz, best, best_i);
-    }
-    // (2) pruned stackless DFS
-    {
-        int l = L;
-        long long n = 0;
-        for (;;) {
-            const double lb = box_lower_bound(boxes + 6 * (s_off[l] + n), qx, qy, qz);
-            if (lb <= best) {
-                if (l == 0) {
-                    scan_leaf(rsp, nr, n, qx, qy, qz, best, best_i);
-                } else {
-                    --l;
-                    n *= kFan;
-                    continue;
-                }
-            }
-            // advance to the next sibling, climbing while we are the last child
-            bool done = false;
-            for (;;) {
-                if (l == L) {
-                    done = true;
-                    break;
-                }
-                if ((n & (kFan - 1)) != (kFan - 1) && n + 1 < s_count[l]) {
-                    ++n;
-                    break;
-                }
-                n >>= 3;
+            if (bc < 0) {  // nothing left under this node: return to the parent
+                if (l == L) break;
                 ++l;
+                n >>= 3;
+                continue;
             }
-            if (done) break;
+            if (l <= 8) taken_lo |= 1ULL << (8 * (l - 1) + bc);
+            else taken_hi |= 1u << (8 * (l - 9) + bc);
+            if (l == 1) {
+                scan_leaf(rsp, nr, c0 + bc, qx, qy, qz, best, best_i);
+            } else {
+                --l;
+                n = c0 + bc;
+                if (l <= 8) taken_lo &= ~(0xffULL << (8 * (l - 1)));  // fresh node on the level below
+                else taken_hi &= ~(0xffu << (8 * (l - 9)));
+            }
         }
     }
     d2_out[i] = best;
