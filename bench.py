@@ -196,10 +196,13 @@ def main():
         eng.timers_reset()
         suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme)
         fam = {}
-        for name in ("nn1", "mme", "sort", "morton", "gather", "bvh", "cells", "nn_stats", "voxel_keys", "voxel", "w2", "scs"):
+        for name in ("nn_grid", "nn1", "mme", "sort", "morton", "gather", "bvh", "cells", "nn_stats", "voxel_keys", "voxel",
+                     "w2", "scs"):
             ms, cnt = eng.timer(name)
             if cnt:
                 fam[name] = (ms, cnt)
+        nn_fallback = eng.timer("nn_fallback_queries")[1]
+        nn_total = eng.timer("nn_queries")[1]
         eng.timers_enable(False)
         if rank == 0 and fam:
             dom = max(fam, key=lambda k: fam[k][0])
@@ -209,7 +212,7 @@ def main():
             if dom == "mme":
                 units = (n_e + (n_g if evaluate_gt_mme else 0)) * shard / cnt
                 alg_bytes = BYTES_PER_MME_QUERY * units
-            elif dom == "nn1":
+            elif dom in ("nn1", "nn_grid"):
                 units = (n_e + n_g) * shard / cnt
                 alg_bytes = BYTES_PER_NN_QUERY * units
             else:
@@ -227,7 +230,9 @@ def main():
                                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
                                 "units_per_launch": units, "algorithmic_bytes_per_launch": alg_bytes,
                                 "kernel_ms_per_step": {k: v[0] for k, v in fam.items()},
-                                "queries_per_s": {"nn1": (n_e + n_g) * shard / (fam["nn1"][0] * 1e-3) if "nn1" in fam else None,
+                                "nn_fallback_fraction": (nn_fallback / nn_total) if nn_total else None,
+                                "queries_per_s": {"nn": (n_e + n_g) * shard / ((fam.get("nn1", (0, 0))[0] + fam.get("nn_grid", (0, 0))[0]) * 1e-3)
+                                                  if ("nn1" in fam or "nn_grid" in fam) else None,
                                                   "mme": (n_e + (n_g if evaluate_gt_mme else 0)) * shard / (fam["mme"][0] * 1e-3)
                                                   if "mme" in fam else None}}
 

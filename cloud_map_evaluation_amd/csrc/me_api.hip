@@ -267,12 +267,20 @@ int me_timers_reset(me_ctx *ctx) {
     if (!ctx) return ME_ERR_ARG;
     ctx->timers_collect();
     ctx->timers.clear();
+    ctx->nn_fallback = ctx->nn_queries = 0;
     return ME_OK;
 }
 
 int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launches) {
     if (!ctx || !name) return ME_ERR_ARG;
     ctx->timers_collect();
+    if (std::strcmp(name, "nn_fallback_queries") == 0 || std::strcmp(name, "nn_queries") == 0) {
+        // counters, not timers: 1-NN queries that needed the BVH pass / all 1-NN queries since the last reset
+        const long long v = name[3] == 'f' ? ctx->nn_fallback : ctx->nn_queries;
+        if (total_ms) *total_ms = 0.0;
+        if (launches) *launches = v;
+        return ME_OK;
+    }
     auto it = ctx->timers.find(name);
     if (total_ms) *total_ms = it == ctx->timers.end() ? 0.0 : it->second.total_ms;
     if (launches) *launches = it == ctx->timers.end() ? 0 : it->second.launches;

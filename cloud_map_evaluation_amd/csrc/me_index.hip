@@ -66,16 +66,6 @@ __global__ void __launch_bounds__(256) k_bbox(const double *__restrict__ xyz, lo
     }
 }
 
-__device__ __forceinline__ unsigned long long spread21(unsigned long long x) {
-    x &= 0x1fffffULL;
-    x = (x | x << 32) & 0x1f00000000ffffULL;
-    x = (x | x << 16) & 0x1f0000ff0000ffULL;
-    x = (x | x << 8) & 0x100f00f00f00f00fULL;
-    x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
-    x = (x | x << 2) & 0x1249249249249249ULL;
-    return x;
-}
-
 __global__ void k_morton(const double *__restrict__ xyz, long long n, double ox, double oy, double oz, double fine_h,
                          unsigned long long *__restrict__ codes, unsigned int *__restrict__ iota) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,9 +73,9 @@ __global__ void k_morton(const double *__restrict__ xyz, long long n, double ox,
     const double lim = 2097151.0;
     // division (not multiply-by-reciprocal): (p-o)/(h*2^-s) == ((p-o)/h)*2^s exactly, so the radius cell
     // floor((p-o)/h) is exactly the top bits of the fine coordinate.
-    const double fx = fmin(fmax(floor((xyz[3 * i] - ox) / fine_h), 0.0), lim);
-    const double fy = fmin(fmax(floor((xyz[3 * i + 1] - oy) / fine_h), 0.0), lim);
-    const double fz = fmin(fmax(floor((xyz[3 * i + 2] - oz) / fine_h), 0.0), lim);
+    const double fx = fmin(fmax(fine_coord(xyz[3 * i], ox, fine_h), 0.0), lim);
+    const double fy = fmin(fmax(fine_coord(xyz[3 * i + 1], oy, fine_h), 0.0), lim);
+    const double fz = fmin(fmax(fine_coord(xyz[3 * i + 2], oz, fine_h), 0.0), lim);
     codes[i] = spread21((unsigned long long) fx) | (spread21((unsigned long long) fy) << 1) |
                (spread21((unsigned long long) fz) << 2);
     iota[i] = (unsigned int) i;
@@ -179,7 +169,57 @@ __global__ void k_hash_insert(const unsigned long long *__restrict__ cell_code, 
 
 __global__ void k_set_u32(unsigned int *p, long long i, unsigned int v) { p[i] = v; }
 
+// highest differing Morton level between neighbours of the sorted code array: hist[k] += 1 when codes[i-1] and
+// codes[i] first differ at level k (bits 3k..3k+2).  #occupied cells at level k = 1 + sum_{j >= k} hist[j].
+__global__ void __launch_bounds__(256) k_level_hist(const unsigned long long *__restrict__ codes, long long n,
+                                                    unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int sh[32];
+    if (threadIdx.x < 32) sh[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += (long long) gridDim.x * blockDim.x) {
+        const unsigned long long x = codes[i] ^ codes[i - 1];
+        if (x) atomicAdd(&sh[(63 - __clzll((long long) x)) / 3], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long) sh[threadIdx.x]);
+}
+
 static inline unsigned int grid_for(long long n, int block = 256) { return (unsigned int) ((n + block - 1) / block); }
+
+// occupied cells of Morton level `shift` (unique code >> 3*shift, run starts) + open-addressing hash
+static int build_grid_table(me_ctx *ctx, Cloud &c, int shift, GridTable &t, GridView &g) {
+    const long long n = c.n;
+    const int shift3 = 3 * shift;
+    DevBuf &flags = ctx->tmp[0], &pos = ctx->tmp[1];
+    ME_CHECK(ctx, flags.ensure((size_t) n * 4));
+    ME_CHECK(ctx, pos.ensure((size_t) n * 4));
+    hipLaunchKernelGGL(k_cell_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(), n, shift3,
+                       flags.as<unsigned int>());
+    ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), n));
+    const long long n_cells = c.level_unique[shift];
+    ME_CHECK(ctx, t.cell_code.ensure((size_t) n_cells * 8));
+    ME_CHECK(ctx, t.cell_start.ensure((size_t) (n_cells + 1) * 4));
+    hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(),
+                       flags.as<unsigned int>(), pos.as<unsigned int>(), n, shift3, t.cell_code.as<unsigned long long>(),
+                       t.cell_start.as<unsigned int>());
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, ctx->stream, t.cell_start.as<unsigned int>(), n_cells, (unsigned int) n);
+    unsigned long long hsize = 64;
+    while (hsize < 2ULL * (unsigned long long) n_cells) hsize <<= 1;
+    ME_CHECK(ctx, t.hkeys.ensure((size_t) hsize * 8));
+    ME_CHECK(ctx, t.hvals.ensure((size_t) hsize * 4));
+    ME_CHECK(ctx, hipMemsetAsync(t.hkeys.p, 0xFF, (size_t) hsize * 8, ctx->stream));
+    hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n_cells)), dim3(256), 0, ctx->stream, t.cell_code.as<unsigned long long>(),
+                       n_cells, t.hkeys.as<unsigned long long>(), t.hvals.as<unsigned int>(), (unsigned int) (hsize - 1));
+    t.shift = shift;
+    g.cell_code = t.cell_code.as<unsigned long long>();
+    g.cell_start = t.cell_start.as<unsigned int>();
+    g.hkeys = t.hkeys.as<unsigned long long>();
+    g.hvals = t.hvals.as<unsigned int>();
+    g.hmask = (unsigned int) (hsize - 1);
+    g.n_cells = n_cells;
+    g.shift = shift;
+    return ME_OK;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // host side
@@ -240,6 +280,12 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     if (!(cell_size > 0)) cell_size = (extent > 0 ? extent / 128.0 : 1.0);
     // a hair larger than the radius so that |p-q| < r can never straddle two cell boundaries through rounding
     const double cell_h = cell_size * (1.0 + 0x1p-20);
+    // origin snapped to the global cell lattice: two clouds built with the same cell size get ALIGNED grids, so the
+    // points of one cell of the query cloud fall into one cell of the reference cloud (the 1-NN grid pass groups
+    // lanes by reference cell; with a common lattice a wave of Morton-consecutive queries touches few of them)
+    for (int d = 0; d < 3; ++d) c.origin[d] = std::floor(c.bbox_lo[d] / cell_h) * cell_h;
+    extent = 0;
+    for (int d = 0; d < 3; ++d) extent = std::fmax(extent, c.bbox_hi[d] - c.origin[d]);
     const double ncell = std::floor(extent / cell_h) + 1.0;
     int bits_cell = 1;
     while ((double) (1LL << bits_cell) < ncell && bits_cell <= kMortonBits) ++bits_cell;
@@ -248,7 +294,6 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     c.shift = kMortonBits - bits_cell;
     c.cell_h = cell_h;
     c.fine_h = std::ldexp(cell_h, -c.shift);
-    for (int d = 0; d < 3; ++d) c.origin[d] = c.bbox_lo[d];
     c.index_valid = false;
     c.nn_ref_slot = -1;
     ctx->cloud[1 - slot].nn_ref_slot = -1;
@@ -297,44 +342,36 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
                                c.boxes.as<float>() + 6 * v.off[l - 1], v.count[l - 1],
                                c.boxes.as<float>() + 6 * v.off[l], v.count[l]);
     }
-    // --- occupied radius cells + hash ---
+    // --- occupied cells per Morton level -> pick the 1-NN grid level; build the cell tables ---
     {
-        const int shift3 = 3 * c.shift;
-        DevBuf &flags = ctx->tmp[0], &pos = ctx->tmp[1];  // codes_in / iota are dead now
-        ME_CHECK(ctx, flags.ensure((size_t) n * 4));
-        ME_CHECK(ctx, pos.ensure((size_t) n * 4));
         TimerScope ts(ctx, "cells");
-        hipLaunchKernelGGL(k_cell_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(), n,
-                           shift3, flags.as<unsigned int>());
-        ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), n));
-        unsigned int last_pos = 0, last_flag = 0;
-        ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-        ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ME_CHECK(ctx, ctx->red.ensure(64 * 8));
+        unsigned long long *d_hist = ctx->red.as<unsigned long long>();
+        ME_CHECK(ctx, hipMemsetAsync(d_hist, 0, 32 * 8, ctx->stream));
+        hipLaunchKernelGGL(k_level_hist, dim3((unsigned int) std::min<long long>(1024, (n + 255) / 256)), dim3(256), 0,
+                           ctx->stream, c.codes.as<unsigned long long>(), n, d_hist);
+        unsigned long long h_hist[32];
+        ME_CHECK(ctx, hipMemcpyAsync(h_hist, d_hist, sizeof(h_hist), hipMemcpyDeviceToHost, ctx->stream));
         ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        const long long n_cells = (long long) last_pos + last_flag;
-        ME_CHECK(ctx, c.cell_code.ensure((size_t) n_cells * 8));
-        ME_CHECK(ctx, c.cell_start.ensure((size_t) (n_cells + 1) * 4));
-        hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(),
-                           flags.as<unsigned int>(), pos.as<unsigned int>(), n, shift3,
-                           c.cell_code.as<unsigned long long>(), c.cell_start.as<unsigned int>());
-        hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, ctx->stream, c.cell_start.as<unsigned int>(), n_cells,
-                           (unsigned int) n);
-        unsigned long long hsize = 64;
-        while (hsize < 2ULL * (unsigned long long) n_cells) hsize <<= 1;
-        ME_CHECK(ctx, c.hkeys.ensure((size_t) hsize * 8));
-        ME_CHECK(ctx, c.hvals.ensure((size_t) hsize * 4));
-        ME_CHECK(ctx, hipMemsetAsync(c.hkeys.p, 0xFF, (size_t) hsize * 8, ctx->stream));
-        hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n_cells)), dim3(256), 0, ctx->stream,
-                           c.cell_code.as<unsigned long long>(), n_cells, c.hkeys.as<unsigned long long>(),
-                           c.hvals.as<unsigned int>(), (unsigned int) (hsize - 1));
-        GridView &g = c.grid;
-        g.cell_code = c.cell_code.as<unsigned long long>();
-        g.cell_start = c.cell_start.as<unsigned int>();
-        g.hkeys = c.hkeys.as<unsigned long long>();
-        g.hvals = c.hvals.as<unsigned int>();
-        g.hmask = (unsigned int) (hsize - 1);
-        g.n_cells = n_cells;
-        g.shift = c.shift;
+        long long acc = 1;
+        for (int k = kMortonBits; k >= 0; --k) {  // level k: cell edge fine_h * 2^k
+            if (k < kMortonBits) acc += (long long) h_hist[k];
+            c.level_unique[k] = (k == kMortonBits) ? 1 : acc;
+        }
+        // 1-NN grid: the finest level whose occupied cells hold >= 12 points on average (27-cell stencil ~ a few
+        // hundred candidates per query at most, yet a guaranteed radius of one cell edge resolves almost all queries)
+        int nn_shift = kMortonBits - 1;
+        for (int k = 0; k < kMortonBits; ++k)
+            if ((double) n / (double) c.level_unique[k] >= 12.0) {
+                nn_shift = k;
+                break;
+            }
+        ME_TRY(build_grid_table(ctx, c, c.shift, c.grid_tab, c.grid));
+        if (nn_shift == c.shift) {
+            c.nn_grid = c.grid;
+        } else {
+            ME_TRY(build_grid_table(ctx, c, nn_shift, c.nn_tab, c.nn_grid));
+        }
     }
     ME_CHECK(ctx, hipGetLastError());
     c.index_valid = true;

@@ -66,6 +66,17 @@ struct GridView {
     int shift;                            // fine Morton code >> (3*shift) = cell code
 };
 
+struct GridTable {
+    DevBuf cell_code, cell_start, hkeys, hvals;
+    int shift = -1;
+};
+
+// Morton frame of a cloud, as the kernels need it to place a foreign point into this cloud's grid
+struct FrameView {
+    double ox, oy, oz;  // origin (bbox min)
+    double fine_h;      // edge of the finest (21-bit) cell
+};
+
 struct Cloud {
     long long n = 0;
     bool uploaded = false;
@@ -82,11 +93,13 @@ struct Cloud {
     // BVH
     BvhView bvh{};
     DevBuf boxes;
-    // cell table
-    GridView grid{};
-    DevBuf cell_code, cell_start, hkeys, hvals;
+    // cell tables: `grid` at the radius level (MME), `nn_grid` at the level whose occupied cells hold ~16 points
+    // (1-NN fast path); they share storage when the two levels coincide
+    GridTable grid_tab, nn_tab;
+    GridView grid{}, nn_grid{};
+    long long level_unique[kMortonBits + 1] = {0};  // occupied cells per Morton level
     // last NN result with this cloud as the query (Morton-sorted query order)
-    DevBuf nn_d2, nn_idx;
+    DevBuf nn_d2, nn_idx, nn_list;
     int nn_ref_slot = -1;
     // voxel table (ascending key order)
     double vox_size = 0;
@@ -124,6 +137,7 @@ struct me_ctx {
     };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
+    long long nn_fallback = 0, nn_queries = 0;  // counted only while timers are on
 
     int fail(int code, const std::string &msg) {
         err = msg;
@@ -234,6 +248,35 @@ __device__ __forceinline__ long long block_sum_256_ll(long long v, long long *sm
     return r;
 }
 
+__device__ __forceinline__ unsigned long long spread21(unsigned long long x) {
+    x &= 0x1fffffULL;
+    x = (x | x << 32) & 0x1f00000000ffffULL;
+    x = (x | x << 16) & 0x1f0000ff0000ffULL;
+    x = (x | x << 8) & 0x100f00f00f00f00fULL;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+    x = (x | x << 2) & 0x1249249249249249ULL;
+    return x;
+}
+__device__ __forceinline__ unsigned int compact21(unsigned long long x) {
+    x &= 0x1249249249249249ULL;
+    x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ULL;
+    x = (x ^ (x >> 4)) & 0x100f00f00f00f00fULL;
+    x = (x ^ (x >> 8)) & 0x1f0000ff0000ffULL;
+    x = (x ^ (x >> 16)) & 0x1f00000000ffffULL;
+    x = (x ^ (x >> 32)) & 0x1fffffULL;
+    return (unsigned int) x;
+}
+__device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
+    const unsigned int lo = (unsigned int) __builtin_amdgcn_readlane((int) (unsigned int) v, lane);
+    const unsigned int hi = (unsigned int) __builtin_amdgcn_readlane((int) (unsigned int) (v >> 32), lane);
+    return ((unsigned long long) hi << 32) | lo;
+}
+
+// fine (21-bit/axis) grid coordinate of a coordinate in a cloud's frame — the ONE definition every kernel uses
+// (division, not reciprocal multiply: (p-o)/(h*2^-s) == ((p-o)/h)*2^s exactly, so a coarser cell is a bit prefix)
+__device__ __forceinline__ double fine_coord(double x, double o, double fine_h) { return floor((x - o) / fine_h); }
+
 __device__ __forceinline__ unsigned long long hash_u64(unsigned long long k) {
     k ^= k >> 33;
     k *= 0xff51afd7ed558ccdULL;
@@ -254,6 +297,56 @@ __device__ __forceinline__ int hash_lookup(const unsigned long long *__restrict_
         if (k == kEmptyKey) return -1;
         s = (s + 1) & mask;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-level candidate grouping shared by the radius (MME) and 1-NN grid kernels.
+//
+// Every lane holds one query and its grid cell (cx,cy,cz).  The group of a round = the pending lanes whose cell is
+// within Chebyshev distance 1 of the leader's (first pending lane's) cell.  Their cells span at most 3x3x3, so the
+// union of their 3x3x3 neighbourhoods is the group's cell bounding box grown by one: at most 5x5x5 = 125 cells,
+// each resolved by ONE hash probe (lane t takes cells t and t+64).  The caller then streams every non-empty run once
+// with wave-uniform addresses and lets ALL group lanes test each candidate: compared with one stencil per distinct
+// cell this shares candidate fetches between neighbouring cells and keeps the whole wave busy.
+// Returns whether this lane is in the group; (rs0,rc0) / (rs1,rc1) = start/count of this lane's two runs.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool wave_group_runs(bool pending, int cx, int cy, int cz, const GridView &g, int cell_lim,
+                                                int lane, int &rs0, int &rc0, int &rs1, int &rc1) {
+    const unsigned long long pm = __ballot(pending);  // caller guarantees pm != 0
+    const int leader = __ffsll((long long) pm) - 1;
+    const int lx = readlane_i(cx, leader), ly = readlane_i(cy, leader), lz = readlane_i(cz, leader);
+    const int ex = cx - lx, ey = cy - ly, ez = cz - lz;
+    const bool in = pending && ex >= -1 && ex <= 1 && ey >= -1 && ey <= 1 && ez >= -1 && ez <= 1;
+    const int x0 = lx - 1 - (__ballot(in && ex < 0) ? 1 : 0), x1 = lx + 1 + (__ballot(in && ex > 0) ? 1 : 0);
+    const int y0 = ly - 1 - (__ballot(in && ey < 0) ? 1 : 0), y1 = ly + 1 + (__ballot(in && ey > 0) ? 1 : 0);
+    const int z0 = lz - 1 - (__ballot(in && ez < 0) ? 1 : 0), z1 = lz + 1 + (__ballot(in && ez > 0) ? 1 : 0);
+    const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    const int n_keys = nx * ny * nz;  // <= 125
+    rs0 = rc0 = rs1 = rc1 = 0;
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        const int t = lane + 64 * slot;
+        if (t < n_keys) {
+            const int ix = x0 + t % nx, iy = y0 + (t / nx) % ny, iz = z0 + t / (nx * ny);
+            if (ix >= 0 && iy >= 0 && iz >= 0 && ix < cell_lim && iy < cell_lim && iz < cell_lim) {
+                const unsigned long long key = spread21((unsigned long long) ix) | (spread21((unsigned long long) iy) << 1) |
+                                               (spread21((unsigned long long) iz) << 2);
+                const int ci = hash_lookup(g.hkeys, g.hvals, g.hmask, key);
+                if (ci >= 0) {
+                    const int s = (int) g.cell_start[ci];
+                    const int c = (int) g.cell_start[ci + 1] - s;
+                    if (slot == 0) {
+                        rs0 = s;
+                        rc0 = c;
+                    } else {
+                        rs1 = s;
+                        rc1 = c;
+                    }
+                }
+            }
+        }
+    }
+    return in;
 }
 #endif
 

@@ -19,32 +19,6 @@
 
 namespace me {
 
-__device__ __forceinline__ unsigned long long spread21(unsigned long long x) {
-    x &= 0x1fffffULL;
-    x = (x | x << 32) & 0x1f00000000ffffULL;
-    x = (x | x << 16) & 0x1f0000ff0000ffULL;
-    x = (x | x << 8) & 0x100f00f00f00f00fULL;
-    x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
-    x = (x | x << 2) & 0x1249249249249249ULL;
-    return x;
-}
-__device__ __forceinline__ unsigned int compact21(unsigned long long x) {
-    x &= 0x1249249249249249ULL;
-    x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ULL;
-    x = (x ^ (x >> 4)) & 0x100f00f00f00f00fULL;
-    x = (x ^ (x >> 8)) & 0x1f0000ff0000ffULL;
-    x = (x ^ (x >> 16)) & 0x1f00000000ffffULL;
-    x = (x ^ (x >> 32)) & 0x1fffffULL;
-    return (unsigned int) x;
-}
-
-__device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
-    const unsigned int lo = (unsigned int) __builtin_amdgcn_readlane((int) (unsigned int) v, lane);
-    const unsigned int hi = (unsigned int) __builtin_amdgcn_readlane((int) (unsigned int) (v >> 32), lane);
-    return ((unsigned long long) hi << 32) | lo;
-}
-
 __global__ void __launch_bounds__(256)
 k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
       GridView g, double r2, int min_k, double *__restrict__ ent_s, unsigned char *__restrict__ valid_s,
@@ -72,49 +46,56 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
     double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
     bool done = !active;
 
-    for (;;) {
-        const unsigned long long pending = __ballot(!done);
-        if (pending == 0) break;
-        const int leader = __ffsll((long long) pending) - 1;
-        const unsigned long long cur = readlane_u64(mycell, leader);
-        const int cx = (int) compact21(cur), cy = (int) compact21(cur >> 1), cz = (int) compact21(cur >> 2);
-        // lanes 0..26 resolve one neighbour cell each
-        int nb_start = 0, nb_cnt = 0;
-        if (lane < 27) {
-            const int nx = cx + (lane % 3) - 1, ny = cy + ((lane / 3) % 3) - 1, nz = cz + (lane / 9) - 1;
-            if (nx >= 0 && ny >= 0 && nz >= 0 && nx < cell_lim && ny < cell_lim && nz < cell_lim) {
-                const unsigned long long key = spread21((unsigned long long) nx) | (spread21((unsigned long long) ny) << 1) |
-                                               (spread21((unsigned long long) nz) << 2);
-                const int ci = hash_lookup(g.hkeys, g.hvals, g.hmask, key);
-                if (ci >= 0) {
-                    nb_start = (int) g.cell_start[ci];
-                    nb_cnt = (int) g.cell_start[ci + 1] - nb_start;
-                }
+    const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
+
+    auto test = [&](const SPoint &p) {
+        const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+        const double d2 = (dx * dx + dy * dy) + dz * dz;  // bit-identical to the CPU path (no FMA)
+        if (d2 < r2) {                                    // strict, nanoflann RadiusResultSet [upstream]
+            ++k;
+            s1x += dx;
+            s1y += dy;
+            s1z += dz;
+            sxx = fma(dx, dx, sxx);
+            sxy = fma(dx, dy, sxy);
+            sxz = fma(dx, dz, sxz);
+            syy = fma(dy, dy, syy);
+            syz = fma(dy, dz, syz);
+            szz = fma(dz, dz, szz);
+        }
+    };
+    auto stream_run = [&](int cs, int ce, bool in) {
+        int j = cs;
+        for (; j + 1 < ce; j += 2) {  // two wave-uniform (scalar) fetches in flight
+            const SPoint p0 = sp[j];
+            const SPoint p1 = sp[j + 1];
+            if (in) {
+                test(p0);
+                test(p1);
             }
         }
-        const bool in = !done && (mycell == cur);
-        for (int n = 0; n < 27; ++n) {
-            const int cs = readlane_i(nb_start, n);
-            const int ce = cs + readlane_i(nb_cnt, n);
-            for (int j = cs; j < ce; ++j) {
-                const SPoint p = sp[j];  // wave-uniform address
-                if (in) {
-                    const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;  // bit-identical to the CPU path (no FMA)
-                    if (d2 < r2) {                                    // strict, nanoflann RadiusResultSet [upstream]
-                        ++k;
-                        s1x += dx;
-                        s1y += dy;
-                        s1z += dz;
-                        sxx = fma(dx, dx, sxx);
-                        sxy = fma(dx, dy, sxy);
-                        sxz = fma(dx, dz, sxz);
-                        syy = fma(dy, dy, syy);
-                        syz = fma(dy, dz, syz);
-                        szz = fma(dz, dz, szz);
-                    }
-                }
-            }
+        if (j < ce) {
+            const SPoint p0 = sp[j];
+            if (in) test(p0);
+        }
+    };
+
+    while (__ballot(!done)) {
+        int rs0, rc0, rs1, rc1;
+        const bool in = wave_group_runs(!done, cx, cy, cz, g, cell_lim, lane, rs0, rc0, rs1, rc1);
+        unsigned long long m = __ballot(rc0 > 0);
+        while (m) {
+            const int n = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            const int cs = readlane_i(rs0, n);
+            stream_run(cs, cs + readlane_i(rc0, n), in);
+        }
+        m = __ballot(rc1 > 0);
+        while (m) {
+            const int n = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            const int cs = readlane_i(rs1, n);
+            stream_run(cs, cs + readlane_i(rc1, n), in);
         }
         if (in) done = true;
     }

@@ -39,29 +39,147 @@ __device__ __forceinline__ void scan_leaf(const SPoint *__restrict__ rsp, long l
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Fast path: uniform-grid 1-NN.  A wavefront owns 64 consecutive (Morton-ordered) queries.  For each distinct
+// reference-grid cell among its lanes it resolves the 27 neighbour runs (one hash probe per lane) and streams
+// them with wave-uniform addresses (scalar loads), every lane keeping its own running minimum in fp64.
+// A lane is RESOLVED when its best distance does not exceed its distance to the faces of the 3x3x3 block: every
+// reference point outside the block is farther, so the minimum is the exact global minimum.  Unresolved lanes
+// (no neighbour within about one cell edge: outliers, non-overlapping map regions, queries outside the reference
+// bbox) are appended to a list, with their best-so-far as the initial bound, for the BVH kernel below.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, GridView g,
+          FrameView fr, double *__restrict__ d2_out, int *__restrict__ idx_out, unsigned int *__restrict__ list,
+          unsigned int *__restrict__ list_count) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int per = gridDim.x / 8;  // XCD-aware chunking, gridDim.x is a multiple of 8
+    const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const long long i = q_begin + (long long) vb * blockDim.x + threadIdx.x;
+    const bool active = i < q_end;
+    const int cell_bits = kMortonBits - g.shift;
+    const int cell_lim = 1 << cell_bits;
+    const double cell_h = ldexp(fr.fine_h, g.shift);
+
+    double qx = 0, qy = 0, qz = 0;
+    int mcx = 0, mcy = 0, mcz = 0;  // the query's cell in the REFERENCE cloud's grid
+    bool in_grid = false;
+    if (active) {
+        const SPoint q = qsp[i];
+        qx = q.x;
+        qy = q.y;
+        qz = q.z;
+        const double fx = fine_coord(qx, fr.ox, fr.fine_h), fy = fine_coord(qy, fr.oy, fr.fine_h),
+                     fz = fine_coord(qz, fr.oz, fr.fine_h);
+        const double lim = 2097151.0;
+        in_grid = fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx <= lim && fy <= lim && fz <= lim;
+        if (in_grid) {
+            mcx = (int) ((unsigned int) fx >> g.shift);
+            mcy = (int) ((unsigned int) fy >> g.shift);
+            mcz = (int) ((unsigned int) fz >> g.shift);
+        }
+    }
+    double best = INFINITY;
+    long long best_i = 0x7fffffffffffffffLL;
+    bool done = !active || !in_grid;
+
+    auto test = [&](const SPoint &p) {
+        const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
+        if (d < best || (d == best && p.idx < best_i)) {
+            best = d;
+            best_i = p.idx;
+        }
+    };
+    auto stream_run = [&](int cs, int ce, bool in) {
+        int j = cs;
+        for (; j + 1 < ce; j += 2) {  // two wave-uniform (scalar) fetches in flight
+            const SPoint p0 = rsp[j];
+            const SPoint p1 = rsp[j + 1];
+            if (in) {
+                test(p0);
+                test(p1);
+            }
+        }
+        if (j < ce) {
+            const SPoint p0 = rsp[j];
+            if (in) test(p0);
+        }
+    };
+    // (the candidate set of a round is a superset of the lane's own 3x3x3 block; extra candidates only help)
+    while (__ballot(!done)) {
+        int rs0, rc0, rs1, rc1;
+        const bool in = wave_group_runs(!done, mcx, mcy, mcz, g, cell_lim, lane, rs0, rc0, rs1, rc1);
+        unsigned long long m = __ballot(rc0 > 0);
+        while (m) {
+            const int n = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            const int cs = readlane_i(rs0, n);
+            stream_run(cs, cs + readlane_i(rc0, n), in);
+        }
+        m = __ballot(rc1 > 0);
+        while (m) {
+            const int n = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            const int cs = readlane_i(rs1, n);
+            stream_run(cs, cs + readlane_i(rc1, n), in);
+        }
+        if (in) done = true;
+    }
+
+    bool unresolved = false;
+    if (active) {
+        unresolved = true;
+        if (in_grid && best < INFINITY) {
+            // distance from q to the faces of the 3x3x3 cell block around its cell (>= one cell edge... minus where
+            // q sits in its cell); anything outside the block is at least that far away
+            const double lox = fr.ox + (double) (mcx - 1) * cell_h, hix = fr.ox + (double) (mcx + 2) * cell_h;
+            const double loy = fr.oy + (double) (mcy - 1) * cell_h, hiy = fr.oy + (double) (mcy + 2) * cell_h;
+            const double loz = fr.oz + (double) (mcz - 1) * cell_h, hiz = fr.oz + (double) (mcz + 2) * cell_h;
+            double gmin = fmin(fmin(qx - lox, hix - qx), fmin(fmin(qy - loy, hiy - qy), fmin(qz - loz, hiz - qz)));
+            gmin *= (1.0 - 1e-9);  // rounding slack of the cell assignment
+            unresolved = !(gmin > 0.0 && best <= gmin * gmin);
+        }
+        d2_out[i] = best;  // final if resolved, initial bound otherwise
+        idx_out[i] = (best_i == 0x7fffffffffffffffLL) ? -1 : (int) best_i;
+    }
+    // wave-aggregated append of the unresolved lanes
+    const unsigned long long um = __ballot(unresolved);
+    if (um) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(list_count, (unsigned int) __popcll(um));
+        base = (unsigned int) readlane_i((int) base, 0);
+        if (unresolved) list[base + (unsigned int) __popcll(um & ((1ULL << lane) - 1ULL))] = (unsigned int) (i - q_begin);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// General path: nearest-first BVH walk (see the header).  `list` == nullptr: every query of [q_begin, q_end);
+// otherwise the queries q_begin + list[t], t < *list_count, starting from the bound the grid pass left behind.
+// ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
-      BvhView bvh, double *__restrict__ d2_out, int *__restrict__ idx_out) {
+      BvhView bvh, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
+      const unsigned int *__restrict__ list_count) {
     __shared__ long long s_count[kMaxLevels], s_off[kMaxLevels];
     if (threadIdx.x < kMaxLevels) {
         s_count[threadIdx.x] = bvh.count[threadIdx.x];
         s_off[threadIdx.x] = bvh.off[threadIdx.x];
     }
     __syncthreads();
-    // XCD-aware chunking: block b runs on XCD b % 8; give each XCD one contiguous eighth of the (Morton-ordered)
-    // queries so the BVH nodes / leaves it touches stay in that XCD's private L2.
-    // (gridDim.x is a multiple of 8.)
-    const unsigned int per = gridDim.x / 8;
-    const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    const long long i = q_begin + (long long) vb * blockDim.x + threadIdx.x;
-    if (i >= q_end) return;
-
-    const SPoint q = qsp[i];
-    const double qx = q.x, qy = q.y, qz = q.z;
     const int L = bvh.n_levels - 1;
     const float *__restrict__ boxes = bvh.boxes;
+    const long long n_items = list ? (long long) *list_count : (q_end - q_begin);
+    for (long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += (long long) gridDim.x * blockDim.x) {
+    const long long i = q_begin + (list ? (long long) list[t] : t);
+    const SPoint q = qsp[i];
+    const double qx = q.x, qy = q.y, qz = q.z;
     double best = INFINITY;
     long long best_i = 0x7fffffffffffffffLL;
+    if (list) {
+        best = d2_out[i];
+        const int bi = idx_out[i];
+        if (bi >= 0) best_i = bi;
+    }
 
     if (L == 0) {
         scan_leaf(rsp, nr, 0, qx, qy, qz, best, best_i);  // the whole cloud is one leaf
@@ -120,6 +238,7 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
     }
     d2_out[i] = best;
     idx_out[i] = (int) best_i;
+    }  // grid-stride loop over queries
 }
 
 // ---- un-permute results to the caller's (original) query order ----
@@ -271,9 +390,30 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
     ctx->shard_range(q.n, b, e);
     if (e > b) {
         const unsigned int nb = (unsigned int) (((e - b + 255) / 256 + 7) / 8 * 8);  // multiple of 8 (XCD chunking)
-        TimerScope ts(ctx, "nn1");
-        hipLaunchKernelGGL(k_nn1, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
-                           r.bvh, q.nn_d2.as<double>(), q.nn_idx.as<int>());
+        ME_CHECK(ctx, q.nn_list.ensure((size_t) (e - b) * 4 + 64));
+        ME_CHECK(ctx, ctx->red.ensure(64));
+        unsigned int *d_cnt = ctx->red.as<unsigned int>();
+        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+        FrameView fr{r.origin[0], r.origin[1], r.origin[2], r.fine_h};
+        {
+            TimerScope ts(ctx, "nn_grid");
+            hipLaunchKernelGGL(k_nn_grid, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
+                               r.nn_grid, fr, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
+        }
+        {
+            // the list length stays on the device: a fixed grid strides over it (no host round trip)
+            const unsigned int nbf = (unsigned int) std::min<long long>(nb, 256 * 16);
+            TimerScope ts(ctx, "nn1");
+            hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
+                               r.bvh, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
+        }
+        if (ctx->timers_on) {  // fallback share, for the bench report
+            unsigned int h = 0;
+            ME_CHECK(ctx, hipMemcpyAsync(&h, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+            ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->nn_fallback += h;
+            ctx->nn_queries += e - b;
+        }
     }
     ME_CHECK(ctx, hipGetLastError());
     q.nn_ref_slot = rslot;

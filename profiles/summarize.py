@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 output (gpurun_out/prof_rNN/{stats,pmc_fetch,pmc_write}) into small tracked summaries.
+
+usage: python profiles/summarize.py gpurun_out/prof_r01 profiles/r01
+writes <out>_kernel_stats.csv (per-kernel calls / avg ms / % of GPU time, names shortened) and
+<out>_hbm_traffic.json (per-launch FETCH_SIZE / WRITE_SIZE in bytes for the engine's own kernels, with the gfx950
+correction of /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE x2 for wide coalesced streaming reads is NOT
+applied blindly — both the raw and the x2 figure are reported, the kernels here are gather-dominated).
+"""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    m = re.match(r"(?:void )?(me::k_\w+)", name)
+    if m:
+        return m.group(1)
+    if "radix_sort_onesweep_iteration" in name or "onesweep_iteration_kernel" in name:
+        return "rocprim::radix_sort_onesweep_iteration" + ("[torch]" if "at::cuda" in name else "")
+    if "radix_sort_onesweep_global_offsets" in name or "onesweep_histograms" in name:
+        return "rocprim::radix_sort_onesweep_histogram"
+    if "scan_impl" in name or "lookback_scan" in name:
+        return "rocprim::scan"
+    if name.startswith("void at::native") or "at::native" in name:
+        return "torch::" + re.sub(r"<.*", "", name.split("at::native::")[1])[:60] + " [synthetic data generation]"
+    return re.sub(r"\(.*", "", name)[:80]
+
+
+def main(src, out):
+    rows = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(f"{src}/stats/*/*_kernel_stats.csv"):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Name"])
+            rows[k][0] += int(r["Calls"])
+            rows[k][1] += float(r["TotalDurationNs"])
+    tot = sum(v[1] for v in rows.values()) or 1.0
+    with open(out + "_kernel_stats.csv", "w") as fo:
+        fo.write("kernel,calls,total_ms,avg_ms,percent\n")
+        for k, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            fo.write(f"{k},{c},{t/1e6:.3f},{t/1e6/c:.4f},{100*t/tot:.2f}\n")
+    traffic = {}
+    for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        acc = defaultdict(lambda: [0, 0.0])
+        for f in glob.glob(f"{src}/{sub}/*/*_counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != cname:
+                    continue
+                k = short(r["Kernel_Name"])
+                if not k.startswith("me::"):
+                    continue
+                acc[k][0] += 1
+                acc[k][1] += float(r["Counter_Value"]) * 1024.0  # rocprofv3 reports KiB
+        for k, (c, v) in acc.items():
+            traffic.setdefault(k, {})[cname + "_bytes_per_launch"] = v / c
+            traffic[k]["launches"] = c
+    for k, d in traffic.items():
+        f_, w_ = d.get("FETCH_SIZE_bytes_per_launch", 0.0), d.get("WRITE_SIZE_bytes_per_launch", 0.0)
+        d["hbm_bytes_per_launch_raw"] = f_ + w_
+        d["hbm_bytes_per_launch_fetch_x2"] = 2 * f_ + w_
+    json.dump(traffic, open(out + "_hbm_traffic.json", "w"), indent=1, sort_keys=True)
+    print(open(out + "_kernel_stats.csv").read()[:1500])
+    print(json.dumps({k: v for k, v in traffic.items() if k in ("me::k_nn1", "me::k_mme")}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
