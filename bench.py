@@ -45,55 +45,14 @@ def parse():
 
 
 def suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme):
-    """One full pass; returns the scalars.  All ranks run it; per-point passes are slab-sharded."""
-    import numpy as np
+    """One full pass; returns the scalars.  All ranks run it; per-point passes are slab-sharded, partial sums are
+    all-reduced over RCCL (cloud_map_evaluation_amd/dist.py)."""
+    import torch
 
-    from cloud_map_evaluation_amd.engine import ME_GATE_LE_UNSQUARED, ME_SLOT_EST, ME_SLOT_GT
+    from cloud_map_evaluation_amd import dist as medist
 
-    eng.upload(ME_SLOT_EST, est_d, T=np.eye(4), cell_size=P.nn_radius_)  # initial_matrix (identity) + index
-    eng.upload(ME_SLOT_GT, gt_d, cell_size=P.nn_radius_)
-    # --- MME (map_eval.cpp:56) ---
-    m_e = eng.mme(ME_SLOT_EST, P.nn_radius_, 10, per_point=False)
-    m_g = eng.mme(ME_SLOT_GT, P.nn_radius_, 5, per_point=False) if evaluate_gt_mme else (0.0, None, None, 0, 0.0)
-    # --- AC / COM / CD (map_eval.cpp:76, :1194) ---
-    parts = []
-    for q, r in ((ME_SLOT_EST, ME_SLOT_GT), (ME_SLOT_GT, ME_SLOT_EST)):
-        eng.nn1(q, r, fetch=False)
-        parts.append(eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_))
-    vec = []
-    for pp in parts:
-        vec += [pp.n_corr] + list(pp.n_inl) + list(pp.sum_d) + list(pp.sum_d2) + [pp.sum_sqrt_all]
-    vec += [m_e[4], m_e[3], m_g[4], m_g[3]]
-    vec = np.array(vec, dtype=np.float64)  # counts < 2^53: exact in fp64
-    if world > 1:
-        import torch
-
-        t = torch.from_numpy(vec).cuda()
-        dist.all_reduce(t)  # RCCL sum of the shard partials
-        vec = t.cpu().numpy()
-    stats = []
-    for i, (q, n_src) in enumerate(((ME_SLOT_EST, n_e), (ME_SLOT_GT, n_g))):
-        o = i * 17
-        C = vec[o]
-        mean = vec[o + 6:o + 11] / C if C > 0 else np.full(5, np.nan)
-        sig = eng.nn_sigma_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, mean)
-        if world > 1:
-            import torch
-
-            t = torch.from_numpy(sig).cuda()
-            dist.all_reduce(t)
-            sig = t.cpu().numpy()
-        stats.append(dict(n_corr=int(C), number=vec[o + 1:o + 6].copy(), mean=mean,
-                          rmse=np.sqrt(vec[o + 11:o + 16] / C) if C > 0 else np.full(5, np.nan),
-                          fitness=vec[o + 1:o + 6] / n_src, sigma=np.sqrt(sig / C) if C > 0 else np.full(5, np.nan),
-                          mean_nn=vec[o + 16] / n_src))
-    cd = stats[0]["mean_nn"] + stats[1]["mean_nn"]
-    mme_est = vec[34] / vec[35] if vec[35] > 0 else 0.0
-    mme_gt = vec[36] / vec[37] if vec[37] > 0 else 0.0
-    # --- AWD / SCS (map_eval.cpp:85) — voxel tables are small; every rank computes them (no exchange needed) ---
-    v = eng.calculateVMD(P.vmd_voxel_size_, rows=False)
-    return dict(ac=stats[0]["rmse"], com=stats[0]["fitness"], cd=cd, mme_est=mme_est, mme_gt=mme_gt, awd=v["awd"],
-                scs=v["scs"], n_w=v["n_rows"], mme_valid=int(vec[35]))
+    return medist.suite_step(eng, dist if world > 1 else None, torch.device("cuda", torch.cuda.current_device()), est_d, gt_d,
+                             P, evaluate_gt_mme)
 
 
 def cpu_baseline(args, P, evaluate_gt_mme):

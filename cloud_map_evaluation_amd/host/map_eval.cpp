@@ -1,0 +1,435 @@
+// map_eval.cpp — host orchestration mirroring MapEval::process (map_eval/src/map_eval.cpp:4-102): same config keys,
+// same result-file lines, same output file names; every metric comes from libmapeval_hip.so (no CPU metric path).
+#include "map_eval.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <ctime>
+#include <filesystem>
+#include <iomanip>
+#include <iostream>
+#include <numeric>
+#include <sstream>
+
+#include "pcd_io.hpp"
+#include "yaml_lite.hpp"
+
+namespace fs = std::filesystem;
+
+namespace {
+
+struct TicToc {  // include/tic_toc.h:10-24 — milliseconds since construction
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double toc() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// Eigen's default IOFormat for `os << v.transpose()`: entries right-aligned to the widest one, separated by one space.
+std::string eigen_row(const Vector5d &v, int precision) {
+    std::vector<std::string> s;
+    size_t w = 0;
+    for (double x : v) {
+        std::ostringstream o;
+        o << std::fixed << std::setprecision(precision) << x;
+        s.push_back(o.str());
+        w = std::max(w, s.back().size());
+    }
+    std::string out;
+    for (size_t i = 0; i < s.size(); ++i) {
+        if (i) out += " ";
+        out += std::string(w - s[i].size(), ' ') + s[i];
+    }
+    return out;
+}
+
+Vector5d to5(const double *p) { return Vector5d{{p[0], p[1], p[2], p[3], p[4]}}; }
+
+void push_results(std::vector<Vector5d> &dst, const me_nn_stats_out &o) {
+    // result.push_back(mean, rmse, fitness, sigma, number) (map_eval.cpp:1140-1144)
+    dst.clear();
+    dst.push_back(to5(o.mean));
+    dst.push_back(to5(o.rmse));
+    dst.push_back(to5(o.fitness));
+    dst.push_back(to5(o.sigma));
+    dst.push_back(to5(o.number));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+void Param::printParam() const {
+    std::cout << "\n[==================== Experiment Configuration ====================]\n"
+              << "Experiment Name: " << name_ << "\n"
+              << "Evaluation Map Path: " << evaluation_map_pcd_path_ << "\n"
+              << "Ground Truth Map Path: " << map_gt_path_ << "\n"
+              << "Result Save Path: " << result_path_ << "\n"
+              << "ICP Maximum Distance: " << icp_max_distance_ << "\n"
+              << "Evaluation Method: " << evaluation_method_ << "\n"
+              << "Truncation Distance: " << eigen_row(trunc_dist_, 6) << "\n"
+              << "Save Immediate Result: " << save_immediate_result_ << "\n"
+              << "Evaluate MME: " << evaluate_mme_ << "\n"
+              << "Evaluate Ground Truth MME: " << evaluate_gt_mme_ << "\n"
+              << "Nearest Neighbor Radius: " << nn_radius_ << "\n"
+              << "Use Initial Matrix for Evaluation: " << evaluate_using_initial_ << "\n"
+              << "Voxel Size for VMD: " << vmd_voxel_size_ << "\n"
+              << "GPU device: " << gpu_device << "\n"
+              << "[====================================================================]\n";
+}
+
+Param loadParametersFromYAML(const std::string &yaml_file_path) {
+    // Same required / optional key split as map_eval_main.cpp:120-208 (a missing required key throws).
+    const yaml_lite::Document config = yaml_lite::Document::load_file(yaml_file_path);
+    Param param;
+    param.evaluation_method_ = config.as_int("registration_methods");
+    param.icp_max_distance_ = config.as_double("icp_max_distance");
+    if (config.has("accuracy_level") && config.at("accuracy_level").seq.size() >= 5)
+        for (int i = 0; i < 5; ++i) param.trunc_dist_[i] = yaml_lite::Document::to_double(config.at("accuracy_level").seq[i], "accuracy_level");
+    if (config.has("initial_matrix") && config.at("initial_matrix").rows.size() >= 4)
+        for (int i = 0; i < 4; ++i) {
+            const auto &row = config.at("initial_matrix").rows[i];
+            if (row.size() < 4) throw std::runtime_error("initial_matrix: each row needs 4 numbers");
+            for (int j = 0; j < 4; ++j) param.initial_matrix_[4 * i + j] = yaml_lite::Document::to_double(row[j], "initial_matrix");
+        }
+    param.save_immediate_result_ = config.as_bool("save_immediate_result");
+    param.evaluate_mme_ = config.as_bool("evaluate_mme");
+    param.evaluate_gt_mme_ = config.as_bool("evaluate_gt_mme");
+    param.evaluate_using_initial_ = config.as_bool("evaluate_using_initial");
+    param.nn_radius_ = config.as_double("nn_radius");
+    param.vmd_voxel_size_ = config.as_double("vmd_voxel_size");
+    param.downsample_size = config.as_double("downsample_size");
+    param.evaluation_map_pcd_path_ = config.as_string("estimate_map_path");
+    param.map_gt_path_ = config.as_string("gt_map_path");
+    param.name_ = config.as_string("scene_name");
+    if (!param.evaluation_map_pcd_path_.empty() && param.evaluation_map_pcd_path_.back() != '/') param.evaluation_map_pcd_path_ += '/';
+    param.result_path_ = param.evaluation_map_pcd_path_ + "map_results/";
+    if (config.has("pcd_file_name")) param.pcd_file_name_ = config.as_string("pcd_file_name");
+    if (config.has("evaluate_noised_gt")) param.evaluate_noised_gt_ = config.as_bool("evaluate_noised_gt");
+    if (config.has("noise_std_dev")) param.noise_std_dev_ = config.as_double("noise_std_dev");
+    if (config.has("voxel_size")) param.voxel_size_ = config.as_double("voxel_size");
+    if (config.has("use_visualization")) param.use_visualization = config.as_bool("use_visualization");
+    param.enable_debug = config.as_bool("enable_debug");
+    if (config.has("use_tbb_mme")) param.use_tbb_mme = config.as_bool("use_tbb_mme");
+    if (config.has("gpu_device")) param.gpu_device = config.as_int("gpu_device");
+    if (config.has("strict_reference")) param.strict_reference = config.as_bool("strict_reference");
+    return param;
+}
+
+std::string paramToJson(const Param &p) {
+    std::ostringstream o;
+    o << std::setprecision(17);
+    auto b = [](bool v) { return v ? "true" : "false"; };
+    o << "{\"registration_methods\": " << p.evaluation_method_ << ", \"icp_max_distance\": " << p.icp_max_distance_
+      << ", \"accuracy_level\": [";
+    for (int i = 0; i < 5; ++i) o << (i ? ", " : "") << p.trunc_dist_[i];
+    o << "], \"initial_matrix\": [";
+    for (int i = 0; i < 16; ++i) o << (i ? ", " : "") << p.initial_matrix_[i];
+    o << "], \"save_immediate_result\": " << b(p.save_immediate_result_) << ", \"evaluate_mme\": " << b(p.evaluate_mme_)
+      << ", \"evaluate_gt_mme\": " << b(p.evaluate_gt_mme_) << ", \"evaluate_using_initial\": " << b(p.evaluate_using_initial_)
+      << ", \"nn_radius\": " << p.nn_radius_ << ", \"vmd_voxel_size\": " << p.vmd_voxel_size_
+      << ", \"downsample_size\": " << p.downsample_size << ", \"estimate_map_path\": \"" << p.evaluation_map_pcd_path_
+      << "\", \"gt_map_path\": \"" << p.map_gt_path_ << "\", \"scene_name\": \"" << p.name_ << "\", \"pcd_file_name\": \""
+      << p.pcd_file_name_ << "\", \"enable_debug\": " << b(p.enable_debug) << ", \"use_tbb_mme\": " << b(p.use_tbb_mme)
+      << ", \"use_visualization\": " << b(p.use_visualization) << ", \"result_path\": \"" << p.result_path_
+      << "\", \"gpu_device\": " << p.gpu_device << ", \"strict_reference\": " << b(p.strict_reference) << "}";
+    return o.str();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+MapEval::MapEval(Param &param) : param_(param), map_3d_(new PointCloud), gt_3d_(new PointCloud) {
+    // results sub-folder by file name (map_eval.h:143-155), created next to the estimated map (:158-164)
+    if (param_.pcd_file_name_ == "merged_maps_all_trans.pcd") subfolder = "merged_maps_all_results/";
+    else if (param_.pcd_file_name_ == "merged_maps_s0_trans.pcd") subfolder = "merged_maps_s0_results/";
+    else if (param_.pcd_file_name_ == "merged_maps_s1_trans.pcd") subfolder = "merged_maps_s1_results/";
+    else subfolder = "map_results/";
+    results_subfolder = param_.evaluation_map_pcd_path_ + subfolder;
+    std::cout << "INFO: Saving results to: " << results_subfolder << std::endl;
+    std::error_code ec;
+    if (!fs::exists(results_subfolder)) fs::create_directory(results_subfolder, ec);
+    results_file_path = results_subfolder + "map_results.txt";
+    file_result.open(results_file_path, std::ios::app);  // append mode (:168)
+    if (!file_result.is_open()) std::cerr << "ERROR: Failed to open results file at " << results_file_path << std::endl;
+    const std::time_t now_c = std::chrono::system_clock::to_time_t(std::chrono::system_clock::now());
+    std::stringstream time_stream;
+    time_stream << std::put_time(std::localtime(&now_c), "%Y-%m-%d %X");
+    file_result << param_.name_ << " ===================== " << time_stream.str() << " ===================== " << std::endl;
+    file_result << "Ground Truth Path: " << param_.map_gt_path_ << std::endl;
+    file_result << "Evaluation Map Path: " << param_.evaluation_map_pcd_path_ + param_.pcd_file_name_ << std::endl;
+    std::cout << "INFO: Evaluation details saved to " << results_file_path << std::endl;
+}
+
+MapEval::~MapEval() {
+    if (ctx_) me_destroy(ctx_);
+    file_result.close();
+}
+
+int MapEval::fail(const std::string &msg) {
+    last_error = msg;
+    std::cerr << "ERROR: " << msg << std::endl;
+    return -1;
+}
+
+void MapEval::VoxelDownSample(PointCloud &cloud, double voxel_size) {
+    // open3d::geometry::PointCloud::VoxelDownSample [upstream]: voxel index = floor((p - (min_bound - vs/2)) / vs), output =
+    // mean of the points of each voxel.  Output order here: ascending voxel index (Open3D: hash-map iteration order).
+    if (!(voxel_size > 0) || cloud.IsEmpty()) return;
+    const size_t n = cloud.size();
+    double mn[3] = {cloud.points_[0], cloud.points_[1], cloud.points_[2]};
+    for (size_t i = 1; i < n; ++i)
+        for (int d = 0; d < 3; ++d) mn[d] = std::min(mn[d], cloud.points_[3 * i + d]);
+    for (int d = 0; d < 3; ++d) mn[d] -= voxel_size * 0.5;
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t key = 0;
+        for (int d = 0; d < 3; ++d) {
+            const double r = std::floor((cloud.points_[3 * i + d] - mn[d]) / voxel_size);
+            if (r < 0 || r >= 2097152.0) throw std::runtime_error("VoxelDownSample: voxel_size too small for the cloud extent");
+            key = (key << 21) | (uint64_t) r;
+        }
+        keyed[i] = {key, (uint32_t) i};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<double> out;
+    out.reserve(n / 2 * 3);
+    size_t i = 0;
+    while (i < n) {
+        size_t j = i;
+        double s[3] = {0, 0, 0};
+        while (j < n && keyed[j].first == keyed[i].first) {
+            for (int d = 0; d < 3; ++d) s[d] += cloud.points_[3 * (size_t) keyed[j].second + d];
+            ++j;
+        }
+        for (int d = 0; d < 3; ++d) out.push_back(s[d] / (double) (j - i));
+        i = j;
+    }
+    cloud.points_.swap(out);
+}
+
+int MapEval::process() {
+    TicToc tic_toc;
+    std::string err;
+    // ground truth: .pcd or .ply by extension (map_eval.cpp:9-17)
+    const std::string ext = param_.map_gt_path_.substr(param_.map_gt_path_.find_last_of(".") + 1);
+    bool ok_gt;
+    if (ext == "pcd") ok_gt = pcio::read_pcd(param_.map_gt_path_, gt_3d_->points_, &err);
+    else if (ext == "ply") ok_gt = pcio::read_ply(param_.map_gt_path_, gt_3d_->points_, &err);
+    else return fail("Unsupported ground truth file format: " + param_.map_gt_path_);
+    if (!ok_gt) std::cerr << "WARNING: " << err << std::endl;
+    const bool success = pcio::read_pcd(param_.evaluation_map_pcd_path_ + param_.pcd_file_name_, map_3d_->points_, &err);
+    if (param_.enable_debug)
+        std::cout << "INFO: Loading map point cloud from: " << param_.evaluation_map_pcd_path_ + param_.pcd_file_name_ << std::endl;
+    if (!success) return fail("Failed to load point cloud from the specified path.");
+    if (map_3d_->IsEmpty() || gt_3d_->IsEmpty()) return fail("One or both point clouds are empty!");
+
+    VoxelDownSample(*map_3d_, param_.downsample_size);  // (:38-39)
+    VoxelDownSample(*gt_3d_, param_.downsample_size);
+    file_result << std::fixed << std::setprecision(15) << "Estimated-Ground Truth point count: " << map_3d_->size() << " / "
+                << gt_3d_->size() << std::endl;
+    if (param_.enable_debug)
+        std::cout << "INFO: Loaded point clouds: " << map_3d_->size() << " points (Map), " << gt_3d_->size()
+                  << " points (Ground Truth)." << std::endl;
+    t1 = tic_toc.toc();
+
+    // ---- the GPU engine: no CPU fallback ----
+    ctx_ = me_create(param_.gpu_device, 0);
+    if (!ctx_) return fail(std::string("GPU engine unavailable: ") + me_last_error(nullptr));
+    me_timers_enable(ctx_, 1);
+    // The reference computes MME on the map as loaded (:56) and transforms it afterwards, inside
+    // calculateMetricsWithInitialMatrix (:1206).  With an identity initial_matrix (the shipped configs) one upload serves
+    // every metric; otherwise the map is uploaded untransformed for MME and re-uploaded with T for AC/COM/CD/AWD/SCS.
+    const double *T = param_.evaluate_using_initial_ ? param_.initial_matrix_.data() : nullptr;
+    bool identity = true;
+    for (int i = 0; i < 16 && T; ++i) identity = identity && (T[i] == ((i % 5 == 0) ? 1.0 : 0.0));
+    const bool mme_before_transform = param_.evaluate_mme_ && T && !identity;
+    if (me_upload_cloud(ctx_, ME_SLOT_GT, gt_3d_->points_.data(), (int64_t) gt_3d_->size(), nullptr, param_.nn_radius_) != ME_OK ||
+        me_upload_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data(), (int64_t) map_3d_->size(), mme_before_transform ? nullptr : T,
+                        param_.nn_radius_) != ME_OK)
+        return fail(me_last_error(ctx_));
+
+    if (param_.evaluate_mme_) {
+        if (param_.enable_debug) std::cout << "INFO: Starting MME calculation..." << std::endl;
+        computeMME(*map_3d_, *gt_3d_);
+        if (!last_error.empty()) return -1;
+        if (param_.save_immediate_result_) saveMmeResults();
+        t2 = tic_toc.toc();
+        if (param_.enable_debug) std::cout << "INFO: MME calculation completed in: " << (t2 - t1) / 1000.0 << " seconds." << std::endl;
+    } else {
+        t2 = t1;
+    }
+
+    if (param_.evaluate_using_initial_) {
+        if (param_.enable_debug) std::cout << "INFO: Using initial matrix without registration." << std::endl;
+        if (mme_before_transform &&
+            me_upload_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data(), (int64_t) map_3d_->size(), T, param_.nn_radius_) != ME_OK)
+            return fail(me_last_error(ctx_));
+        if (T) me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data());  // *map_3d_ = map_3d_->Transform(...) (:1206)
+        calculateMetricsWithInitialMatrix();
+        if (!last_error.empty()) return -1;
+    } else {
+        // performRegistration (map_eval.cpp:191-237) = Open3D ICP / GICP: a third-party optimiser, outside the GPU hot path
+        // (SURVEY.md section 8f rank 2).  Align the map first and evaluate with evaluate_using_initial: true.
+        return fail("evaluate_using_initial: false needs ICP registration, which this build does not provide; "
+                    "pass the alignment as initial_matrix and set evaluate_using_initial: true");
+    }
+    t5 = t4 = t3 = tic_toc.toc();
+
+    calculateVMD();
+    if (!last_error.empty()) return -1;
+    if (param_.enable_debug) std::cout << "INFO: VMD calculation completed." << std::endl;
+    if (param_.save_immediate_result_) saveRegistrationResults();
+    if (param_.enable_debug) std::cout << "INFO: Results saved successfully." << std::endl;
+    return 0;
+}
+
+void MapEval::computeMME(PointCloud &cloud, PointCloud &gt) {
+    // est: ComputeMeanMapEntropyUsingNormal[TBB] k >= 10 (map_eval.cpp:1675); gt: ComputeMeanMapEntropy k >= 5 (:1458)
+    est_entropies.assign(cloud.size(), 0.0);
+    valid_entropy_points.assign(cloud.size(), 0);
+    double s = 0;
+    int64_t nv = 0;
+    if (me_mme(ctx_, ME_SLOT_EST, param_.nn_radius_, 10, est_entropies.data(), valid_entropy_points.data(), &s, &nv) != ME_OK) {
+        fail(me_last_error(ctx_));
+        return;
+    }
+    mme_est = nv > 0 ? s / (double) nv : 0.0;
+    if (param_.enable_debug)
+        std::cout << "TBB MME Valid_points " << nv * 100.0 / (double) cloud.size() << "% " << nv << " " << cloud.size() << std::endl;
+    if (nv * 100.0 / (double) cloud.size() < 0.6) std::cerr << "valid points is too small, please check the input point cloud" << std::endl;
+    if (param_.evaluate_gt_mme_) {
+        gt_entropies.assign(gt.size(), 0.0);
+        std::vector<uint8_t> gv(gt.size(), 0);
+        if (me_mme(ctx_, ME_SLOT_GT, param_.nn_radius_, 5, gt_entropies.data(), gv.data(), &s, &nv) != ME_OK) {
+            fail(me_last_error(ctx_));
+            return;
+        }
+        mme_gt = nv > 0 ? s / (double) nv : 0.0;
+        std::cout << "MME EST-GT: " << mme_est << " " << mme_gt << std::endl;
+    } else {
+        std::cout << "MME EST: " << mme_est << std::endl;
+    }
+}
+
+void MapEval::calculateMetricsWithInitialMatrix() {
+    TicToc tt;
+    me_nn_stats_out eg, ge;
+    // est -> gt: keep (i, nn) iff d2 <= icp_max_distance (:1215-1223, squared vs un-squared, sic)
+    if (me_nn1(ctx_, ME_SLOT_EST, ME_SLOT_GT, nullptr, nullptr) != ME_OK ||
+        me_nn_stats(ctx_, ME_SLOT_EST, param_.icp_max_distance_, ME_GATE_LE_UNSQUARED, param_.trunc_dist_.data(), &eg) != ME_OK) {
+        fail(me_last_error(ctx_));
+        return;
+    }
+    t_acc = tt.toc() / 1000.0;
+    // gt -> est (:1226-1236): the intended (gt_i, map_nn) pairing — the reference stores the pair swapped and then indexes
+    // the wrong clouds (undefined behaviour when N_e != N_g); see DESIGN.md "deviations".
+    if (me_nn1(ctx_, ME_SLOT_GT, ME_SLOT_EST, nullptr, nullptr) != ME_OK ||
+        me_nn_stats(ctx_, ME_SLOT_GT, param_.icp_max_distance_, ME_GATE_LE_UNSQUARED, param_.trunc_dist_.data(), &ge) != ME_OK) {
+        fail(me_last_error(ctx_));
+        return;
+    }
+    push_results(est_gt_results, eg);
+    push_results(gt_est_results, ge);
+    for (int i = 0; i < 5; ++i) {
+        cd_vec[i] = est_gt_results[1][i] + gt_est_results[1][i];  // (:1245)
+        const double overlap_ratio = est_gt_results[2][i], rmse = est_gt_results[1][i];
+        f1_vec[i] = 2 * overlap_ratio * rmse / (overlap_ratio + rmse);  // (:1249, sic)
+        const int num_intersection = (int) est_gt_results[4][i];
+        const long long num_union = (long long) map_3d_->size() + (long long) gt_3d_->size() - num_intersection;
+        iou_vec[i] = (double) num_intersection / (double) num_union;  // (:1250-1252)
+    }
+    // FULL CD: the reference never computes it on this path (stays 0.0); it is free here (same two searches).
+    const double t0 = tt.toc();
+    full_chamfer_dist = param_.strict_reference ? 0.0 : (eg.mean_nn_dist + ge.mean_nn_dist);  // (:1429)
+    t_fcd = (tt.toc() - t0) / 1000.0 + (tt.toc() / 1000.0 - t_acc);
+    std::cout << "INFO: Chamfer Distance: " << eigen_row(cd_vec, 6) << std::endl;
+    std::cout << "INFO: F1 Score: " << eigen_row(f1_vec, 6) << std::endl;
+    std::cout << "INFO: est-gt MME: " << mme_est << " " << mme_gt << std::endl;
+    std::cout << "INFO: IoU: " << eigen_row(iou_vec, 6) << std::endl;
+}
+
+double MapEval::computeChamferDistance() {
+    double cd = 0;
+    if (me_chamfer(ctx_, &cd) != ME_OK) fail(me_last_error(ctx_));
+    return cd;
+}
+
+void MapEval::calculateVMD() {
+    TicToc ticToc;
+    int64_t nv = 0;
+    // buildVoxelMap(gt), buildVoxelMap(est), updateVoxelMap (:248-252)
+    if (me_voxel_gaussians(ctx_, ME_SLOT_GT, param_.vmd_voxel_size_, nullptr, nullptr, nullptr, nullptr, nullptr, &nv) != ME_OK ||
+        me_voxel_gaussians(ctx_, ME_SLOT_EST, param_.vmd_voxel_size_, nullptr, nullptr, nullptr, nullptr, nullptr, &nv) != ME_OK) {
+        fail(me_last_error(ctx_));
+        return;
+    }
+    t_v = ticToc.toc();
+    int64_t n_rows = 0, counts[3] = {0, 0, 0};
+    if (me_awd_scs(ctx_, param_.vmd_voxel_size_, 100, 5, nullptr, nullptr, &n_rows, &vmd, &scs_overall, counts) != ME_OK) {
+        fail(me_last_error(ctx_));
+        return;
+    }
+    std::cout << "Update active/old/new voxel num: " << counts[0] << " " << counts[1] << " " << counts[2] << std::endl;
+    std::vector<double> rows((size_t) n_rows * 27), ws((size_t) n_rows);
+    if (n_rows > 0) {
+        int64_t cap = n_rows;
+        if (me_awd_scs(ctx_, param_.vmd_voxel_size_, 100, 5, rows.data(), ws.data(), &cap, &vmd, &scs_overall, counts) != ME_OK) {
+            fail(me_last_error(ctx_));
+            return;
+        }
+    }
+    t_vmd = ticToc.toc();
+    // voxel_errors.txt: 27 columns, default ostream precision (:292-302); rows in ascending voxel-index order
+    std::ofstream output_file(results_subfolder + "voxel_errors.txt");
+    if (!output_file.is_open()) {
+        std::cerr << "ERROR: Failed to open voxel error output file." << std::endl;
+        return;
+    }
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const double *p = rows.data() + 27 * r;
+        for (int c = 0; c < 27; ++c) {
+            if (c == 10 || c == 11) output_file << (long long) p[c];
+            else output_file << p[c];
+            output_file << (c == 26 ? "" : " ");
+        }
+        output_file << std::endl;
+    }
+    output_file.close();
+    std::cout << "INFO: Calculated VMD: " << vmd << std::endl;
+    // voxel_wasserstein_cdf.txt (:330-341)
+    std::ofstream cdf_file(results_subfolder + "voxel_wasserstein_cdf.txt");
+    if (!cdf_file.is_open()) {
+        std::cerr << "ERROR: Failed to open CDF output file." << std::endl;
+        return;
+    }
+    for (size_t i = 0; i < ws.size(); ++i) cdf_file << ws[i] << " " << static_cast<double>(i + 1) / ws.size() << std::endl;
+    cdf_file.close();
+    t_cdf = ticToc.toc();
+    t_scs = t_cdf;  // SCS ran inside me_awd_scs
+    std::cout << "INFO: Spatial Consistency Score (SCS): " << scs_overall << std::endl;
+}
+
+void MapEval::saveMmeResults() {
+    if (!param_.evaluate_mme_) return;
+    file_result << std::fixed << std::setprecision(5) << "MME: " << mme_est << " " << mme_gt << " " << min_abs_entropy << " "
+                << max_abs_entropy << std::endl;  // (:395-396)
+    // map_entropy.pcd / gt_entropy.pcd are colour renderings (ColorPointCloudByMME) — out of scope; the raw entropies
+    // are written instead so that nothing is lost.
+    std::ofstream e(results_subfolder + "map_entropy.txt");
+    for (size_t i = 0; i < est_entropies.size(); ++i) e << est_entropies[i] << " " << (int) valid_entropy_points[i] << "\n";
+}
+
+void MapEval::saveRegistrationResults() {
+    // identical lines and precisions to map_eval.cpp:439-476
+    file_result << std::fixed << std::setprecision(15) << "RMSE/AC: " << eigen_row(est_gt_results.at(1), 15) << std::endl;
+    file_result << std::fixed << std::setprecision(15) << "Comp: " << eigen_row(est_gt_results.at(2), 15) << std::endl;
+    file_result << std::fixed << std::setprecision(5) << "FULL CD: " << full_chamfer_dist << std::endl;
+    file_result << std::fixed << std::setprecision(5) << "VMD: " << vmd << std::endl;
+    file_result << std::fixed << std::setprecision(5) << "SCS: " << scs_overall << std::endl;
+    file_result << "Time load-MME-mesh-ICP-Metric-AC-FCD: " << t1 / 1000.0 << " " << (t2 - t1) / 1000.0 << " " << 0.0 << " "
+                << 0.0 << " " << (t5 - t2) / 1000.0 << " " << t_acc << " " << t_fcd << std::endl;
+    file_result << "VMD Time voxelization-WD-CDF-SCS: " << t_v / 1000.0 << " " << (t_vmd - t_v) / 1000.0 << " "
+                << (t_cdf - t_vmd) / 1000.0 << " " << (t_scs - t_cdf) / 1000.0 << std::endl;
+    file_result << "AC+MME Time: " << t_acc + (t2 - t1) / 1000.0 << std::endl;
+    file_result << "CD+MME Time: " << t_fcd + (t2 - t1) / 1000.0 << std::endl;
+    file_result << "AWD+SCS Time: " << t_v / 1000.0 + (t_vmd - t_v) / 1000.0 + (t_scs - t_cdf) / 1000.0 << std::endl;
+    file_result.close();
+    if (param_.enable_debug) std::cout << "INFO: Results saved to " << results_subfolder + "map_results.txt" << std::endl;
+}
