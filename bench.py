@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--nn-radius", type=float, default=0.1)
     ap.add_argument("--voxel", type=float, default=3.0)
     ap.add_argument("--no-gt-mme", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=400_000, help="GT points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="GT points of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 

@@ -8,6 +8,7 @@
 //   4. an implicit 8-ary BVH over consecutive 16-point blocks of the sorted array (fp32 boxes rounded outward),
 //   5. the table of occupied radius cells + an open-addressing hash (cell Morton code -> cell index).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "me_internal.hpp"
@@ -358,11 +359,12 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
             if (k < kMortonBits) acc += (long long) h_hist[k];
             c.level_unique[k] = (k == kMortonBits) ? 1 : acc;
         }
-        // 1-NN grid: the finest level whose occupied cells hold >= 12 points on average (27-cell stencil ~ a few
+        // 1-NN grid: the finest level whose occupied cells hold >= 6 points on average (27-cell stencil ~ a few
         // hundred candidates per query at most, yet a guaranteed radius of one cell edge resolves almost all queries)
         int nn_shift = kMortonBits - 1;
+        static const double nn_occ = std::getenv("ME_NN_OCC") ? std::atof(std::getenv("ME_NN_OCC")) : 6.0;  // tuning knob (measured: 6 beats 12 and 3 on the bench scene)
         for (int k = 0; k < kMortonBits; ++k)
-            if ((double) n / (double) c.level_unique[k] >= 12.0) {
+            if ((double) n / (double) c.level_unique[k] >= nn_occ) {
                 nn_shift = k;
                 break;
             }

@@ -310,8 +310,12 @@ __device__ __forceinline__ int hash_lookup(const unsigned long long *__restrict_
 // cell this shares candidate fetches between neighbouring cells and keeps the whole wave busy.
 // Returns whether this lane is in the group; (rs0,rc0) / (rs1,rc1) = start/count of this lane's two runs.
 // ------------------------------------------------------------------------------------------------------------
+struct GroupBox {
+    int x0, y0, z0, nx, ny;  // origin and x/y extent of the probed cell box (wave-uniform)
+};
+
 __device__ __forceinline__ bool wave_group_runs(bool pending, int cx, int cy, int cz, const GridView &g, int cell_lim,
-                                                int lane, int &rs0, int &rc0, int &rs1, int &rc1) {
+                                                int lane, int &rs0, int &rc0, int &rs1, int &rc1, GroupBox *box = nullptr) {
     const unsigned long long pm = __ballot(pending);  // caller guarantees pm != 0
     const int leader = __ffsll((long long) pm) - 1;
     const int lx = readlane_i(cx, leader), ly = readlane_i(cy, leader), lz = readlane_i(cz, leader);
@@ -322,6 +326,13 @@ __device__ __forceinline__ bool wave_group_runs(bool pending, int cx, int cy, in
     const int z0 = lz - 1 - (__ballot(in && ez < 0) ? 1 : 0), z1 = lz + 1 + (__ballot(in && ez > 0) ? 1 : 0);
     const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
     const int n_keys = nx * ny * nz;  // <= 125
+    if (box) {
+        box->x0 = x0;
+        box->y0 = y0;
+        box->z0 = z0;
+        box->nx = nx;
+        box->ny = ny;
+    }
     rs0 = rc0 = rs1 = rc1 = 0;
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot) {
@@ -346,6 +357,62 @@ __device__ __forceinline__ bool wave_group_runs(bool pending, int cx, int cy, in
             }
         }
     }
+    return in;
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-level cell-run table for the PER-LANE walkers.  Group = pending lanes whose cell lies within Chebyshev
+// distance kGroupR of the leader's; the cell box of the group grown by one (<= 7x7x7 = 343 cells) is resolved with
+// one hash probe per (lane, slot) into a wave-private LDS table `tab` (>= kGroupTab entries of {start, count}).
+// Every group lane then reads the runs of its own 3x3x3 block from the table: tab[(x-x0) + nx*((y-y0) + ny*(z-z0))].
+// 64 Morton-consecutive points almost always form one group, so the whole wave walks its candidates together.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kGroupR = 2;
+constexpr int kGroupTab = 343;
+
+__device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, int cz, const GridView &g, int cell_lim,
+                                                 int lane, int2 *tab, GroupBox &box) {
+    const unsigned long long pm = __ballot(pending);  // caller guarantees pm != 0
+    const int leader = __ffsll((long long) pm) - 1;
+    const int lx = readlane_i(cx, leader), ly = readlane_i(cy, leader), lz = readlane_i(cz, leader);
+    const int ex = cx - lx, ey = cy - ly, ez = cz - lz;
+    const bool in = pending && ex >= -kGroupR && ex <= kGroupR && ey >= -kGroupR && ey <= kGroupR && ez >= -kGroupR && ez <= kGroupR;
+    const int x0 = wave_min_i(in ? cx : lx) - 1, x1 = wave_max_i(in ? cx : lx) + 1;
+    const int y0 = wave_min_i(in ? cy : ly) - 1, y1 = wave_max_i(in ? cy : ly) + 1;
+    const int z0 = wave_min_i(in ? cz : lz) - 1, z1 = wave_max_i(in ? cz : lz) + 1;
+    const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    const int n_keys = nx * ny * nz;  // <= 343
+    box.x0 = x0;
+    box.y0 = y0;
+    box.z0 = z0;
+    box.nx = nx;
+    box.ny = ny;
+    for (int t = lane; t < n_keys; t += 64) {
+        const int ix = x0 + t % nx, iy = y0 + (t / nx) % ny, iz = z0 + t / (nx * ny);
+        int2 run = make_int2(0, 0);
+        if (ix >= 0 && iy >= 0 && iz >= 0 && ix < cell_lim && iy < cell_lim && iz < cell_lim) {
+            const unsigned long long key = spread21((unsigned long long) ix) | (spread21((unsigned long long) iy) << 1) |
+                                           (spread21((unsigned long long) iz) << 2);
+            const int ci = hash_lookup(g.hkeys, g.hvals, g.hmask, key);
+            if (ci >= 0) {
+                run.x = (int) g.cell_start[ci];
+                run.y = (int) g.cell_start[ci + 1] - run.x;
+            }
+        }
+        tab[t] = run;
+    }
+    __builtin_amdgcn_wave_barrier();
     return in;
 }
 #endif

@@ -13,6 +13,7 @@
 //   never exceeds the *computed* distance of a point inside: the result is the exact brute-force minimum of
 //   ((dx*dx + dy*dy) + dz*dz), bit-identical to the CPU path.
 #include <cmath>
+#include <cstdlib>
 
 #include "me_internal.hpp"
 
@@ -143,6 +144,129 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         idx_out[i] = (best_i == 0x7fffffffffffffffLL) ? -1 : (int) best_i;
     }
     // wave-aggregated append of the unresolved lanes
+    const unsigned long long um = __ballot(unresolved);
+    if (um) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(list_count, (unsigned int) __popcll(um));
+        base = (unsigned int) readlane_i((int) base, 0);
+        if (unresolved) list[base + (unsigned int) __popcll(um & ((1ULL << lane) - 1ULL))] = (unsigned int) (i - q_begin);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fast path, per-lane variant: every lane walks ITS OWN 3x3x3 block (27 hash probes, then the runs) with ordinary
+// vector loads.  Lanes of one cell issue identical addresses in lockstep (one cache line per instruction), so the
+// memory pipe sees a handful of lines per load while each lane tests only its own ~27 cells of candidates instead
+// of the wave's union.  Same exactness argument and same unresolved-list hand-over as k_nn_grid.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_nn_cells(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, GridView g,
+           FrameView fr, double *__restrict__ d2_out, int *__restrict__ idx_out, unsigned int *__restrict__ list,
+           unsigned int *__restrict__ list_count) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int per = gridDim.x / 8;  // XCD-aware chunking, gridDim.x is a multiple of 8
+    const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const long long i = q_begin + (long long) vb * blockDim.x + threadIdx.x;
+    const bool active = i < q_end;
+    const int cell_lim = 1 << (kMortonBits - g.shift);
+    const double cell_h = ldexp(fr.fine_h, g.shift);
+
+    double qx = 0, qy = 0, qz = 0;
+    int mcx = 0, mcy = 0, mcz = 0;
+    bool in_grid = false;
+    double best = INFINITY;
+    int best_j = -1;  // position in the sorted reference array
+    if (active) {
+        const SPoint q = qsp[i];
+        qx = q.x;
+        qy = q.y;
+        qz = q.z;
+        const double fx = fine_coord(qx, fr.ox, fr.fine_h), fy = fine_coord(qy, fr.oy, fr.fine_h),
+                     fz = fine_coord(qz, fr.oz, fr.fine_h);
+        const double lim = 2097151.0;
+        in_grid = fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx <= lim && fy <= lim && fz <= lim;
+        if (in_grid) {
+            mcx = (int) ((unsigned int) fx >> g.shift);
+            mcy = (int) ((unsigned int) fy >> g.shift);
+            mcz = (int) ((unsigned int) fz >> g.shift);
+        }
+    }
+    // The cell lookups are shared by the wave (one hash probe per lane resolves the group's whole cell box, parked in
+    // a wave-private LDS table); the candidate walk is per lane.
+    __shared__ int2 s_tab[4][kGroupTab + 1];
+    int2 *tab = s_tab[threadIdx.x >> 6];
+    bool done = !active || !in_grid;
+    while (__ballot(!done)) {
+        GroupBox bx;
+        const bool in = wave_group_table(!done, mcx, mcy, mcz, g, cell_lim, lane, tab, bx);
+        if (in) {
+            // FLATTENED walk over this lane's 27 runs: every wave iteration tests exactly one candidate per lane (a
+            // per-cell loop would run max-over-lanes(count) iterations for each of the 27 cells), and the next
+            // candidate's load is issued before the current one is tested.
+            const int bx_ = mcx - 1 - bx.x0, by_ = mcy - 1 - bx.y0, bz_ = mcz - 1 - bx.z0;
+            int n = -1, j = 0, e = 0;
+            auto advance = [&]() -> bool {
+                while (j >= e) {
+                    if (++n >= 27) return false;
+                    const int2 run = tab[(bx_ + n % 3) + bx.nx * ((by_ + (n / 3) % 3) + bx.ny * (bz_ + n / 9))];
+                    j = run.x;
+                    e = run.x + run.y;
+                }
+                return true;
+            };
+            bool have = advance();
+            double cx_ = 0, cy_ = 0, cz_ = 0;
+            int cj = 0;
+            if (have) {
+                cx_ = rsp[j].x;
+                cy_ = rsp[j].y;
+                cz_ = rsp[j].z;
+                cj = j++;
+            }
+            while (have) {
+                const bool have_next = advance();
+                double nx_ = 0, ny_ = 0, nz_ = 0;
+                int nj = 0;
+                if (have_next) {
+                    nx_ = rsp[j].x;
+                    ny_ = rsp[j].y;
+                    nz_ = rsp[j].z;
+                    nj = j++;
+                }
+                const double d = dist2_exact(qx, qy, qz, cx_, cy_, cz_);
+                // strict <, runs in ascending order: among coincident reference points (one stable-sorted run) the
+                // first, i.e. the smallest original index, wins
+                if (d < best) {
+                    best = d;
+                    best_j = cj;
+                }
+                cx_ = nx_;
+                cy_ = ny_;
+                cz_ = nz_;
+                cj = nj;
+                have = have_next;
+            }
+            done = true;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    bool unresolved = false;
+    if (active) {
+        unresolved = true;
+        long long best_i = -1;
+        if (best_j >= 0) best_i = rsp[best_j].idx;
+        if (in_grid && best_j >= 0) {
+            const double lox = fr.ox + (double) (mcx - 1) * cell_h, hix = fr.ox + (double) (mcx + 2) * cell_h;
+            const double loy = fr.oy + (double) (mcy - 1) * cell_h, hiy = fr.oy + (double) (mcy + 2) * cell_h;
+            const double loz = fr.oz + (double) (mcz - 1) * cell_h, hiz = fr.oz + (double) (mcz + 2) * cell_h;
+            double gmin = fmin(fmin(qx - lox, hix - qx), fmin(fmin(qy - loy, hiy - qy), fmin(qz - loz, hiz - qz)));
+            gmin *= (1.0 - 1e-9);  // rounding slack of the cell assignment
+            // strictly inside the guaranteed ball: an equally distant point outside the block cannot exist
+            unresolved = !(gmin > 0.0 && best < gmin * gmin);
+        }
+        d2_out[i] = best;
+        idx_out[i] = (int) best_i;
+    }
     const unsigned long long um = __ballot(unresolved);
     if (um) {
         unsigned int base = 0;
@@ -397,8 +521,13 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         FrameView fr{r.origin[0], r.origin[1], r.origin[2], r.fine_h};
         {
             TimerScope ts(ctx, "nn_grid");
-            hipLaunchKernelGGL(k_nn_grid, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
-                               r.nn_grid, fr, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
+            static const int mode = std::getenv("ME_NN_MODE") ? std::atoi(std::getenv("ME_NN_MODE")) : 1;
+            if (mode == 0)
+                hipLaunchKernelGGL(k_nn_grid, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
+                                   r.nn_grid, fr, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
+            else
+                hipLaunchKernelGGL(k_nn_cells, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
+                                   r.nn_grid, fr, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
         }
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)
