@@ -379,20 +379,24 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // 64 Morton-consecutive points almost always form one group, so the whole wave walks its candidates together.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kGroupR = 2;
-constexpr int kGroupTab = 343;
+constexpr int kGroupTab = 343;                               // (2R+1+2H)^3 for halo H = 1
+constexpr int kGroupTab2 = (2 * kGroupR + 5) * (2 * kGroupR + 5) * (2 * kGroupR + 5);  // halo H = 2: 9^3 = 729
 
+// H = halo in cells: 1 when the cell edge covers the search radius, 2 for half-radius cells (5x5x5 stencil)
+template <int H = 1>
 __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, int cz, const GridView &g, int cell_lim,
-                                                 int lane, int2 *tab, GroupBox &box) {
+                                                 int lane, int2 *tab, GroupBox &box, int *n_keys_out = nullptr) {
     const unsigned long long pm = __ballot(pending);  // caller guarantees pm != 0
     const int leader = __ffsll((long long) pm) - 1;
     const int lx = readlane_i(cx, leader), ly = readlane_i(cy, leader), lz = readlane_i(cz, leader);
     const int ex = cx - lx, ey = cy - ly, ez = cz - lz;
     const bool in = pending && ex >= -kGroupR && ex <= kGroupR && ey >= -kGroupR && ey <= kGroupR && ez >= -kGroupR && ez <= kGroupR;
-    const int x0 = wave_min_i(in ? cx : lx) - 1, x1 = wave_max_i(in ? cx : lx) + 1;
-    const int y0 = wave_min_i(in ? cy : ly) - 1, y1 = wave_max_i(in ? cy : ly) + 1;
-    const int z0 = wave_min_i(in ? cz : lz) - 1, z1 = wave_max_i(in ? cz : lz) + 1;
+    const int x0 = wave_min_i(in ? cx : lx) - H, x1 = wave_max_i(in ? cx : lx) + H;
+    const int y0 = wave_min_i(in ? cy : ly) - H, y1 = wave_max_i(in ? cy : ly) + H;
+    const int z0 = wave_min_i(in ? cz : lz) - H, z1 = wave_max_i(in ? cz : lz) + H;
     const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
-    const int n_keys = nx * ny * nz;  // <= 343
+    const int n_keys = nx * ny * nz;  // <= (2R+1+2H)^3
+    if (n_keys_out) *n_keys_out = n_keys;
     box.x0 = x0;
     box.y0 = y0;
     box.z0 = z0;
@@ -414,6 +418,24 @@ __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, i
     }
     __builtin_amdgcn_wave_barrier();
     return in;
+}
+
+// Calls f(begin, end) once per non-empty run of the wave's table, with WAVE-UNIFORM arguments (so that a loop over
+// [begin, end) fetches candidates with scalar loads and all lanes test the same candidate).
+template <class F>
+__device__ __forceinline__ void wave_for_each_run(const int2 *tab, int n_keys, int lane, F &&f) {
+    for (int base = 0; base < n_keys; base += 64) {
+        const int t = base + lane;
+        const int cnt = (t < n_keys) ? tab[t].y : 0;
+        unsigned long long m = __ballot(cnt > 0);
+        while (m) {
+            const int n = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            const int2 run = tab[base + n];
+            const int cs = __builtin_amdgcn_readfirstlane(run.x), cc = __builtin_amdgcn_readfirstlane(run.y);
+            f(cs, cs + cc);
+        }
+    }
 }
 #endif
 

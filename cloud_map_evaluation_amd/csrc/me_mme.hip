@@ -4,10 +4,14 @@
 //
 // Mapping.  Points are Morton-sorted on a grid whose cell edge is (a hair above) the search radius, so the
 // neighbours of every point of a cell lie in the 3x3x3 block around it, and each cell is one contiguous run of
-// the sorted array.  A wavefront owns 64 consecutive sorted points.  For each distinct cell among its lanes it
-//   * resolves the 27 neighbour runs with one hash probe per lane (lanes 0..26),
-//   * streams those runs with WAVE-UNIFORM addresses (one fetch feeds all 64 lanes; the compiler turns it into
-//     scalar loads), every lane of the current cell testing the candidate against its own query in fp64.
+// the sorted array.  A wavefront owns 64 consecutive sorted points.  Per round (usually one or two per wave) it
+//   * groups the lanes whose cell is within Chebyshev distance 1 of the leader's and resolves the group's cell box
+//     grown by one (<= 5x5x5 cells) with one hash probe per lane and slot (wave_group_runs),
+//   * streams every non-empty run ONCE with WAVE-UNIFORM addresses (one fetch feeds all 64 lanes; the compiler turns
+//     it into scalar loads, the candidate sits in SGPRs), every group lane testing it against its own query in fp64.
+// rocprofv3 SQ counters put this kernel at ~90 % VALU issue occupancy (8 waves/SIMD x 11 % each): it is bound by the
+// fp64 candidate tests, not by memory.  A per-lane walk (fewer candidates per lane) was measured slower (vector-L1
+// tag-lookup bound), half-radius cells with a 5x5x5 stencil likewise (same union, 6x the probes).
 // The reference materialises index/distance vectors per query and gathers a 3xk matrix; here nothing is
 // materialised: k, sum(p-q) and sum((p-q)(p-q)^T) are accumulated in registers about the QUERY as origin
 // (|p-q| < r, so the one-pass covariance is as well conditioned as the reference's two-pass one).
@@ -20,7 +24,6 @@
 
 namespace me {
 
-template <int MODE>
 __global__ void __launch_bounds__(256)
 k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
       GridView g, double r2, int min_k, double *__restrict__ ent_s, unsigned char *__restrict__ valid_s,
@@ -82,72 +85,25 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
         }
     };
 
-    if constexpr (MODE == 0) {
-        // wave-shared candidate streams (scalar loads): every group lane tests the union of the group's cells
-        while (__ballot(!done)) {
-            int rs0, rc0, rs1, rc1;
-            const bool in = wave_group_runs(!done, cx, cy, cz, g, cell_lim, lane, rs0, rc0, rs1, rc1);
-            unsigned long long m = __ballot(rc0 > 0);
-            while (m) {
-                const int n = __ffsll((long long) m) - 1;
-                m &= m - 1;
-                const int cs = readlane_i(rs0, n);
-                stream_run(cs, cs + readlane_i(rc0, n), in);
-            }
-            m = __ballot(rc1 > 0);
-            while (m) {
-                const int n = __ffsll((long long) m) - 1;
-                m &= m - 1;
-                const int cs = readlane_i(rs1, n);
-                stream_run(cs, cs + readlane_i(rc1, n), in);
-            }
-            if (in) done = true;
+    // wave-shared candidate streams (scalar loads): every group lane tests the union of the group's cells
+    while (__ballot(!done)) {
+        int rs0, rc0, rs1, rc1;
+        const bool in = wave_group_runs(!done, cx, cy, cz, g, cell_lim, lane, rs0, rc0, rs1, rc1);
+        unsigned long long m = __ballot(rc0 > 0);
+        while (m) {
+            const int n = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            const int cs = readlane_i(rs0, n);
+            stream_run(cs, cs + readlane_i(rc0, n), in);
         }
-    } else {
-        // per-lane flattened walk: the wave resolves its cell box once (LDS run table), then every lane visits the
-        // runs of ITS OWN 3x3x3 block, one candidate per wave iteration, next candidate's load already in flight
-        __shared__ int2 s_tab[4][kGroupTab + 1];
-        int2 *tab = s_tab[threadIdx.x >> 6];
-        while (__ballot(!done)) {
-            GroupBox bx;
-            const bool in = wave_group_table(!done, cx, cy, cz, g, cell_lim, lane, tab, bx);
-            if (in) {
-                const int bx_ = cx - 1 - bx.x0, by_ = cy - 1 - bx.y0, bz_ = cz - 1 - bx.z0;
-                int n = -1, j = 0, e = 0;
-                auto advance = [&]() -> bool {
-                    while (j >= e) {
-                        if (++n >= 27) return false;
-                        const int2 run = tab[(bx_ + n % 3) + bx.nx * ((by_ + (n / 3) % 3) + bx.ny * (bz_ + n / 9))];
-                        j = run.x;
-                        e = run.x + run.y;
-                    }
-                    return true;
-                };
-                bool have = advance();
-                SPoint cur{0, 0, 0, 0};
-                if (have) {
-                    cur.x = sp[j].x;
-                    cur.y = sp[j].y;
-                    cur.z = sp[j].z;
-                    ++j;
-                }
-                while (have) {
-                    const bool have_next = advance();
-                    SPoint nxt{0, 0, 0, 0};
-                    if (have_next) {
-                        nxt.x = sp[j].x;
-                        nxt.y = sp[j].y;
-                        nxt.z = sp[j].z;
-                        ++j;
-                    }
-                    test(cur);
-                    cur = nxt;
-                    have = have_next;
-                }
-                done = true;
-            }
-            __builtin_amdgcn_wave_barrier();
+        m = __ballot(rc1 > 0);
+        while (m) {
+            const int n = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            const int cs = readlane_i(rs1, n);
+            stream_run(cs, cs + readlane_i(rc1, n), in);
         }
+        if (in) done = true;
     }
 
     double H = 0.0;
@@ -240,13 +196,8 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     const double r2 = radius * radius;  // Open3D SearchRadius -> nanoflann radiusSearch(q, r*r) [upstream]
     {
         TimerScope ts(ctx, "mme");
-        static const int mode = std::getenv("ME_MME_MODE") ? std::atoi(std::getenv("ME_MME_MODE")) : 0;  // 0 = wave-shared streams (measured faster), 1 = per-lane walk
-        if (mode == 0)
-            hipLaunchKernelGGL(k_mme<0>, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(),
-                               b, e, c.grid, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc);
-        else
-            hipLaunchKernelGGL(k_mme<1>, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(),
-                               b, e, c.grid, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc);
+        hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
+                           c.grid, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc);
     }
     hipLaunchKernelGGL(k_mme_final, dim3(1), dim3(256), 0, ctx->stream, ps, pc, (int) nb, outs, outc);
     double hs = 0;

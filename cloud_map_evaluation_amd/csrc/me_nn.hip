@@ -41,13 +41,18 @@ __device__ __forceinline__ void scan_leaf(const SPoint *__restrict__ rsp, long l
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Fast path: uniform-grid 1-NN.  A wavefront owns 64 consecutive (Morton-ordered) queries.  For each distinct
-// reference-grid cell among its lanes it resolves the 27 neighbour runs (one hash probe per lane) and streams
-// them with wave-uniform addresses (scalar loads), every lane keeping its own running minimum in fp64.
-// A lane is RESOLVED when its best distance does not exceed its distance to the faces of the 3x3x3 block: every
+// Fast path: uniform-grid 1-NN.  A wavefront owns 64 consecutive (Morton-ordered) queries.  The lanes whose
+// reference-grid cell lies within Chebyshev distance 2 of the leader's form a group (normally the whole wave); the
+// group's cell box grown by one is resolved with one hash probe per (lane, slot) into a wave-private LDS table, and
+// every non-empty run is streamed ONCE with wave-uniform addresses (scalar loads: the candidate sits in SGPRs), every
+// lane keeping its own running minimum in fp64.  The grid level is the finest whose occupied cells hold >= 6 points.
+// A lane is RESOLVED when its best distance is below its distance to the faces of its own 3x3x3 block: every
 // reference point outside the block is farther, so the minimum is the exact global minimum.  Unresolved lanes
 // (no neighbour within about one cell edge: outliers, non-overlapping map regions, queries outside the reference
 // bbox) are appended to a list, with their best-so-far as the initial bound, for the BVH kernel below.
+// Measured alternatives (rocprofv3 SQ/TCP counters, profiles/README.md): a per-lane walk of each lane's own 27 runs
+// tests 4x fewer candidates but is bound by vector-L1 tag lookups (~11 distinct lines per load instruction) and
+// loses; Chebyshev-1 groups serialise a wave into ~5 rounds on a fine grid and lose as well.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, GridView g,
@@ -86,7 +91,8 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
 
     auto test = [&](const SPoint &p) {
         const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
-        if (d < best || (d == best && p.idx < best_i)) {
+        // strict <: coincident reference points sit in one stable-sorted run, the first (smallest index) wins
+        if (d < best) {
             best = d;
             best_i = p.idx;
         }
@@ -107,24 +113,15 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         }
     };
     // (the candidate set of a round is a superset of the lane's own 3x3x3 block; extra candidates only help)
+    __shared__ int2 s_tab[4][kGroupTab + 1];
+    int2 *tab = s_tab[threadIdx.x >> 6];
     while (__ballot(!done)) {
-        int rs0, rc0, rs1, rc1;
-        const bool in = wave_group_runs(!done, mcx, mcy, mcz, g, cell_lim, lane, rs0, rc0, rs1, rc1);
-        unsigned long long m = __ballot(rc0 > 0);
-        while (m) {
-            const int n = __ffsll((long long) m) - 1;
-            m &= m - 1;
-            const int cs = readlane_i(rs0, n);
-            stream_run(cs, cs + readlane_i(rc0, n), in);
-        }
-        m = __ballot(rc1 > 0);
-        while (m) {
-            const int n = __ffsll((long long) m) - 1;
-            m &= m - 1;
-            const int cs = readlane_i(rs1, n);
-            stream_run(cs, cs + readlane_i(rc1, n), in);
-        }
+        GroupBox bx;
+        int nk = 0;
+        const bool in = wave_group_table<1>(!done, mcx, mcy, mcz, g, cell_lim, lane, tab, bx, &nk);
+        wave_for_each_run(tab, nk, lane, [&](int cs, int ce) { stream_run(cs, ce, in); });
         if (in) done = true;
+        __builtin_amdgcn_wave_barrier();
     }
 
     bool unresolved = false;
@@ -138,135 +135,12 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             const double loz = fr.oz + (double) (mcz - 1) * cell_h, hiz = fr.oz + (double) (mcz + 2) * cell_h;
             double gmin = fmin(fmin(qx - lox, hix - qx), fmin(fmin(qy - loy, hiy - qy), fmin(qz - loz, hiz - qz)));
             gmin *= (1.0 - 1e-9);  // rounding slack of the cell assignment
-            unresolved = !(gmin > 0.0 && best <= gmin * gmin);
+            unresolved = !(gmin > 0.0 && best < gmin * gmin);
         }
         d2_out[i] = best;  // final if resolved, initial bound otherwise
         idx_out[i] = (best_i == 0x7fffffffffffffffLL) ? -1 : (int) best_i;
     }
     // wave-aggregated append of the unresolved lanes
-    const unsigned long long um = __ballot(unresolved);
-    if (um) {
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(list_count, (unsigned int) __popcll(um));
-        base = (unsigned int) readlane_i((int) base, 0);
-        if (unresolved) list[base + (unsigned int) __popcll(um & ((1ULL << lane) - 1ULL))] = (unsigned int) (i - q_begin);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Fast path, per-lane variant: every lane walks ITS OWN 3x3x3 block (27 hash probes, then the runs) with ordinary
-// vector loads.  Lanes of one cell issue identical addresses in lockstep (one cache line per instruction), so the
-// memory pipe sees a handful of lines per load while each lane tests only its own ~27 cells of candidates instead
-// of the wave's union.  Same exactness argument and same unresolved-list hand-over as k_nn_grid.
-// ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_nn_cells(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, GridView g,
-           FrameView fr, double *__restrict__ d2_out, int *__restrict__ idx_out, unsigned int *__restrict__ list,
-           unsigned int *__restrict__ list_count) {
-    const int lane = threadIdx.x & 63;
-    const unsigned int per = gridDim.x / 8;  // XCD-aware chunking, gridDim.x is a multiple of 8
-    const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    const long long i = q_begin + (long long) vb * blockDim.x + threadIdx.x;
-    const bool active = i < q_end;
-    const int cell_lim = 1 << (kMortonBits - g.shift);
-    const double cell_h = ldexp(fr.fine_h, g.shift);
-
-    double qx = 0, qy = 0, qz = 0;
-    int mcx = 0, mcy = 0, mcz = 0;
-    bool in_grid = false;
-    double best = INFINITY;
-    int best_j = -1;  // position in the sorted reference array
-    if (active) {
-        const SPoint q = qsp[i];
-        qx = q.x;
-        qy = q.y;
-        qz = q.z;
-        const double fx = fine_coord(qx, fr.ox, fr.fine_h), fy = fine_coord(qy, fr.oy, fr.fine_h),
-                     fz = fine_coord(qz, fr.oz, fr.fine_h);
-        const double lim = 2097151.0;
-        in_grid = fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx <= lim && fy <= lim && fz <= lim;
-        if (in_grid) {
-            mcx = (int) ((unsigned int) fx >> g.shift);
-            mcy = (int) ((unsigned int) fy >> g.shift);
-            mcz = (int) ((unsigned int) fz >> g.shift);
-        }
-    }
-    // The cell lookups are shared by the wave (one hash probe per lane resolves the group's whole cell box, parked in
-    // a wave-private LDS table); the candidate walk is per lane.
-    __shared__ int2 s_tab[4][kGroupTab + 1];
-    int2 *tab = s_tab[threadIdx.x >> 6];
-    bool done = !active || !in_grid;
-    while (__ballot(!done)) {
-        GroupBox bx;
-        const bool in = wave_group_table(!done, mcx, mcy, mcz, g, cell_lim, lane, tab, bx);
-        if (in) {
-            // FLATTENED walk over this lane's 27 runs: every wave iteration tests exactly one candidate per lane (a
-            // per-cell loop would run max-over-lanes(count) iterations for each of the 27 cells), and the next
-            // candidate's load is issued before the current one is tested.
-            const int bx_ = mcx - 1 - bx.x0, by_ = mcy - 1 - bx.y0, bz_ = mcz - 1 - bx.z0;
-            int n = -1, j = 0, e = 0;
-            auto advance = [&]() -> bool {
-                while (j >= e) {
-                    if (++n >= 27) return false;
-                    const int2 run = tab[(bx_ + n % 3) + bx.nx * ((by_ + (n / 3) % 3) + bx.ny * (bz_ + n / 9))];
-                    j = run.x;
-                    e = run.x + run.y;
-                }
-                return true;
-            };
-            bool have = advance();
-            double cx_ = 0, cy_ = 0, cz_ = 0;
-            int cj = 0;
-            if (have) {
-                cx_ = rsp[j].x;
-                cy_ = rsp[j].y;
-                cz_ = rsp[j].z;
-                cj = j++;
-            }
-            while (have) {
-                const bool have_next = advance();
-                double nx_ = 0, ny_ = 0, nz_ = 0;
-                int nj = 0;
-                if (have_next) {
-                    nx_ = rsp[j].x;
-                    ny_ = rsp[j].y;
-                    nz_ = rsp[j].z;
-                    nj = j++;
-                }
-                const double d = dist2_exact(qx, qy, qz, cx_, cy_, cz_);
-                // strict <, runs in ascending order: among coincident reference points (one stable-sorted run) the
-                // first, i.e. the smallest original index, wins
-                if (d < best) {
-                    best = d;
-                    best_j = cj;
-                }
-                cx_ = nx_;
-                cy_ = ny_;
-                cz_ = nz_;
-                cj = nj;
-                have = have_next;
-            }
-            done = true;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    bool unresolved = false;
-    if (active) {
-        unresolved = true;
-        long long best_i = -1;
-        if (best_j >= 0) best_i = rsp[best_j].idx;
-        if (in_grid && best_j >= 0) {
-            const double lox = fr.ox + (double) (mcx - 1) * cell_h, hix = fr.ox + (double) (mcx + 2) * cell_h;
-            const double loy = fr.oy + (double) (mcy - 1) * cell_h, hiy = fr.oy + (double) (mcy + 2) * cell_h;
-            const double loz = fr.oz + (double) (mcz - 1) * cell_h, hiz = fr.oz + (double) (mcz + 2) * cell_h;
-            double gmin = fmin(fmin(qx - lox, hix - qx), fmin(fmin(qy - loy, hiy - qy), fmin(qz - loz, hiz - qz)));
-            gmin *= (1.0 - 1e-9);  // rounding slack of the cell assignment
-            // strictly inside the guaranteed ball: an equally distant point outside the block cannot exist
-            unresolved = !(gmin > 0.0 && best < gmin * gmin);
-        }
-        d2_out[i] = best;
-        idx_out[i] = (int) best_i;
-    }
     const unsigned long long um = __ballot(unresolved);
     if (um) {
         unsigned int base = 0;
@@ -521,13 +395,8 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         FrameView fr{r.origin[0], r.origin[1], r.origin[2], r.fine_h};
         {
             TimerScope ts(ctx, "nn_grid");
-            static const int mode = std::getenv("ME_NN_MODE") ? std::atoi(std::getenv("ME_NN_MODE")) : 1;
-            if (mode == 0)
-                hipLaunchKernelGGL(k_nn_grid, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
-                                   r.nn_grid, fr, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
-            else
-                hipLaunchKernelGGL(k_nn_cells, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
-                                   r.nn_grid, fr, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
+            hipLaunchKernelGGL(k_nn_grid, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
+                               r.nn_grid, fr, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
         }
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)
