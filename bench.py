@@ -5,8 +5,10 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
 one rank per GPU over RCCL.  One "step" = one pass of the whole hot path over the synthetic pair, starting from the
 two clouds RESIDENT IN HBM (raw, unsorted fp64 AoS) and ending with every scalar on the host: Morton sort + index
 build, both 1-NN passes + AC/COM/CD statistics, est-MME (+ GT-MME), voxel Gaussians, AWD, CDF sort, SCS.
-Strong scaling: every rank holds the pair, processes its Morton slab of the per-point passes, and the partial sums
-are all-reduced (RCCL); value = (N_est + N_gt) / max-over-ranks step time.
+Strong scaling (N > 1): every rank sees the pair but keeps, sorts, indexes and searches only its spatial slab (+ halo) of
+both clouds (cloud_map_evaluation_amd/dist.py::suite_step_slab); queries whose nearest neighbour may live on another
+rank are resolved with one all-gather + min-reduce, partial sums are all-reduced, voxel partials all-gathered (RCCL);
+value = (N_est + N_gt) / max-over-ranks step time.
 
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed inside this process) and
 "cpu_baseline" (the CPU oracle = port of the reference's CPU path, timed on this box's host cores on a bounded sample).
@@ -51,8 +53,11 @@ def suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme):
 
     from cloud_map_evaluation_amd import dist as medist
 
-    return medist.suite_step(eng, dist if world > 1 else None, torch.device("cuda", torch.cuda.current_device()), est_d, gt_d,
-                             P, evaluate_gt_mme)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1:
+        # spatial slabs: every rank sorts / indexes / searches only its slab (+ 1 m halo) of both clouds
+        return medist.suite_step_slab(eng, dist, dev, est_d, gt_d, P, dist.get_rank(), world, evaluate_gt_mme, halo=1.0)
+    return medist.suite_step(eng, None, dev, est_d, gt_d, P, evaluate_gt_mme)
 
 
 def cpu_baseline(args, P, evaluate_gt_mme):
@@ -110,7 +115,6 @@ def main():
     torch.cuda.synchronize()
 
     eng = Engine(local_rank)
-    eng.set_shard(rank, world)
 
     def sync():
         torch.cuda.synchronize()
@@ -143,7 +147,10 @@ def main():
                                f"est-MME{'+GT-MME' if evaluate_gt_mme else ''} (r={args.nn_radius}) + voxel Gaussians/AWD/CDF/SCS "
                                f"(voxel={args.voxel}), clouds resident in HBM, index build included",
                    "n_est": n_e, "n_gt": n_g, "nn_radius": args.nn_radius, "vmd_voxel_size": args.voxel,
-                   "parallelism": f"morton-slab x{world} (replicated reference, all-reduced partial sums)"},
+                   "parallelism": ("single GPU" if world == 1 else
+                                   f"spatial slabs x{world} along the longest axis (+1 m halo): each rank sorts/indexes/searches "
+                                   "1/N of both clouds; cross-rank 1-NN resolve (all-gather + min-reduce), all-reduced partial "
+                                   "sums, all-gathered voxel partials (RCCL)")},
         "results": {"AC": [float(x) for x in res["ac"]], "COM": [float(x) for x in res["com"]], "CD": float(res["cd"]),
                     "MME_est": float(res["mme_est"]), "MME_gt": float(res["mme_gt"]), "AWD": float(res["awd"]),
                     "SCS": float(res["scs"]), "W_voxels": int(res["n_w"]), "MME_valid": res["mme_valid"]},

@@ -133,6 +133,8 @@ int me_download_cloud(me_ctx *ctx, int slot, double *xyz_host) {
 
 int me_nn1(me_ctx *ctx, int query_slot, int ref_slot, int32_t *idx, double *d2) {
     if (!ctx) return ME_ERR_ARG;
+    if ((idx || d2) && query_slot >= 0 && query_slot <= 1 && ctx->cloud[query_slot].slab.axis >= 0)
+        return ctx->fail(ME_ERR_STATE, "me_nn1: per-point outputs are not available in slab mode (pass NULL)");
     ME_TRY(me::nn_search(ctx, query_slot, ref_slot));
     if (idx || d2) return me::nn_fetch(ctx, query_slot, idx, d2);
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -167,7 +169,7 @@ void me_nn_finalize(const me_nn_partial *t, const double sigma_num[5], int64_t n
 int me_nn_stats(me_ctx *ctx, int query_slot, double gate, int gate_mode, const double trunc[5], me_nn_stats_out *out) {
     if (!ctx) return ME_ERR_ARG;
     if (!out) return ctx->fail(ME_ERR_ARG, "me_nn_stats: out is NULL");
-    if (ctx->shard_world != 1)
+    if (ctx->shard_world != 1 || ctx->slab.axis >= 0)
         return ctx->fail(ME_ERR_STATE, "me_nn_stats is the single-GPU one-shot; use me_nn_partial_sums / me_nn_sigma_sums when sharded");
     me_nn_partial p;
     ME_TRY(me::nn_partial(ctx, query_slot, gate, gate_mode, trunc, &p));
@@ -181,7 +183,7 @@ int me_nn_stats(me_ctx *ctx, int query_slot, double gate, int gate_mode, const d
 int me_chamfer(me_ctx *ctx, double *cd) {
     if (!ctx) return ME_ERR_ARG;
     if (!cd) return ctx->fail(ME_ERR_ARG, "me_chamfer: cd is NULL");
-    if (ctx->shard_world != 1) return ctx->fail(ME_ERR_STATE, "me_chamfer is single-GPU; use the partial-sum calls when sharded");
+    if (ctx->shard_world != 1 || ctx->slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_chamfer is single-GPU; use the partial-sum calls when sharded");
     const double tr[5] = {0, 0, 0, 0, 0};
     me_nn_partial a, b;
     ME_TRY(me::nn_search(ctx, ME_SLOT_EST, ME_SLOT_GT));
@@ -203,8 +205,48 @@ int me_mme(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, u
 int me_voxel_gaussians(me_ctx *ctx, int slot, double voxel_size, int32_t *keys, int32_t *npts, double *mu, double *sigma,
                        double *entropy, int64_t *n_voxels) {
     if (!ctx) return ME_ERR_ARG;
-    ME_TRY(me::voxel_build(ctx, slot, voxel_size));
+    if (slot < 0 || slot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
+    if (ctx->cloud[slot].slab.axis >= 0)
+        return ctx->fail(ME_ERR_STATE, "me_voxel_gaussians: in slab mode use me_voxel_partials and merge across ranks");
+    ME_TRY(me::voxel_build(ctx, slot, voxel_size, false));
     return me::voxel_export(ctx, slot, keys, npts, mu, sigma, entropy, n_voxels);
+}
+
+int me_voxel_partials(me_ctx *ctx, int slot, double voxel_size, int32_t *keys, int32_t *npts, double *mu, double *m2,
+                      int64_t *n_voxels) {
+    if (!ctx) return ME_ERR_ARG;
+    if (slot < 0 || slot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
+    ME_TRY(me::voxel_build(ctx, slot, voxel_size, true));
+    return me::voxel_export(ctx, slot, keys, npts, mu, m2, nullptr, n_voxels);
+}
+
+int me_set_slab(me_ctx *ctx, int axis, double lo, double hi, double halo) {
+    if (!ctx) return ME_ERR_ARG;
+    if (axis < 0) {
+        ctx->slab = me::SlabView{-1, 0, 0, 0, 0};
+        return ME_OK;
+    }
+    if (axis > 2 || !(lo < hi) || !(halo >= 0)) return ctx->fail(ME_ERR_ARG, "me_set_slab: need axis in 0..2, lo < hi, halo >= 0");
+    ctx->slab = me::SlabView{axis, lo, hi, lo - halo, hi + halo};
+    return ME_OK;
+}
+
+int me_nn_unresolved(me_ctx *ctx, int query_slot, double *xyz_device, int64_t capacity, int64_t *count) {
+    if (!ctx) return ME_ERR_ARG;
+    long long c = 0;
+    const int rc = me::nn_unresolved(ctx, query_slot, xyz_device, capacity, &c);
+    if (count) *count = c;
+    return rc;
+}
+
+int me_nn_points(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_device) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::nn_points(ctx, ref_slot, xyz_device, m, d2_device);
+}
+
+int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t count) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::nn_patch(ctx, query_slot, d2_device, count);
 }
 
 int me_awd_scs(me_ctx *ctx, double voxel_size, int min_pts, int scs_radius, double *rows, double *w_sorted, int64_t *n_rows,
@@ -227,7 +269,7 @@ int me_scs_table(me_ctx *ctx, const int32_t *keys, const double *w, int64_t n, i
 int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out) {
     if (!ctx) return ME_ERR_ARG;
     if (!p || !out) return ctx->fail(ME_ERR_ARG, "me_run_suite: NULL argument");
-    if (ctx->shard_world != 1) return ctx->fail(ME_ERR_STATE, "me_run_suite is single-GPU; drive the partial calls when sharded");
+    if (ctx->shard_world != 1 || ctx->slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_run_suite is single-GPU; drive the partial calls when sharded");
     std::memset(out, 0, sizeof(*out));
     // MME first, as MapEval::process (map_eval.cpp:52-66)
     if (p->evaluate_mme) {

@@ -5,8 +5,8 @@
 //   1. optional rigid/homogeneous transform (map_eval.cpp:1206) + bbox reduction,
 //   2. 63-bit Morton codes on a grid nested in the radius-search cell (cell = code >> 3*shift),
 //   3. radix sort (rocPRIM) and gather into 32-byte SPoint records -> every later pass streams coalesced,
-//   4. an implicit 8-ary BVH over consecutive 16-point blocks of the sorted array (fp32 boxes rounded outward),
-//   5. the table of occupied radius cells + an open-addressing hash (cell Morton code -> cell index).
+//   4. the tables of occupied cells (radius grid, 1-NN grid) + open-addressing hashes (cell Morton code -> cell),
+//   5. a sparse octree over the Morton prefixes above the 1-NN cells (tight fp32 boxes rounded outward).
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -67,6 +67,23 @@ __global__ void __launch_bounds__(256) k_bbox(const double *__restrict__ xyz, lo
     }
 }
 
+// slab mode: keep the points inside [reg_lo, reg_hi) along the slab axis (owned + halo)
+__global__ void k_slab_flags(const double *__restrict__ xyz, long long n, SlabView s, unsigned int *__restrict__ flags) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = xyz[3 * i + s.axis];
+    flags[i] = (v >= s.reg_lo && v < s.reg_hi) ? 1u : 0u;
+}
+__global__ void k_slab_compact(const double *__restrict__ xyz, long long n, const unsigned int *__restrict__ flags,
+                               const unsigned int *__restrict__ pos, double *__restrict__ out) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const long long o = pos[i];
+    out[3 * o] = xyz[3 * i];
+    out[3 * o + 1] = xyz[3 * i + 1];
+    out[3 * o + 2] = xyz[3 * i + 2];
+}
+
 __global__ void k_morton(const double *__restrict__ xyz, long long n, double ox, double oy, double oz, double fine_h,
                          unsigned long long *__restrict__ codes, unsigned int *__restrict__ iota) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,10 +112,20 @@ __global__ void k_gather(const double *__restrict__ xyz, const unsigned int *__r
     sp[i] = p;
 }
 
-__global__ void k_bvh_leaves(const SPoint *__restrict__ sp, long long n, long long n_leaf, float *__restrict__ boxes) {
-    const long long l = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= n_leaf) return;
-    const long long b = l * kLeaf, e = (b + kLeaf < n) ? b + kLeaf : n;
+// octree level 0: one node per occupied 1-NN-grid cell (a contiguous run of sorted points)
+__global__ void k_oct_leaves(const SPoint *__restrict__ sp, const unsigned int *__restrict__ cell_start, long long n_cells,
+                             long long n_points, ONode *__restrict__ nodes) {
+    const long long c = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_cells) return;
+    ONode nd;
+    if (c == n_cells) {  // terminator: holds the end of the last run
+        for (int d = 0; d < 3; ++d) nd.lo[d] = nd.hi[d] = 0.0f;
+        nd.begin = (unsigned int) n_points;
+        nd.parent = 0;
+        nodes[c] = nd;
+        return;
+    }
+    const long long b = cell_start[c], e = cell_start[c + 1];
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (long long j = b; j < e; ++j) {
         const SPoint p = sp[j];
@@ -106,31 +133,47 @@ __global__ void k_bvh_leaves(const SPoint *__restrict__ sp, long long n, long lo
         lo[1] = fmin(lo[1], p.y); hi[1] = fmax(hi[1], p.y);
         lo[2] = fmin(lo[2], p.z); hi[2] = fmax(hi[2], p.z);
     }
-    float *o = boxes + 6 * l;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        o[d] = __double2float_rd(lo[d]);      // outward rounding keeps the fp32 box a superset of the fp64 one
-        o[3 + d] = __double2float_ru(hi[d]);
+        nd.lo[d] = __double2float_rd(lo[d]);  // outward rounding keeps the fp32 box a superset of the fp64 one
+        nd.hi[d] = __double2float_ru(hi[d]);
     }
+    nd.begin = (unsigned int) b;
+    nd.parent = 0;
+    nodes[c] = nd;
 }
 
-__global__ void k_bvh_up(const float *__restrict__ child, long long n_child, float *__restrict__ parent, long long n_parent) {
+// octree level l+1 from level l: parent p owns the children [begin[p], begin[p+1]) (<= 8, contiguous)
+__global__ void k_oct_up(ONode *__restrict__ child, long long n_child, const unsigned int *__restrict__ begin,
+                         long long n_parent, ONode *__restrict__ parent) {
     const long long p = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_parent) return;
-    const long long b = p * kFan, e = (b + kFan < n_child) ? b + kFan : n_child;
+    if (p > n_parent) return;
+    ONode nd;
+    if (p == n_parent) {
+        for (int d = 0; d < 3; ++d) nd.lo[d] = nd.hi[d] = 0.0f;
+        nd.begin = (unsigned int) n_child;
+        nd.parent = 0;
+        parent[p] = nd;
+        return;
+    }
+    const long long b = begin[p], e = (p + 1 < n_parent) ? (long long) begin[p + 1] : n_child;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (long long c = b; c < e; ++c) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            lo[d] = fminf(lo[d], child[6 * c + d]);
-            hi[d] = fmaxf(hi[d], child[6 * c + 3 + d]);
+            lo[d] = fminf(lo[d], child[c].lo[d]);
+            hi[d] = fmaxf(hi[d], child[c].hi[d]);
         }
+        child[c].parent = (unsigned int) p;
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        parent[6 * p + d] = lo[d];
-        parent[6 * p + 3 + d] = hi[d];
+        nd.lo[d] = lo[d];
+        nd.hi[d] = hi[d];
     }
+    nd.begin = (unsigned int) b;
+    nd.parent = 0;
+    parent[p] = nd;
 }
 
 __global__ void k_cell_flags(const unsigned long long *__restrict__ codes, long long n, int shift3,
@@ -238,17 +281,56 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
     c.nn_ref_slot = -1;
     c.n_vox = 0;
     c.vox_size = 0;
+    c.vox_valid = false;
     // any result that used this cloud as the reference is stale now
     ctx->cloud[1 - slot].nn_ref_slot = -1;
     c.n = n;
-    ME_CHECK(ctx, c.xyz.ensure((size_t) n * 3 * sizeof(double)));
-    ME_CHECK(ctx, hipMemcpyAsync(c.xyz.p, src, (size_t) n * 3 * sizeof(double),
-                                 src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-    if (T) {
-        Mat4 m;
-        std::memcpy(m.m, T, sizeof(m.m));
-        hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, m);
+    c.n_total = n;
+    c.slab = ctx->slab;
+    c.n_unres = 0;
+    if (ctx->slab.axis < 0) {
+        ME_CHECK(ctx, c.xyz.ensure((size_t) n * 3 * sizeof(double)));
+        ME_CHECK(ctx, hipMemcpyAsync(c.xyz.p, src, (size_t) n * 3 * sizeof(double),
+                                     src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        if (T) {
+            Mat4 m;
+            std::memcpy(m.m, T, sizeof(m.m));
+            hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, m);
+        }
+    } else {
+        // slab mode: stage the whole cloud, transform, keep only [reg_lo, reg_hi) along the slab axis (stable order)
+        DevBuf &stage = ctx->tmp[3], &flags = ctx->tmp[0], &pos = ctx->tmp[1];
+        ME_CHECK(ctx, stage.ensure((size_t) n * 3 * sizeof(double)));
+        ME_CHECK(ctx, flags.ensure((size_t) n * 4));
+        ME_CHECK(ctx, pos.ensure((size_t) n * 4));
+        ME_CHECK(ctx, hipMemcpyAsync(stage.p, src, (size_t) n * 3 * sizeof(double),
+                                     src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        if (T) {
+            Mat4 m;
+            std::memcpy(m.m, T, sizeof(m.m));
+            hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(256), 0, ctx->stream, stage.as<double>(), n, m);
+        }
+        TimerScope ts(ctx, "slab_filter");
+        hipLaunchKernelGGL(k_slab_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream, stage.as<double>(), n, c.slab,
+                           flags.as<unsigned int>());
+        ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), n));
+        unsigned int last_pos = 0, last_flag = 0;
+        ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const long long kept = (long long) last_pos + last_flag;
+        ME_CHECK(ctx, c.xyz.ensure((size_t) std::max<long long>(kept, 1) * 3 * sizeof(double)));
+        hipLaunchKernelGGL(k_slab_compact, dim3(grid_for(n)), dim3(256), 0, ctx->stream, stage.as<double>(), n,
+                           flags.as<unsigned int>(), pos.as<unsigned int>(), c.xyz.as<double>());
+        c.n = kept;
+        if (kept == 0) {  // this rank's slab (+halo) holds nothing of this cloud: every pass returns empty partials
+            c.uploaded = true;
+            c.index_valid = false;
+            ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            return ME_OK;
+        }
     }
+    n = c.n;
     // bbox
     const unsigned int nb = (unsigned int) std::min<long long>(1024, (n + 255) / 256);
     ME_CHECK(ctx, ctx->red.ensure((size_t) nb * 6 * sizeof(double)));
@@ -318,31 +400,6 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
         hipLaunchKernelGGL(k_gather, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
                            perm.as<unsigned int>(), n, c.sp.as<SPoint>());
     }
-    // --- BVH ---
-    {
-        BvhView &v = c.bvh;
-        long long cnt = (n + kLeaf - 1) / kLeaf, off = 0;
-        int L = 0;
-        for (;;) {
-            if (L >= kMaxLevels) return ctx->fail(ME_ERR_ARG, "cloud too large for the BVH level table");
-            v.count[L] = cnt;
-            v.off[L] = off;
-            off += (cnt + 1) & ~1LL;  // even level offsets: a group of 8 sibling boxes (192 B) is 16-byte aligned
-            ++L;
-            if (cnt == 1) break;
-            cnt = (cnt + kFan - 1) / kFan;
-        }
-        v.n_levels = L;
-        ME_CHECK(ctx, c.boxes.ensure((size_t) (off + kFan) * 6 * sizeof(float)));  // + one group of slack for the burst read
-        v.boxes = c.boxes.as<float>();
-        TimerScope ts(ctx, "bvh");
-        hipLaunchKernelGGL(k_bvh_leaves, dim3(grid_for(v.count[0])), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), n,
-                           v.count[0], c.boxes.as<float>());
-        for (int l = 1; l < L; ++l)
-            hipLaunchKernelGGL(k_bvh_up, dim3(grid_for(v.count[l])), dim3(256), 0, ctx->stream,
-                               c.boxes.as<float>() + 6 * v.off[l - 1], v.count[l - 1],
-                               c.boxes.as<float>() + 6 * v.off[l], v.count[l]);
-    }
     // --- occupied cells per Morton level -> pick the 1-NN grid level; build the cell tables ---
     {
         TimerScope ts(ctx, "cells");
@@ -373,6 +430,45 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
             c.nn_grid = c.grid;
         } else {
             ME_TRY(build_grid_table(ctx, c, nn_shift, c.nn_tab, c.nn_grid));
+        }
+        // --- sparse octree above the 1-NN cells (general 1-NN path) ---
+        {
+            OctView &v = c.oct;
+            int L = 0;
+            long long off = 0;
+            for (int k = nn_shift; k <= kMortonBits; ++k) {
+                if (L >= kMaxLevels) return ctx->fail(ME_ERR_ARG, "octree deeper than the level table (cloud extent / cell size too large)");
+                v.count[L] = c.level_unique[k];
+                v.off[L] = off;
+                off += v.count[L] + 1;
+                ++L;
+                if (c.level_unique[k] == 1) break;
+            }
+            v.n_levels = L;
+            ME_CHECK(ctx, c.oct_nodes.ensure((size_t) (off + kFan) * sizeof(ONode)));  // + slack for the 8-record burst
+            ME_CHECK(ctx, hipMemsetAsync(c.oct_nodes.as<ONode>() + off, 0, kFan * sizeof(ONode), ctx->stream));
+            v.nodes = c.oct_nodes.as<ONode>();
+            ONode *nodes = c.oct_nodes.as<ONode>();
+            hipLaunchKernelGGL(k_oct_leaves, dim3(grid_for(v.count[0] + 1)), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),
+                               c.nn_grid.cell_start, v.count[0], n, nodes);
+            // prefix codes of the current level (level 0: the cell codes of the 1-NN grid), ping-pong
+            DevBuf &ca = ctx->tmp[2], &cb = ctx->tmp[3], &flags = ctx->tmp[0], &pos = ctx->tmp[1], &begin = ctx->tmp[4];
+            const unsigned long long *cur = c.nn_grid.cell_code;
+            for (int l = 0; l + 1 < L; ++l) {
+                const long long nc = v.count[l], np = v.count[l + 1];
+                ME_CHECK(ctx, flags.ensure((size_t) nc * 4));
+                ME_CHECK(ctx, pos.ensure((size_t) nc * 4));
+                ME_CHECK(ctx, begin.ensure((size_t) (np + 1) * 4));
+                DevBuf &nxt = (l % 2 == 0) ? ca : cb;
+                ME_CHECK(ctx, nxt.ensure((size_t) np * 8));
+                hipLaunchKernelGGL(k_cell_flags, dim3(grid_for(nc)), dim3(256), 0, ctx->stream, cur, nc, 3, flags.as<unsigned int>());
+                ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), nc));
+                hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(nc)), dim3(256), 0, ctx->stream, cur, flags.as<unsigned int>(),
+                                   pos.as<unsigned int>(), nc, 3, nxt.as<unsigned long long>(), begin.as<unsigned int>());
+                hipLaunchKernelGGL(k_oct_up, dim3(grid_for(np + 1)), dim3(256), 0, ctx->stream, nodes + v.off[l], nc,
+                                   begin.as<unsigned int>(), np, nodes + v.off[l + 1]);
+                cur = nxt.as<unsigned long long>();
+            }
         }
     }
     ME_CHECK(ctx, hipGetLastError());

@@ -13,9 +13,8 @@
 
 namespace me {
 
-constexpr int kLeaf = 16;      // points per BVH leaf (consecutive Morton-sorted points)
-constexpr int kFan = 8;        // children per internal BVH node
-constexpr int kMaxLevels = 12; // 16 * 8^11 points
+constexpr int kFan = 8;        // children per octree node
+constexpr int kMaxLevels = 17; // octree levels above the leaf cells (taken-masks: 2 x 64 bits)
 constexpr int kMortonBits = 21;
 
 struct DevBuf {
@@ -49,11 +48,21 @@ struct alignas(32) SPoint {
     long long idx;
 };
 
-struct BvhView {
-    const float *boxes;  // 6 floats per node: lo xyz, hi xyz (rounded outward from the fp64 extent)
-    int n_levels;        // level 0 = leaves ... level n_levels-1 = root (1 node)
+// Sparse octree over the Morton prefixes of the sorted points (the general 1-NN path).  Level 0 = the occupied cells of
+// the 1-NN grid (each a contiguous run of `sp`), level l+1 = their unique 3-bit-shorter prefixes, up to a single root.
+// A node's children are contiguous on the level below; every node's box lies inside its octree cell, so boxes of one
+// level never straddle a Morton seam (a fixed-count grouping of consecutive points does, and was measured to cost
+// ~150 node visits per query instead of ~20).
+struct alignas(32) ONode {
+    float lo[3], hi[3];   // tight fp32 box of the points below, rounded OUTWARD from the fp64 extent
+    unsigned int begin;   // first child on the level below (level 0: first point); the node after it holds the end
+    unsigned int parent;  // index on the level above
+};
+struct OctView {
+    const ONode *nodes;
+    int n_levels;  // level 0 = leaf cells ... level n_levels-1 = root (1 node)
     long long count[kMaxLevels];
-    long long off[kMaxLevels];  // node offset of each level inside `boxes`
+    long long off[kMaxLevels];  // offset of each level inside `nodes` (each level stores count + 1 records)
 };
 
 struct GridView {
@@ -71,6 +80,26 @@ struct GridTable {
     int shift = -1;
 };
 
+// Spatial slab of a context (multi-GPU): a point is OWNED iff lo <= p[axis] < hi; [reg_lo, reg_hi) = slab + halo is
+// everything the context holds.  axis < 0: no slab, every point is owned.  +-inf faces never fail a test.
+struct SlabView {
+    int axis;
+    double lo, hi;
+    double reg_lo, reg_hi;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ bool slab_owned(const SlabView &s, double x, double y, double z) {
+    if (s.axis < 0) return true;
+    const double v = s.axis == 0 ? x : (s.axis == 1 ? y : z);
+    return v >= s.lo && v < s.hi;
+}
+__device__ __forceinline__ double slab_face_distance(const SlabView &s, double x, double y, double z) {
+    if (s.axis < 0) return INFINITY;
+    const double v = s.axis == 0 ? x : (s.axis == 1 ? y : z);
+    return fmin(v - s.reg_lo, s.reg_hi - v);  // distance to the nearest face beyond which this context holds nothing
+}
+#endif
+
 // Morton frame of a cloud, as the kernels need it to place a foreign point into this cloud's grid
 struct FrameView {
     double ox, oy, oz;  // origin (bbox min)
@@ -78,7 +107,11 @@ struct FrameView {
 };
 
 struct Cloud {
-    long long n = 0;
+    long long n = 0;        // points held (slab mode: owned + halo)
+    long long n_total = 0;  // points the caller passed to the upload
+    SlabView slab{-1, 0, 0, 0, 0};
+    DevBuf nn_unres;        // slab mode: sorted positions of the not-yet-global 1-NN results
+    long long n_unres = 0;
     bool uploaded = false;
     DevBuf xyz;  // double[n][3] original order, after the optional transform
     // Morton frame
@@ -90,9 +123,9 @@ struct Cloud {
     bool index_valid = false;
     DevBuf codes;  // uint64[n] sorted fine Morton codes
     DevBuf sp;     // SPoint[n] sorted
-    // BVH
-    BvhView bvh{};
-    DevBuf boxes;
+    // sparse octree (general 1-NN path)
+    OctView oct{};
+    DevBuf oct_nodes;
     // cell tables: `grid` at the radius level (MME), `nn_grid` at the level whose occupied cells hold ~16 points
     // (1-NN fast path); they share storage when the two levels coincide
     GridTable grid_tab, nn_tab;
@@ -104,6 +137,7 @@ struct Cloud {
     // voxel table (ascending key order)
     double vox_size = 0;
     long long n_vox = 0;
+    bool vox_valid = false, vox_raw = false;
     DevBuf vox_key;    // uint64[V] packed key
     DevBuf vox_n;      // int32[V]
     DevBuf vox_mu;     // double[V][3]
@@ -128,6 +162,7 @@ struct me_ctx {
     void *host_pinned = nullptr;
     size_t host_pinned_bytes = 0;
     int shard_rank = 0, shard_world = 1;
+    me::SlabView slab{-1, 0, 0, 0, 0};  // applied to the next uploads
     // instrumentation
     bool timers_on = false;
     std::map<std::string, me::TimerRec> timers;
@@ -190,6 +225,9 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size);
 // ---- me_nn.hip ----
 int nn_search(me_ctx *ctx, int qslot, int rslot);
 int nn_fetch(me_ctx *ctx, int qslot, int32_t *idx, double *d2);
+int nn_unresolved(me_ctx *ctx, int qslot, double *xyz_device, long long capacity, long long *count);
+int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, double *d2_device);
+int nn_patch(me_ctx *ctx, int qslot, const double *d2_device, long long count);
 int nn_partial(me_ctx *ctx, int qslot, double gate, int gate_mode, const double trunc[5], me_nn_partial *out);
 int nn_sigma(me_ctx *ctx, int qslot, double gate, int gate_mode, const double mean[5], double sigma_num[5]);
 
@@ -198,7 +236,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
             long long *n_valid);
 
 // ---- me_voxel.hip ----
-int voxel_build(me_ctx *ctx, int slot, double voxel_size);
+int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw);
 int voxel_export(me_ctx *ctx, int slot, int32_t *keys, int32_t *npts, double *mu, double *sigma, double *entropy,
                  int64_t *n_voxels);
 int awd_scs(me_ctx *ctx, double voxel_size, int min_pts, int scs_radius, double *rows, double *w_sorted,

@@ -26,14 +26,14 @@ namespace me {
 
 __global__ void __launch_bounds__(256)
 k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
-      GridView g, double r2, int min_k, double *__restrict__ ent_s, unsigned char *__restrict__ valid_s,
+      GridView g, SlabView slab, double r2, int min_k, double *__restrict__ ent_s, unsigned char *__restrict__ valid_s,
       double *__restrict__ part_sum, long long *__restrict__ part_cnt) {
     const int lane = threadIdx.x & 63;
     // XCD-aware chunking (see k_nn1): gridDim.x is a multiple of 8
     const unsigned int per = gridDim.x / 8;
     const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
     const long long i = i_begin + (long long) vb * blockDim.x + threadIdx.x;
-    const bool active = i < i_end;
+    bool active = i < i_end;
     const int shift3 = 3 * g.shift;
     const int cell_lim = 1 << (kMortonBits - g.shift);
 
@@ -45,6 +45,11 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
         qy = q.y;
         qz = q.z;
         mycell = codes[i] >> shift3;
+        if (!slab_owned(slab, qx, qy, qz)) {  // slab mode: halo points are neighbours only, never queries
+            ent_s[i] = 0.0;
+            valid_s[i] = 0;
+            active = false;
+        }
     }
     int k = 0;
     double s1x = 0, s1y = 0, s1z = 0;
@@ -176,6 +181,15 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     if (min_k < 2) return ctx->fail(ME_ERR_ARG, "me_mme: min_k must be >= 2 (covariance divides by k-1)");
     Cloud &c = ctx->cloud[slot];
     if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "me_mme: cloud not uploaded");
+    if (c.slab.axis >= 0 && (entropies || valid))
+        return ctx->fail(ME_ERR_STATE, "me_mme: per-point outputs are not available in slab mode (pass NULL)");
+    if (c.slab.axis >= 0 && c.slab.reg_lo > -INFINITY && c.slab.lo - c.slab.reg_lo < radius)
+        return ctx->fail(ME_ERR_ARG, "me_mme: slab halo is smaller than the radius");
+    if (c.n == 0) {  // empty slab
+        if (sum_H) *sum_H = 0.0;
+        if (n_valid) *n_valid = 0;
+        return ME_OK;
+    }
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     // the 27-cell stencil is exact only when cell edge >= radius; rebuild when it is not, or when the cells are
     // needlessly coarse (more candidates per query than necessary)
@@ -197,7 +211,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     {
         TimerScope ts(ctx, "mme");
         hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
-                           c.grid, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc);
+                           c.grid, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc);
     }
     hipLaunchKernelGGL(k_mme_final, dim3(1), dim3(256), 0, ctx->stream, ps, pc, (int) nb, outs, outc);
     double hs = 0;

@@ -1,10 +1,10 @@
 // me_nn.hip — batched exact 1-NN (KDTreeFlann::SearchKNN k=1, map_eval.cpp:1218,1231,1415,1424) and the
 // threshold statistics of getDiffRegResultWithCorrespondence (map_eval.cpp:1069-1145).
 //
-// One lane per query, queries in Morton order (neighbouring lanes walk neighbouring nodes, so node and leaf
-// fetches hit L1/L2).  Traversal of the implicit 8-ary BVH is stackless AND nearest-first:
-//   state = (level, node, 64-bit mask: one byte of "children already taken" per level).
-//   At a node the 8 child boxes (192 contiguous bytes, one burst of loads) are bounded at once; the closest
+// Two kernels: a uniform-grid fast path (k_nn_grid) and, for what it cannot settle, a general walk (k_nn1) of a sparse
+// octree over the Morton prefixes: one lane per query, stackless AND nearest-first:
+//   state = (level, node, one byte of "children already taken" per level).
+//   At a node the <= 8 child records (contiguous, one burst of loads) are bounded at once; the closest
 //   not-yet-taken child whose lower bound does not exceed the current best is entered; when none is left the
 //   walk returns to the parent (whose child bounds are simply recomputed).  Nearest-first order makes the
 //   first leaf reached almost always the right one, so far-away queries (outliers, non-overlapping regions;
@@ -26,18 +26,13 @@ __device__ __forceinline__ double box_lower_bound(const float *__restrict__ b, d
     return (dx * dx + dy * dy) + dz * dz;
 }
 
-__device__ __forceinline__ void scan_leaf(const SPoint *__restrict__ rsp, long long nr, long long leaf, double qx,
-                                          double qy, double qz, double &best, long long &best_i) {
-    const long long b = leaf * kLeaf;
-    const long long e = (b + kLeaf < nr) ? b + kLeaf : nr;
-    for (long long j = b; j < e; ++j) {
-        const SPoint p = rsp[j];
-        const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
-        if (d < best || (d == best && p.idx < best_i)) {  // ties -> smallest reference index (as the oracle)
-            best = d;
-            best_i = p.idx;
-        }
-    }
+// squared distance to the farthest corner of the box: an upper bound on the distance to ANY point inside it
+// (monotone operations on the outward-rounded box, so it is >= the computed distance of every contained point)
+__device__ __forceinline__ double box_upper_bound(const float *__restrict__ b, double qx, double qy, double qz) {
+    const double dx = fmax(fabs(qx - (double) b[0]), fabs(qx - (double) b[3]));
+    const double dy = fmax(fabs(qy - (double) b[1]), fabs(qy - (double) b[4]));
+    const double dz = fmax(fabs(qz - (double) b[2]), fabs(qz - (double) b[5]));
+    return (dx * dx + dy * dy) + dz * dz;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -56,13 +51,13 @@ __device__ __forceinline__ void scan_leaf(const SPoint *__restrict__ rsp, long l
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, GridView g,
-          FrameView fr, double *__restrict__ d2_out, int *__restrict__ idx_out, unsigned int *__restrict__ list,
-          unsigned int *__restrict__ list_count) {
+          FrameView fr, SlabView slab, double *__restrict__ d2_out, int *__restrict__ idx_out,
+          unsigned int *__restrict__ list, unsigned int *__restrict__ list_count) {
     const int lane = threadIdx.x & 63;
     const unsigned int per = gridDim.x / 8;  // XCD-aware chunking, gridDim.x is a multiple of 8
     const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
     const long long i = q_begin + (long long) vb * blockDim.x + threadIdx.x;
-    const bool active = i < q_end;
+    bool active = i < q_end;
     const int cell_bits = kMortonBits - g.shift;
     const int cell_lim = 1 << cell_bits;
     const double cell_h = ldexp(fr.fine_h, g.shift);
@@ -75,6 +70,13 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         qx = q.x;
         qy = q.y;
         qz = q.z;
+        if (!slab_owned(slab, qx, qy, qz)) {  // halo point: a reference for others, not a query of this rank
+            d2_out[i] = -1.0;                 // skip marker for the statistics kernels
+            idx_out[i] = -1;
+            active = false;
+        }
+    }
+    if (active) {
         const double fx = fine_coord(qx, fr.ox, fr.fine_h), fy = fine_coord(qy, fr.oy, fr.fine_h),
                      fz = fine_coord(qz, fr.oz, fr.fine_h);
         const double lim = 2097151.0;
@@ -151,91 +153,107 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// General path: nearest-first BVH walk (see the header).  `list` == nullptr: every query of [q_begin, q_end);
-// otherwise the queries q_begin + list[t], t < *list_count, starting from the bound the grid pass left behind.
+// General path: nearest-first walk of the sparse octree (see the header).  `list` == nullptr: every query of
+// [q_begin, q_end); otherwise the queries q_begin + list[t], t < *list_count, starting from the bound the grid pass
+// left behind.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
-      BvhView bvh, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
+      OctView oct, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
       const unsigned int *__restrict__ list_count) {
-    __shared__ long long s_count[kMaxLevels], s_off[kMaxLevels];
-    if (threadIdx.x < kMaxLevels) {
-        s_count[threadIdx.x] = bvh.count[threadIdx.x];
-        s_off[threadIdx.x] = bvh.off[threadIdx.x];
-    }
+    __shared__ long long s_off[kMaxLevels];
+    if (threadIdx.x < kMaxLevels) s_off[threadIdx.x] = oct.off[threadIdx.x];
     __syncthreads();
-    const int L = bvh.n_levels - 1;
-    const float *__restrict__ boxes = bvh.boxes;
+    const int L = oct.n_levels - 1;  // root level
+    const ONode *__restrict__ nodes = oct.nodes;
     const long long n_items = list ? (long long) *list_count : (q_end - q_begin);
     for (long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += (long long) gridDim.x * blockDim.x) {
-    const long long i = q_begin + (list ? (long long) list[t] : t);
-    const SPoint q = qsp[i];
-    const double qx = q.x, qy = q.y, qz = q.z;
-    double best = INFINITY;
-    long long best_i = 0x7fffffffffffffffLL;
-    if (list) {
-        best = d2_out[i];
-        const int bi = idx_out[i];
-        if (bi >= 0) best_i = bi;
-    }
-
-    if (L == 0) {
-        scan_leaf(rsp, nr, 0, qx, qy, qz, best, best_i);  // the whole cloud is one leaf
-    } else {
-        int l = L;                     // current internal node = (l, n); its children live on level l-1
-        long long n = 0;
-        // "children already entered" of the current node of every level on the path: one byte per level
-        // (levels 1..8 in taken_lo, 9..11 in taken_hi; 16 * 8^9 points > 2^31, so this covers every cloud)
-        unsigned long long taken_lo = 0;
-        unsigned int taken_hi = 0;
-        for (;;) {
-            const long long c0 = n * kFan;
-            const long long rem = s_count[l - 1] - c0;  // >= 1 children exist
-            // one burst: 8 child boxes = 12 x 16 B (level offsets are even, so the group is 16-byte aligned;
-            // the buffer is padded, lanes of a short last group are masked below)
-            const float4 *__restrict__ g = reinterpret_cast<const float4 *>(boxes + 6 * (s_off[l - 1] + c0));
-            float f[48];
-#pragma unroll
-            for (int v = 0; v < 12; ++v) {
-                const float4 t = g[v];
-                f[4 * v] = t.x;
-                f[4 * v + 1] = t.y;
-                f[4 * v + 2] = t.z;
-                f[4 * v + 3] = t.w;
-            }
-            const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
-                                             : (taken_hi >> (8 * (l - 9))) & 0xffu;
-            double bd = INFINITY;
-            int bc = -1;
-#pragma unroll
-            for (int c = 0; c < kFan; ++c) {
-                const double lb = box_lower_bound(&f[6 * c], qx, qy, qz);
-                const bool ok = (c < rem) && !((tk >> c) & 1u) && lb <= best;  // <=: ties may hold a smaller index
-                if (ok && lb < bd) {
-                    bd = lb;
-                    bc = c;
+        const long long i = q_begin + (list ? (long long) list[t] : t);
+        const SPoint q = qsp[i];
+        const double qx = q.x, qy = q.y, qz = q.z;
+        double best = INFINITY;
+        long long best_i = 0x7fffffffffffffffLL;
+        if (list) {
+            best = d2_out[i];
+            const int bi = idx_out[i];
+            if (bi >= 0) best_i = bi;
+        }
+        auto scan_cell = [&](long long leaf) {  // leaf cell = points [begin, next.begin)
+            const long long b = nodes[leaf].begin, e = nodes[leaf + 1].begin;
+            for (long long j = b; j < e; ++j) {
+                const SPoint p = rsp[j];
+                const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
+                if (d < best || (d == best && p.idx < best_i)) {  // ties -> smallest reference index (as the oracle)
+                    best = d;
+                    best_i = p.idx;
                 }
             }
-            if (bc < 0) {  // nothing left under this node: return to the parent
-                if (l == L) break;
-                ++l;
-                n >>= 3;
-                continue;
-            }
-            if (l <= 8) taken_lo |= 1ULL << (8 * (l - 1) + bc);
-            else taken_hi |= 1u << (8 * (l - 9) + bc);
-            if (l == 1) {
-                scan_leaf(rsp, nr, c0 + bc, qx, qy, qz, best, best_i);
-            } else {
-                --l;
-                n = c0 + bc;
-                if (l <= 8) taken_lo &= ~(0xffULL << (8 * (l - 1)));  // fresh node on the level below
-                else taken_hi &= ~(0xffu << (8 * (l - 9)));
+        };
+        if (L == 0) {
+            scan_cell(0);  // the whole cloud is one cell
+        } else {
+            int l = L;          // current node = (l, n); its children live on level l-1
+            long long n = 0;
+            // "children already entered" of the current node of every level on the path: one byte per level
+            unsigned long long taken_lo = 0, taken_hi = 0;  // levels 1..8 / 9..16
+            double bound = best;  // pruning bound: min(best found, tightest box upper bound seen)
+            for (;;) {
+                const ONode *__restrict__ me = nodes + s_off[l] + n;
+                const long long cb = me[0].begin;
+                const int cnt = (int) (me[1].begin - cb);  // 1..8 children, contiguous on the level below
+                const ONode *__restrict__ ch = nodes + s_off[l - 1] + cb;
+                // one burst: up to 8 child records (32 B each; the buffer has 8 records of slack, short groups are masked)
+                float f[48];
+                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(ch);
+#pragma unroll
+                for (int c = 0; c < kFan; ++c) {
+                    const float4 a = g[2 * c], bb = g[2 * c + 1];
+                    f[6 * c] = a.x;
+                    f[6 * c + 1] = a.y;
+                    f[6 * c + 2] = a.z;
+                    f[6 * c + 3] = a.w;
+                    f[6 * c + 4] = bb.x;
+                    f[6 * c + 5] = bb.y;
+                }
+                const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
+                                                 : (unsigned int) (taken_hi >> (8 * (l - 9))) & 0xffu;
+                // every child box also yields an UPPER bound on the answer (some point lies inside it, no farther than
+                // its farthest corner): keeps the depth-first walk from sweeping a wide region on a loose `best`
+#pragma unroll
+                for (int c = 0; c < kFan; ++c)
+                    if (c < cnt) bound = fmin(bound, box_upper_bound(&f[6 * c], qx, qy, qz));
+                double bd = INFINITY;
+                int bc = -1;
+#pragma unroll
+                for (int c = 0; c < kFan; ++c) {
+                    const double lb = box_lower_bound(&f[6 * c], qx, qy, qz);
+                    const bool ok = (c < cnt) && !((tk >> c) & 1u) && lb <= bound;  // <=: ties may hold a smaller index
+                    if (ok && lb < bd) {
+                        bd = lb;
+                        bc = c;
+                    }
+                }
+                if (bc < 0) {  // nothing left under this node: return to the parent
+                    if (l == L) break;
+                    n = me[0].parent;
+                    ++l;
+                    continue;
+                }
+                if (l <= 8) taken_lo |= 1ULL << (8 * (l - 1) + bc);
+                else taken_hi |= 1ULL << (8 * (l - 9) + bc);
+                if (l == 1) {
+                    scan_cell(s_off[0] + cb + bc);
+                    bound = fmin(bound, best);
+                } else {
+                    --l;
+                    n = cb + bc;
+                    if (l <= 8) taken_lo &= ~(0xffULL << (8 * (l - 1)));  // fresh node on the level below
+                    else taken_hi &= ~(0xffULL << (8 * (l - 9)));
+                }
             }
         }
-    }
-    d2_out[i] = best;
-    idx_out[i] = (int) best_i;
+        d2_out[i] = best;
+        idx_out[i] = (int) best_i;
     }  // grid-stride loop over queries
 }
 
@@ -277,6 +295,7 @@ k_nn_partial(const double *__restrict__ d2s, long long q_begin, long long q_end,
     for (long long i = q_begin + (long long) blockIdx.x * blockDim.x + threadIdx.x; i < q_end;
          i += (long long) gridDim.x * blockDim.x) {
         const double d2 = d2s[i];
+        if (d2 < 0.0) continue;     // slab mode: halo point, not a query of this rank
         const double d = sqrt(d2);  // (map_pt - gt_pt).norm(), map_eval.cpp:1095
         sd[10] += d;                // computeChamferDistance, ungated (map_eval.cpp:1416)
         if (gate_pass(sp, d2)) {
@@ -315,7 +334,7 @@ k_nn_sigma(const double *__restrict__ d2s, long long q_begin, long long q_end, S
     for (long long i = q_begin + (long long) blockIdx.x * blockDim.x + threadIdx.x; i < q_end;
          i += (long long) gridDim.x * blockDim.x) {
         const double d2 = d2s[i];
-        if (gate_pass(sp, d2)) {
+        if (d2 >= 0.0 && gate_pass(sp, d2)) {
             const double d = sqrt(d2);
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
@@ -376,34 +395,112 @@ static StatParams make_params(double gate, int gate_mode, const double trunc[5])
     return sp;
 }
 
+// ---- slab mode helpers -------------------------------------------------------------------------------------
+// the reference slab of this rank is empty: every owned query is unresolved with an infinite bound
+__global__ void k_nn_fill_empty(const SPoint *__restrict__ qsp, long long n, SlabView slab, double *__restrict__ d2_out,
+                                int *__restrict__ idx_out) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SPoint q = qsp[i];
+    d2_out[i] = slab_owned(slab, q.x, q.y, q.z) ? INFINITY : -1.0;
+    idx_out[i] = -1;
+}
+
+// owned queries whose best distance is not below their distance to the nearest outer face of (slab + halo): a closer
+// reference point may live on another rank
+__global__ void k_nn_collect_unresolved(const SPoint *__restrict__ qsp, long long n, SlabView slab,
+                                        const double *__restrict__ d2, unsigned int *__restrict__ list,
+                                        unsigned int *__restrict__ count) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    bool un = false;
+    if (i < n) {
+        const double d = d2[i];
+        if (d >= 0.0) {  // owned
+            const SPoint q = qsp[i];
+            const double f = slab_face_distance(slab, q.x, q.y, q.z);
+            un = !(d < f * f);
+        }
+    }
+    const unsigned long long um = __ballot(un);
+    if (um) {
+        const int lane = threadIdx.x & 63;
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(count, (unsigned int) __popcll(um));
+        base = (unsigned int) readlane_i((int) base, 0);
+        if (un) list[base + (unsigned int) __popcll(um & ((1ULL << lane) - 1ULL))] = (unsigned int) i;
+    }
+}
+
+__global__ void k_nn_export_xyz(const SPoint *__restrict__ qsp, const unsigned int *__restrict__ list, long long m,
+                                double *__restrict__ xyz) {
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const SPoint q = qsp[list[t]];
+    xyz[3 * t] = q.x;
+    xyz[3 * t + 1] = q.y;
+    xyz[3 * t + 2] = q.z;
+}
+
+__global__ void k_points_to_sp(const double *__restrict__ xyz, long long m, SPoint *__restrict__ sp) {
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    SPoint p;
+    p.x = xyz[3 * t];
+    p.y = xyz[3 * t + 1];
+    p.z = xyz[3 * t + 2];
+    p.idx = t;
+    sp[t] = p;
+}
+
+__global__ void k_fill_f64(double *p, long long n, double v) {
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = v;
+}
+
+__global__ void k_nn_patch(const unsigned int *__restrict__ list, long long m, const double *__restrict__ d2_new,
+                           double *__restrict__ d2) {
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const unsigned int i = list[t];
+    d2[i] = fmin(d2[i], d2_new[t]);
+}
+
 int nn_search(me_ctx *ctx, int qslot, int rslot) {
     if (qslot < 0 || qslot > 1 || rslot < 0 || rslot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
     Cloud &q = ctx->cloud[qslot];
     Cloud &r = ctx->cloud[rslot];
-    if (!q.index_valid || !r.index_valid) return ctx->fail(ME_ERR_STATE, "me_nn1: upload both clouds first");
+    const bool slab = q.slab.axis >= 0;
+    if (!q.uploaded || !r.uploaded || (!slab && (!q.index_valid || !r.index_valid)))
+        return ctx->fail(ME_ERR_STATE, "me_nn1: upload both clouds first");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
+    q.nn_ref_slot = rslot;
+    q.n_unres = 0;
+    if (q.n == 0) return ME_OK;  // empty slab: nothing to query
     ME_CHECK(ctx, q.nn_d2.ensure((size_t) q.n * 8));
     ME_CHECK(ctx, q.nn_idx.ensure((size_t) q.n * 4));
+    ME_CHECK(ctx, ctx->red.ensure(64));
+    unsigned int *d_cnt = ctx->red.as<unsigned int>();
     long long b, e;
     ctx->shard_range(q.n, b, e);
-    if (e > b) {
+    if (r.n == 0) {
+        hipLaunchKernelGGL(k_nn_fill_empty, dim3((unsigned int) ((q.n + 255) / 256)), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(),
+                           q.n, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>());
+    } else if (e > b) {
         const unsigned int nb = (unsigned int) (((e - b + 255) / 256 + 7) / 8 * 8);  // multiple of 8 (XCD chunking)
         ME_CHECK(ctx, q.nn_list.ensure((size_t) (e - b) * 4 + 64));
-        ME_CHECK(ctx, ctx->red.ensure(64));
-        unsigned int *d_cnt = ctx->red.as<unsigned int>();
         ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
         FrameView fr{r.origin[0], r.origin[1], r.origin[2], r.fine_h};
         {
             TimerScope ts(ctx, "nn_grid");
             hipLaunchKernelGGL(k_nn_grid, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
-                               r.nn_grid, fr, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
+                               r.nn_grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
         }
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)
             const unsigned int nbf = (unsigned int) std::min<long long>(nb, 256 * 16);
             TimerScope ts(ctx, "nn1");
             hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
-                               r.bvh, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
+                               r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
         }
         if (ctx->timers_on) {  // fallback share, for the bench report
             unsigned int h = 0;
@@ -413,8 +510,67 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
             ctx->nn_queries += e - b;
         }
     }
+    if (slab) {  // which owned queries might have a closer neighbour on another rank?
+        ME_CHECK(ctx, q.nn_unres.ensure((size_t) q.n * 4 + 64));
+        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_nn_collect_unresolved, dim3((unsigned int) ((q.n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           q.sp.as<SPoint>(), q.n, q.slab, q.nn_d2.as<double>(), q.nn_unres.as<unsigned int>(), d_cnt);
+        unsigned int h = 0;
+        ME_CHECK(ctx, hipMemcpyAsync(&h, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        q.n_unres = h;
+    }
     ME_CHECK(ctx, hipGetLastError());
-    q.nn_ref_slot = rslot;
+    return ME_OK;
+}
+
+int nn_unresolved(me_ctx *ctx, int qslot, double *xyz_device, long long capacity, long long *count) {
+    if (qslot < 0 || qslot > 1 || !count) return ctx->fail(ME_ERR_ARG, "me_nn_unresolved: bad argument");
+    Cloud &q = ctx->cloud[qslot];
+    if (q.nn_ref_slot < 0) return ctx->fail(ME_ERR_STATE, "no NN result for this slot (call me_nn1 first)");
+    *count = q.n_unres;
+    if (!xyz_device || q.n_unres == 0) return ME_OK;
+    if (capacity < q.n_unres) return ctx->fail(ME_ERR_CAPACITY, "me_nn_unresolved: capacity too small");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_nn_export_xyz, dim3((unsigned int) ((q.n_unres + 255) / 256)), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(),
+                       q.nn_unres.as<unsigned int>(), q.n_unres, xyz_device);
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
+int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, double *d2_device) {
+    if (rslot < 0 || rslot > 1 || m < 0 || (m > 0 && (!xyz_device || !d2_device))) return ctx->fail(ME_ERR_ARG, "me_nn_points: bad argument");
+    Cloud &r = ctx->cloud[rslot];
+    if (!r.uploaded) return ctx->fail(ME_ERR_STATE, "me_nn_points: reference cloud not uploaded");
+    if (m == 0) return ME_OK;
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    const unsigned int nb = (unsigned int) ((m + 255) / 256);
+    if (r.n == 0) {
+        hipLaunchKernelGGL(k_fill_f64, dim3(nb), dim3(256), 0, ctx->stream, d2_device, m, (double) INFINITY);
+    } else {
+        DevBuf &qs = ctx->tmp[0], &qi = ctx->tmp[1];
+        ME_CHECK(ctx, qs.ensure((size_t) m * sizeof(SPoint)));
+        ME_CHECK(ctx, qi.ensure((size_t) m * 4));
+        hipLaunchKernelGGL(k_points_to_sp, dim3(nb), dim3(256), 0, ctx->stream, xyz_device, m, qs.as<SPoint>());
+        TimerScope ts(ctx, "nn1");
+        hipLaunchKernelGGL(k_nn1, dim3(std::min<unsigned int>(nb, 256 * 16)), dim3(256), 0, ctx->stream, qs.as<SPoint>(), 0LL, m,
+                           r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
+                           (const unsigned int *) nullptr);
+    }
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_CHECK(ctx, hipGetLastError());
+    return ME_OK;
+}
+
+int nn_patch(me_ctx *ctx, int qslot, const double *d2_device, long long count) {
+    if (qslot < 0 || qslot > 1 || (count > 0 && !d2_device)) return ctx->fail(ME_ERR_ARG, "me_nn_patch: bad argument");
+    Cloud &q = ctx->cloud[qslot];
+    if (count != q.n_unres) return ctx->fail(ME_ERR_ARG, "me_nn_patch: count differs from me_nn_unresolved");
+    if (count == 0) return ME_OK;
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_nn_patch, dim3((unsigned int) ((count + 255) / 256)), dim3(256), 0, ctx->stream,
+                       q.nn_unres.as<unsigned int>(), count, d2_device, q.nn_d2.as<double>());
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ME_OK;
 }
 

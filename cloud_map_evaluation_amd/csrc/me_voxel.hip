@@ -28,10 +28,17 @@ __device__ __host__ __forceinline__ void unpack_key(unsigned long long k, int &k
     kz = (int) (k & 0x1fffff) - kKeyBias;
 }
 
-__global__ void k_voxel_keys(const double *__restrict__ xyz, long long n, double vs, unsigned long long *__restrict__ keys,
-                             unsigned int *__restrict__ iota, int *__restrict__ err) {
+constexpr unsigned long long kVoxSentinel = 0x7fffffffffffffffULL;  // sorts after every real key
+
+__global__ void k_voxel_keys(const double *__restrict__ xyz, long long n, double vs, SlabView slab,
+                             unsigned long long *__restrict__ keys, unsigned int *__restrict__ iota, int *__restrict__ err) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (!slab_owned(slab, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])) {  // slab mode: halo points belong to another rank
+        keys[i] = kVoxSentinel;
+        iota[i] = (unsigned int) i;
+        return;
+    }
     // getVoxelIndex (voxel_calculator.cpp:241-245): floor(x / voxel_size) — IEEE division, not a reciprocal multiply
     const double fx = floor(xyz[3 * i] / vs), fy = floor(xyz[3 * i + 1] / vs), fz = floor(xyz[3 * i + 2] / vs);
     const double lim = (double) (kKeyBias - 16);
@@ -75,7 +82,7 @@ __device__ __forceinline__ double det3_rowmajor(const double *m) {
 // one wavefront per voxel
 __global__ void __launch_bounds__(256)
 k_voxel_gauss(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, const unsigned int *__restrict__ seg_start,
-              long long n_vox, int *__restrict__ vn, double *__restrict__ vmu, double *__restrict__ vsig,
+              long long n_vox, int raw, int *__restrict__ vn, double *__restrict__ vmu, double *__restrict__ vsig,
               double *__restrict__ vent) {
     const int lane = threadIdx.x & 63;
     const long long v = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -106,7 +113,7 @@ k_voxel_gauss(const double *__restrict__ xyz, const unsigned int *__restrict__ p
     if (lane == 0) {
         double S[9] = {cxx, cxy, cxz, cxy, cyy, cyz, cxz, cyz, czz};  // M2 = sum (p-mu)(p-mu)^T (Welford's S, :41)
         double ent = 0.0;
-        if (cnt > 10) {  // (:47)
+        if (cnt > 10 && !raw) {  // (:47); raw = keep M2 undivided (multi-GPU partials)
             const double nm1 = (double) (cnt - 1);
 #pragma unroll
             for (int k = 0; k < 9; ++k) S[k] = S[k] / nm1;  // first division (:48)
@@ -495,12 +502,20 @@ int scs_table(me_ctx *ctx, const int32_t *keys, const double *w, long long n, in
 }
 
 // ------------------------------------------------------------------------------------------------------------
-int voxel_build(me_ctx *ctx, int slot, double voxel_size) {
+int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
     if (slot < 0 || slot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
     if (!(voxel_size > 0)) return ctx->fail(ME_ERR_ARG, "voxel_size must be > 0");
     Cloud &c = ctx->cloud[slot];
     if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "voxel pass: cloud not uploaded");
-    if (c.n_vox > 0 && c.vox_size == voxel_size) return ME_OK;  // cached
+    if (c.vox_valid && c.vox_size == voxel_size && c.vox_raw == raw) return ME_OK;  // cached
+    c.vox_valid = false;
+    if (c.n == 0) {  // empty slab
+        c.n_vox = 0;
+        c.vox_size = voxel_size;
+        c.vox_raw = raw;
+        c.vox_valid = true;
+        return ME_OK;
+    }
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     const long long n = c.n;
     DevBuf &keys_in = ctx->tmp[0], &iota = ctx->tmp[1], &keys = ctx->tmp[2], &perm = ctx->tmp[3], &flags = ctx->tmp[4];
@@ -513,7 +528,7 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size) {
     ME_CHECK(ctx, hipMemsetAsync(d_err, 0, 4, ctx->stream));
     {
         TimerScope ts(ctx, "voxel_keys");
-        hipLaunchKernelGGL(k_voxel_keys, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, voxel_size,
+        hipLaunchKernelGGL(k_voxel_keys, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, voxel_size, c.slab,
                            keys_in.as<unsigned long long>(), iota.as<unsigned int>(), d_err);
     }
     // radix sort is stable: cloud order is preserved inside every voxel
@@ -532,10 +547,15 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size) {
     ME_CHECK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (h_err) return ctx->fail(ME_ERR_ARG, "voxel index out of range (|floor(p/voxel_size)| must be < 2^20)");
-    const long long V = (long long) last_pos + last_flag;
+    long long V = (long long) last_pos + last_flag;
+    if (c.slab.axis >= 0) {  // the halo points were keyed with the sentinel: their segment (the last one) is dropped
+        unsigned long long last_key = 0;
+        ME_CHECK(ctx, hipMemcpy(&last_key, keys.as<unsigned long long>() + (n - 1), 8, hipMemcpyDeviceToHost));
+        if (last_key == kVoxSentinel) V -= 1;
+    }
     DevBuf &seg_start = ctx->tmp[0];
     ME_CHECK(ctx, seg_start.ensure((size_t) (V + 1) * 4));
-    ME_CHECK(ctx, c.vox_key.ensure((size_t) V * 8));
+    ME_CHECK(ctx, c.vox_key.ensure((size_t) (V + 1) * 8));
     ME_CHECK(ctx, c.vox_n.ensure((size_t) V * 4));
     ME_CHECK(ctx, c.vox_mu.ensure((size_t) V * 24));
     ME_CHECK(ctx, c.vox_sigma.ensure((size_t) V * 72));
@@ -543,17 +563,23 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size) {
     hipLaunchKernelGGL(k_seg_scatter, dim3(grid_for(n)), dim3(256), 0, ctx->stream, keys.as<unsigned long long>(),
                        flags.as<unsigned int>(), pos.as<unsigned int>(), n, c.vox_key.as<unsigned long long>(),
                        seg_start.as<unsigned int>());
-    hipLaunchKernelGGL(k_set_u32v, dim3(1), dim3(1), 0, ctx->stream, seg_start.as<unsigned int>(), V, (unsigned int) n);
+    if (c.slab.axis < 0)  // (in slab mode entry V is the start of the dropped sentinel segment or, if none, set here)
+        hipLaunchKernelGGL(k_set_u32v, dim3(1), dim3(1), 0, ctx->stream, seg_start.as<unsigned int>(), V, (unsigned int) n);
+    else if (V == (long long) last_pos + last_flag)
+        hipLaunchKernelGGL(k_set_u32v, dim3(1), dim3(1), 0, ctx->stream, seg_start.as<unsigned int>(), V, (unsigned int) n);
     {
         TimerScope ts(ctx, "voxel");
-        hipLaunchKernelGGL(k_voxel_gauss, dim3((unsigned int) ((V + 3) / 4)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
-                           perm.as<unsigned int>(), seg_start.as<unsigned int>(), V, c.vox_n.as<int>(), c.vox_mu.as<double>(),
+        if (V > 0)
+            hipLaunchKernelGGL(k_voxel_gauss, dim3((unsigned int) ((V + 3) / 4)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
+                           perm.as<unsigned int>(), seg_start.as<unsigned int>(), V, raw ? 1 : 0, c.vox_n.as<int>(), c.vox_mu.as<double>(),
                            c.vox_sigma.as<double>(), c.vox_entropy.as<double>());
     }
     ME_CHECK(ctx, hipGetLastError());
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     c.n_vox = V;
     c.vox_size = voxel_size;
+    c.vox_raw = raw;
+    c.vox_valid = true;
     return ME_OK;
 }
 
@@ -583,8 +609,10 @@ int voxel_export(me_ctx *ctx, int slot, int32_t *keys, int32_t *npts, double *mu
 int awd_scs(me_ctx *ctx, double voxel_size, int min_pts, int scs_radius, double *rows, double *w_sorted, int64_t *n_rows,
             double *awd, double *scs, int64_t counts[3]) {
     if (scs_radius < 1 || scs_radius > 10) return ctx->fail(ME_ERR_ARG, "scs_radius must be in [1, 10]");
-    ME_TRY(voxel_build(ctx, ME_SLOT_GT, voxel_size));
-    ME_TRY(voxel_build(ctx, ME_SLOT_EST, voxel_size));
+    if (ctx->cloud[0].slab.axis >= 0 || ctx->cloud[1].slab.axis >= 0)
+        return ctx->fail(ME_ERR_STATE, "me_awd_scs: in slab mode merge me_voxel_partials across ranks, then use me_w2_batch / me_scs_table");
+    ME_TRY(voxel_build(ctx, ME_SLOT_GT, voxel_size, false));
+    ME_TRY(voxel_build(ctx, ME_SLOT_EST, voxel_size, false));
     Cloud &E = ctx->cloud[ME_SLOT_EST], &G = ctx->cloud[ME_SLOT_GT];
     const long long Ve = E.n_vox, Vg = G.n_vox;
     DevBuf &gi = ctx->tmp[0], &match = ctx->tmp[1], &active = ctx->tmp[2], &mpos = ctx->tmp[3];

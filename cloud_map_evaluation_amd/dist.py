@@ -63,6 +63,187 @@ def direction_stats(vec: np.ndarray, i: int, sigma_num: np.ndarray, n_src: int) 
     )
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Spatial slab mode (north-star variant): every rank indexes only its slab (+ halo) of both clouds.
+# ---------------------------------------------------------------------------------------------------------------
+def _all_reduce(t, dist, comm_device, op=None):
+    """all_reduce of a torch tensor living anywhere, through `comm_device` (cuda for nccl/RCCL, cpu for gloo)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    src_device = t.device
+    c = t.to(comm_device).contiguous()
+    dist.all_reduce(c, op=op if op is not None else dist.ReduceOp.SUM)
+    return c.to(src_device)
+
+
+def _all_gather_rows(t, rows_max: int, dist, comm_device, pad_value: float):
+    """all_gather of a (rows, k) tensor padded to rows_max rows -> (world * rows_max, k) on t.device."""
+    import torch
+
+    world = dist.get_world_size()
+    k = t.shape[1]
+    buf = torch.full((rows_max, k), pad_value, dtype=t.dtype, device=comm_device)
+    if t.shape[0]:
+        buf[:t.shape[0]] = t.to(comm_device)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    return torch.cat(parts, 0).to(t.device)
+
+
+def slab_bounds(gt, rank: int, world: int, bins: int = 8192):
+    """Equal-count slabs along the longest axis of the GT cloud (identical on every rank: same data, same code).
+    Returns (axis, lo, hi) with -inf / +inf on the outermost faces."""
+    import torch
+
+    t = gt if isinstance(gt, torch.Tensor) else torch.from_numpy(np.asarray(gt))
+    # a deterministic ~1 M-point subsample is plenty to balance the slabs (the outer faces are +-inf anyway) and keeps
+    # this step at well under a millisecond on 50 M points
+    t = t[::max(1, t.shape[0] // 1_000_000)]
+    mn, mx = t.min(0).values, t.max(0).values
+    axis = int(torch.argmax(mx - mn).item())
+    a, b = float(mn[axis]), float(mx[axis])
+    if not b > a:
+        return axis, -np.inf, np.inf
+    h = torch.histc(t[:, axis].to(torch.float64), bins=bins, min=a, max=b)
+    cum = torch.cumsum(h, 0)
+    total = float(cum[-1])
+    edges = []
+    for k in range(1, world):
+        idx = int(torch.searchsorted(cum, torch.tensor([total * k / world], dtype=cum.dtype, device=cum.device)).item())
+        edges.append(a + (b - a) * min(idx + 1, bins) / bins)
+    cuts = [-np.inf] + edges + [np.inf]
+    return axis, cuts[rank], cuts[rank + 1]
+
+
+def merge_voxel_partials(rows: np.ndarray):
+    """rows (m, 16) = [kx, ky, kz, n, mu(3), M2(9)] partials from all ranks (n == 0 rows are padding) -> per-voxel
+    (keys[V,3] int32 ascending, n[V] int64, mu[V,3], sigma_stored[V,3,3]) exactly as VoxelCalculator::buildVoxelMap
+    leaves them (voxel_calculator.cpp:21-56): M2/(n-1)^2 for n > 10, raw M2 otherwise.  Chan's parallel update."""
+    rows = rows[rows[:, 3] > 0]
+    if len(rows) == 0:
+        return np.zeros((0, 3), np.int32), np.zeros(0, np.int64), np.zeros((0, 3)), np.zeros((0, 3, 3))
+    k3 = np.rint(rows[:, :3]).astype(np.int64)
+    bias = 1 << 20
+    packed = ((k3[:, 0] + bias) << 42) | ((k3[:, 1] + bias) << 21) | (k3[:, 2] + bias)
+    uniq, inv = np.unique(packed, return_inverse=True)
+    inv = inv.ravel()
+    V = len(uniq)
+    n_i = rows[:, 3]
+    n = np.zeros(V)
+    np.add.at(n, inv, n_i)
+    mu = np.zeros((V, 3))
+    np.add.at(mu, inv, n_i[:, None] * rows[:, 4:7])
+    mu /= n[:, None]
+    d = rows[:, 4:7] - mu[inv]
+    m2 = np.zeros((V, 9))
+    np.add.at(m2, inv, rows[:, 7:16] + n_i[:, None] * (d[:, :, None] * d[:, None, :]).reshape(-1, 9))
+    sig = m2.copy()
+    big = n > 10
+    nm1 = (n[big] - 1.0)[:, None]
+    sig[big] = sig[big] / nm1 / nm1  # the reference's two successive divisions (voxel_calculator.cpp:48, :102)
+    keys = np.stack([(uniq >> 42) - bias, ((uniq >> 21) & 0x1FFFFF) - bias, (uniq & 0x1FFFFF) - bias], 1).astype(np.int32)
+    return keys, n.astype(np.int64), mu, sig.reshape(V, 3, 3)
+
+
+def awd_scs_from_tables(eng, est_tab, gt_tab, min_pts: int = 100, scs_radius: int = 5):
+    """calculateVMD's join + W + AWD + SCS (map_eval.cpp:262-389) on merged voxel tables; W and SCS run on the device."""
+    ek, en, emu, esig = est_tab
+    gk, gn, gmu, gsig = gt_tab
+    bias = 1 << 20
+    pack = lambda k: ((k[:, 0].astype(np.int64) + bias) << 42) | ((k[:, 1].astype(np.int64) + bias) << 21) | (k[:, 2].astype(np.int64) + bias)
+    pe, pg = pack(ek), pack(gk)
+    common, ie, ig = np.intersect1d(pe, pg, assume_unique=True, return_indices=True)
+    keep = (en[ie] >= min_pts) & (gn[ig] >= min_pts)  # (map_eval.cpp:280)
+    ie, ig = ie[keep], ig[keep]
+    if len(ie) == 0:
+        return dict(awd=float("nan"), scs=float("nan"), n_rows=0)
+    # computeWassersteinDistanceGaussian(gt_voxel, est_voxel) (map_eval.cpp:284)
+    w = eng.w2_batch(gmu[ig], gsig[ig].reshape(-1, 9), gn[ig], emu[ie], esig[ie].reshape(-1, 9), en[ie])
+    return dict(awd=float(np.mean(w)), scs=float(eng.scs_table(ek[ie], w, scs_radius)), n_rows=int(len(ie)))
+
+
+def suite_step_slab(eng, dist, comm_device, est, gt, P, rank: int, world: int, evaluate_gt_mme: bool = True, halo: float = 1.0):
+    """Full suite with SPATIAL slabs: every rank sorts / indexes only ~1/world of each cloud (+ halo).
+
+    Collectives per suite: 2 x (all-reduce MAX of a count [+ all-gather of unresolved queries + all-reduce MIN]),
+    all-reduce SUM of the 38 partials, all-reduce SUM of the 10 sigma numerators, all-reduce MAX of two table sizes and
+    two all-gathers of voxel partial tables.
+    """
+    import torch
+
+    n_e, n_g = int(est.shape[0]), int(gt.shape[0])
+    axis, lo, hi = slab_bounds(gt, rank, world)
+    halo = max(float(halo), 1.0001 * float(P.nn_radius_))
+    eng.set_slab(axis, lo, hi, halo)
+    eng.upload(ME_SLOT_EST, est, T=np.asarray(P.initial_matrix_, dtype=np.float64), cell_size=P.nn_radius_)
+    eng.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
+    # --- MME: exact with halo >= radius ---
+    if P.evaluate_mme_:
+        m = eng.mme(ME_SLOT_EST, P.nn_radius_, 10, per_point=False)
+        m_e = (m[4], m[3])
+        m_g = (0.0, 0)
+        if evaluate_gt_mme:
+            m = eng.mme(ME_SLOT_GT, P.nn_radius_, 5, per_point=False)
+            m_g = (m[4], m[3])
+    else:
+        m_e = m_g = (0.0, 0)
+    # --- 1-NN: local search, then the cross-rank step for queries whose ball crosses the slab's outer faces ---
+    parts = []
+    n_cross = 0
+    for q, r in ((ME_SLOT_EST, ME_SLOT_GT), (ME_SLOT_GT, ME_SLOT_EST)):
+        eng.nn1(q, r, fetch=False)
+        cnt = eng.nn_unresolved_count(q)
+        if dist is not None and world > 1:
+            # everybody learns everybody's count (one tiny all-reduce of a one-hot vector)
+            onehot = torch.zeros(world, dtype=torch.int64)
+            onehot[rank] = cnt
+            counts = _all_reduce(onehot, dist, comm_device).tolist()
+            cmax = max(counts)
+            if cmax > 0:
+                mine = eng.nn_unresolved(q)
+                allq = _all_gather_rows(mine, cmax, dist, comm_device, pad_value=0.0)  # (world*cmax, 3)
+                valid = torch.cat([torch.arange(k * cmax, k * cmax + c) for k, c in enumerate(counts)]).to(allq.device)
+                d2_valid = eng.nn_points(r, allq[valid])  # every rank answers every open query against its own part
+                d2 = torch.full((world * cmax,), float("inf"), dtype=torch.float64, device=d2_valid.device)
+                d2[valid] = d2_valid
+                d2 = _all_reduce(d2, dist, comm_device, dist.ReduceOp.MIN)  # global nearest distance
+                eng.nn_patch(q, d2[rank * cmax: rank * cmax + cnt])
+        n_cross += cnt
+        parts.append(eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_))
+    vec = pack_partials(parts, m_e, m_g)
+    vec = np.concatenate([vec, [float(n_cross)]])
+    vec = all_reduce_sum(vec, dist, comm_device)
+    sig_local = []
+    for i, q in enumerate((ME_SLOT_EST, ME_SLOT_GT)):
+        C = vec[i * _DIR]
+        mean = vec[i * _DIR + 6:i * _DIR + 11] / C if C > 0 else np.zeros(5)
+        sig_local.append(eng.nn_sigma_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, mean))
+    sig = all_reduce_sum(np.concatenate(sig_local), dist, comm_device)
+    s_eg = direction_stats(vec, 0, sig[:5], n_e)
+    s_ge = direction_stats(vec, 1, sig[5:], n_g)
+    o = 2 * _DIR
+    mme_est = vec[o] / vec[o + 1] if vec[o + 1] > 0 else 0.0
+    mme_gt = vec[o + 2] / vec[o + 3] if vec[o + 3] > 0 else 0.0
+    # --- voxel Gaussians: per-rank partials of the owned points, merged (Chan) after one all-gather per cloud ---
+    tabs = []
+    local = []
+    for slot in (ME_SLOT_EST, ME_SLOT_GT):
+        k, n, mu, m2 = eng.voxel_partials(slot, P.vmd_voxel_size_)
+        rows = np.concatenate([k.astype(np.float64), n[:, None].astype(np.float64), mu, m2.reshape(-1, 9)], 1) if len(n) else np.zeros((0, 16))
+        local.append(rows)
+    if dist is not None and world > 1:
+        vmax = _all_reduce(torch.tensor([len(local[0]), len(local[1])], dtype=torch.int64), dist, comm_device, dist.ReduceOp.MAX)
+        for rows, m in zip(local, vmax.tolist()):
+            g = _all_gather_rows(torch.from_numpy(rows), max(int(m), 1), dist, comm_device, pad_value=0.0)
+            tabs.append(merge_voxel_partials(g.numpy()))
+    else:
+        tabs = [merge_voxel_partials(rows) for rows in local]
+    v = awd_scs_from_tables(eng, tabs[0], tabs[1])
+    return dict(est_gt=s_eg, gt_est=s_ge, ac=s_eg["rmse"], com=s_eg["fitness"], cd=s_eg["mean_nn"] + s_ge["mean_nn"],
+                mme_est=mme_est, mme_gt=mme_gt, mme_valid=int(vec[o + 1]), awd=v["awd"], scs=v["scs"], n_w=v["n_rows"],
+                n_est=n_e, n_gt=n_g, n_cross_rank_queries=int(vec[o + 4]), slab=(axis, lo, hi, halo))
+
+
 def suite_step(eng, dist, device, est, gt, P, evaluate_gt_mme: bool = True, upload: bool = True):
     """One full pass of the hot path (what MapEval::process runs between load and save, map_eval.cpp:52-85).
 

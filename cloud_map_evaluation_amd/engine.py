@@ -243,6 +243,59 @@ class Engine:
         self._ck(self._L.me_scs_table(self._ctx, _addr(keys), _addr(w), w.shape[0], radius, C.byref(out)))
         return out.value
 
+    # ---- multi-GPU spatial slab mode (include/mapeval_hip.h: me_set_slab ...) ----
+    def set_slab(self, axis: int, lo: float = 0.0, hi: float = 0.0, halo: float = 0.0):
+        """Keep lo-halo <= p[axis] < hi+halo at the next uploads; lo <= p[axis] < hi are the points this rank owns."""
+        self._ck(self._L.me_set_slab(self._ctx, int(axis), float(lo), float(hi), float(halo)))
+
+    def nn_unresolved_count(self, query_slot: int) -> int:
+        n = C.c_int64(0)
+        self._ck(self._L.me_nn_unresolved(self._ctx, query_slot, 0, 0, C.byref(n)))
+        return n.value
+
+    def nn_unresolved(self, query_slot: int):
+        """(count, 3) float64 cuda tensor: owned queries whose 1-NN may live on another rank."""
+        import torch
+
+        cnt = self.nn_unresolved_count(query_slot)
+        out = torch.empty((cnt, 3), dtype=torch.float64, device=torch.device("cuda", self.device))
+        if cnt:
+            n = C.c_int64(0)
+            self._ck(self._L.me_nn_unresolved(self._ctx, query_slot, out.data_ptr(), cnt, C.byref(n)))
+        return out
+
+    def nn_points(self, ref_slot: int, xyz):
+        """Exact squared distance of arbitrary points (cuda tensor (m,3) float64) to this rank's part of ref_slot."""
+        import torch
+
+        xyz = xyz.to(torch.device("cuda", self.device), torch.float64).contiguous()
+        torch.cuda.current_stream(xyz.device).synchronize()
+        d2 = torch.empty(xyz.shape[0], dtype=torch.float64, device=xyz.device)
+        self._ck(self._L.me_nn_points(self._ctx, ref_slot, xyz.data_ptr(), int(xyz.shape[0]), d2.data_ptr()))
+        return d2
+
+    def nn_patch(self, query_slot: int, d2):
+        import torch
+
+        d2 = d2.to(torch.device("cuda", self.device), torch.float64).contiguous()
+        torch.cuda.current_stream(d2.device).synchronize()
+        self._ck(self._L.me_nn_patch(self._ctx, query_slot, d2.data_ptr(), int(d2.shape[0])))
+
+    def voxel_partials(self, slot: int, voxel_size: float):
+        """Owned-point voxel partials: keys[V,3] int32, n[V] int32, mu[V,3], raw M2[V,3,3]."""
+        nv = C.c_int64(0)
+        self._ck(self._L.me_voxel_partials(self._ctx, slot, float(voxel_size), 0, 0, 0, 0, C.byref(nv)))
+        v = nv.value
+        keys = np.empty((v, 3), np.int32)
+        n = np.empty(v, np.int32)
+        mu = np.empty((v, 3), np.float64)
+        m2 = np.empty((v, 9), np.float64)
+        if v:
+            nv = C.c_int64(v)
+            self._ck(self._L.me_voxel_partials(self._ctx, slot, float(voxel_size), _addr(keys), _addr(n), _addr(mu), _addr(m2),
+                                               C.byref(nv)))
+        return keys, n, mu, m2.reshape(v, 3, 3)
+
     # ---- whole suite ----
     def run_suite(self, p: Param, gate_mode: int = ME_GATE_LE_UNSQUARED) -> _lib.SuiteOut:
         sp = _lib.SuiteParams()

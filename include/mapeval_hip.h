@@ -79,6 +79,32 @@ int me_version(void);
  * the caller to all-reduce (RCCL).  Default (0,1) = whole job. */
 int me_set_shard(me_ctx *ctx, int rank, int world);
 
+/* Multi-GPU SPATIAL slab (no reference counterpart).  After this call me_upload_cloud* keeps only the points with
+ * lo - halo <= p[axis] < hi + halo (after the transform); points with lo <= p[axis] < hi are OWNED by this context —
+ * they are the queries of every per-point pass and the only contributors to the voxel partials — the rest are halo,
+ * visible as reference points / neighbours only.  Every rank therefore sorts and indexes ~1/world of each cloud.
+ * MME is exact when halo >= nn_radius.  1-NN is exact for every query whose best distance is below its distance to
+ * the slab's outer faces; the others are returned by me_nn_unresolved for the cross-rank step (me_nn_points on every
+ * rank, min-reduce, me_nn_patch).  Per-point outputs (idx/d2/entropies arrays) are not available in slab mode.
+ * axis < 0 switches slab mode off.  Must be called before the uploads it applies to. */
+int me_set_slab(me_ctx *ctx, int axis, double lo, double hi, double halo);
+
+/* Slab mode, 1-NN cross-rank step.  me_nn_unresolved: the owned queries of the last me_nn1(query_slot, ..) whose
+ * result is not yet provably global; xyz_device (capacity x 3, device memory) receives their coordinates, *count
+ * their number (ME_ERR_CAPACITY if it exceeds capacity; xyz_device may be NULL to query the count). */
+int me_nn_unresolved(me_ctx *ctx, int query_slot, double *xyz_device, int64_t capacity, int64_t *count);
+/* Exact squared distance from each of m arbitrary points (device, m x 3) to the nearest point this context holds of
+ * ref_slot (owned + halo) -> d2_device[m]. */
+int me_nn_points(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_device);
+/* Overwrites the squared distances of the unresolved queries (same order as me_nn_unresolved returned them) with the
+ * globally min-reduced values d2_device[count]. */
+int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t count);
+
+/* Slab mode, voxel partials: Gaussians of the OWNED points only, RAW second moments (M2 = sum (p-mu)(p-mu)^T, no
+ * division), ascending key order; partials of the same voxel from different ranks merge with Chan's formula. */
+int me_voxel_partials(me_ctx *ctx, int slot, double voxel_size, int32_t *keys /*V x 3*/, int32_t *npts /*V*/,
+                      double *mu /*V x 3*/, double *m2 /*V x 9*/, int64_t *n_voxels);
+
 /* ---- clouds ------------------------------------------------------------------------------------------------ */
 /* Replaces: *map_3d_ = map_3d_->Transform(initial_matrix) (map_eval.cpp:1206) + every KDTreeFlann::SetGeometry
  * (map_eval.cpp:1214,1227,1401-1402,1449,1551,1619): uploads the cloud, applies T (row-major 4x4, NULL = none;

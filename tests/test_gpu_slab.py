@@ -1,0 +1,146 @@
+"""Spatial slab mode (multi-GPU design) exercised on ONE GPU.
+
+1. slab primitives, ranks emulated one after another: MME partials, voxel partials (Chan merge) and the local 1-NN +
+   cross-rank resolve add up to / reproduce the single-context result exactly (counts) or to 1e-12 (sums);
+2. the real driver (cloud_map_evaluation_amd.dist.suite_step_slab) with TWO processes sharing this GPU and gloo
+   collectives on the CPU — the same code path the 8-GPU run takes with RCCL — against the CPU oracle.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TRUNC = (0.2, 0.1, 0.08, 0.05, 0.01)
+
+
+def _scene(n=120_000):
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.campus_pair(n, density=2500.0, seed=5, origin=(100.0, -50.0, 3.0))
+    return est.numpy(), gt.numpy()
+
+
+def test_slab_primitives_sum_to_whole():
+    import torch
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, gt = _scene()
+    # a few far-away est points: their nearest GT point lies in another slab -> cross-rank step
+    est = np.concatenate([est, est[:200] + np.array([3.0, 0.0, 25.0])])
+    world = 4
+    with Engine(0) as eng:
+        eng.upload(0, est, cell_size=0.1)
+        eng.upload(1, gt, cell_size=0.1)
+        whole_mme = eng.mme(0, 0.1, 10)
+        _, d2_whole = eng.nn1(0, 1)
+        whole_tab = eng.voxel_gaussians(0, 1.0)
+        # --- emulate the ranks ---
+        mme_s, mme_c, sum_sqrt, n_q = 0.0, 0, 0.0, 0
+        rows_all = []
+        unresolved_total = 0
+        for rank in range(world):
+            axis, lo, hi = medist.slab_bounds(torch.from_numpy(gt), rank, world)
+            eng.set_slab(axis, lo, hi, 0.5)
+            eng.upload(0, est, cell_size=0.1)
+            eng.upload(1, gt, cell_size=0.1)
+            m = eng.mme(0, 0.1, 10, per_point=False)
+            mme_s += m[4]
+            mme_c += m[3]
+            eng.nn1(0, 1, fetch=False)
+            open_q = eng.nn_unresolved(0)
+            unresolved_total += len(open_q)
+            if len(open_q):
+                # "other ranks" answer: emulate with a slab-free context holding the whole GT cloud
+                with Engine(0) as full:
+                    full.upload(1, gt, cell_size=0.1)
+                    eng.nn_patch(0, full.nn_points(1, open_q))
+            p = eng.nn_partial_sums(0, -1.0, 0, TRUNC)
+            sum_sqrt += p.sum_sqrt_all
+            n_q += p.n_corr  # gate < 0: every owned query is a correspondence
+            k, n, mu, m2 = eng.voxel_partials(0, 1.0)
+            rows_all.append(np.concatenate([k.astype(float), n[:, None].astype(float), mu, m2.reshape(-1, 9)], 1))
+        eng.set_slab(-1)
+    assert n_q == len(est)                                    # every query owned by exactly one rank
+    assert unresolved_total >= 100                            # the lifted points needed the cross-rank step
+    assert mme_c == whole_mme[3]                              # bit-exact valid count across slabs
+    np.testing.assert_allclose(mme_s, whole_mme[4], rtol=1e-12)
+    np.testing.assert_allclose(sum_sqrt, np.sqrt(d2_whole).sum(), rtol=1e-12)
+    keys, n, mu, sig = medist.merge_voxel_partials(np.concatenate(rows_all))
+    wk, wn, wmu, wsig, _ = whole_tab
+    assert np.array_equal(keys, wk) and np.array_equal(n, wn)  # same voxels, same populations
+    np.testing.assert_allclose(mu, wmu, rtol=1e-13)
+    np.testing.assert_allclose(sig, wsig, rtol=1e-7, atol=1e-18)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, est, gt, T, q):
+    import torch
+    import torch.distributed as dist
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Engine, Param
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=1.0, initial_matrix_=T)
+        with Engine(0) as eng:
+            res = medist.suite_step_slab(eng, dist, torch.device("cpu"), est, gt, P, rank, world, halo=0.5)
+        q.put((rank, {k: (v if not isinstance(v, dict) else {kk: np.asarray(vv) for kk, vv in v.items()}) for k, v in res.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_process_slab_suite_matches_oracle():
+    import torch.multiprocessing as mp
+
+    import oracle
+
+    est, gt = _scene(100_000)
+    est = np.concatenate([est, est[:150] + np.array([2.0, 0.0, 30.0])])
+    T = np.eye(4)
+    T[:3, 3] = [0.003, -0.002, 0.001]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, est, gt, T, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    est_t = oracle.transform(est, T)
+    o_eg = oracle.reg_stats(est_t, gt, 1.0, 0, TRUNC)
+    o_ge = oracle.reg_stats(gt, est_t, 1.0, 0, TRUNC)
+    o_me = oracle.mme(est_t, 0.1, 10)
+    o_mg = oracle.mme(gt, 0.1, 5)
+    o_v = oracle.awd_scs(oracle.VoxelMap(gt, 1.0), oracle.VoxelMap(est_t, 1.0))
+    for rank in (0, 1):
+        r = results[rank]
+        assert r["n_cross_rank_queries"] >= 100
+        for got, exp in ((r["est_gt"], o_eg), (r["gt_est"], o_ge)):
+            assert got["n_corr"] == exp.n_corr
+            assert np.array_equal(got["number"], exp.number)          # bit-exact inlier counts
+            for k in ("mean", "rmse", "sigma"):
+                np.testing.assert_allclose(got[k], getattr(exp, k), rtol=1e-9)
+        np.testing.assert_allclose(r["cd"], oracle.chamfer(est_t, gt), rtol=1e-9)
+        assert r["mme_valid"] == o_me[3]
+        np.testing.assert_allclose(r["mme_est"], o_me[0], rtol=1e-9)
+        np.testing.assert_allclose(r["mme_gt"], o_mg[0], rtol=1e-9)
+        assert r["n_w"] == len(o_v["rows"])
+        np.testing.assert_allclose(r["awd"], o_v["awd"], rtol=1e-9)
+        np.testing.assert_allclose(r["scs"], o_v["scs"], rtol=1e-9)
