@@ -181,3 +181,213 @@ def test_single_process_path_needs_no_process_group():
     assert np.array_equal(r["est_gt"]["number"], o.number)
     np.testing.assert_allclose(r["ac"], o.rmse, rtol=1e-12)
     np.testing.assert_allclose(r["com"], o.fitness, rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# spatial slab mode (suite_step_slab): the same protocol the multi-GPU run uses, with a CPU stand-in engine
+# ---------------------------------------------------------------------------------------------------------------
+class OracleSlabEngine(OracleShardEngine):
+    """Stand-in for Engine in slab mode: holds only slab + halo of each cloud, owns the slab."""
+
+    def __init__(self):
+        super().__init__()
+        self.slab = None
+        self.owned = {}
+        self.unres = {}
+
+    def set_slab(self, axis, lo=0.0, hi=0.0, halo=0.0):
+        self.slab = None if axis < 0 else (axis, lo, hi, lo - halo, hi + halo)
+
+    def upload(self, slot, xyz, T=None, cell_size=0.0):
+        import oracle
+
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        if T is not None:
+            xyz = oracle.transform(xyz, T)
+        if self.slab is None:
+            self.cloud[slot], self.owned[slot] = xyz, np.ones(len(xyz), bool)
+            return
+        a, lo, hi, rlo, rhi = self.slab
+        v = xyz[:, a]
+        keep = (v >= rlo) & (v < rhi)
+        self.cloud[slot] = xyz[keep]
+        self.owned[slot] = (v[keep] >= lo) & (v[keep] < hi)
+
+    def mme(self, slot, radius, min_k, per_point=False):
+        import oracle
+
+        if len(self.cloud[slot]) == 0:
+            return 0.0, None, None, 0, 0.0
+        _, ent, val, _, _ = oracle.mme(self.cloud[slot], radius, min_k)
+        o = self.owned[slot]
+        return 0.0, None, None, int(val[o].sum()), float(ent[o].sum())
+
+    def nn1(self, q, r, fetch=False):
+        import oracle
+
+        nq = len(self.cloud[q])
+        d2 = oracle.nn1(self.cloud[r], self.cloud[q])[1] if len(self.cloud[r]) and nq else np.full(nq, np.inf)
+        self.d2[q] = d2
+        if self.slab is None:
+            self.unres[q] = np.zeros(0, np.int64)
+        else:
+            a, lo, hi, rlo, rhi = self.slab
+            v = self.cloud[q][:, a]
+            face = np.minimum(v - rlo, rhi - v)
+            self.unres[q] = np.nonzero(self.owned[q] & ~(d2 < face * face))[0]
+        return None, None
+
+    def nn_unresolved_count(self, q):
+        return len(self.unres[q])
+
+    def nn_unresolved(self, q):
+        import torch
+
+        return torch.from_numpy(self.cloud[q][self.unres[q]].copy())
+
+    def nn_points(self, r, xyz):
+        import oracle
+        import torch
+
+        pts = xyz.numpy()
+        if len(self.cloud[r]) == 0 or len(pts) == 0:
+            return torch.full((len(pts),), float("inf"), dtype=torch.float64)
+        return torch.from_numpy(oracle.nn1(self.cloud[r], pts)[1])
+
+    def nn_patch(self, q, d2):
+        self.d2[q][self.unres[q]] = np.minimum(self.d2[q][self.unres[q]], d2.numpy())
+
+    def _slab(self, n):  # statistics run over the owned points only
+        raise NotImplementedError
+
+    def nn_partial_sums(self, q, gate, mode, trunc):
+        d2 = self.d2[q][self.owned[q]]
+        keep = self._gate(d2, gate, mode)
+        d = np.sqrt(d2)
+        out = types.SimpleNamespace(n_query=len(d2), n_corr=int(keep.sum()), n_inl=[], sum_d=[], sum_d2=[],
+                                    sum_sqrt_all=float(d.sum()))
+        for t in trunc:
+            inl = keep & (d <= t)
+            out.n_inl.append(int(inl.sum()))
+            out.sum_d.append(float(d[inl].sum()))
+            out.sum_d2.append(float(d2[inl].sum()))
+        return out
+
+    def nn_sigma_sums(self, q, gate, mode, mean):
+        d2 = self.d2[q][self.owned[q]]
+        d = np.sqrt(d2[self._gate(d2, gate, mode)])
+        return np.array([((d - m) ** 2).sum() for m in mean])
+
+    def voxel_partials(self, slot, vs):
+        p = self.cloud[slot][self.owned[slot]]
+        if len(p) == 0:
+            return np.zeros((0, 3), np.int32), np.zeros(0, np.int32), np.zeros((0, 3)), np.zeros((0, 3, 3))
+        keys = np.floor(p / vs).astype(np.int32)
+        uk, inv = np.unique(keys, axis=0, return_inverse=True)
+        inv = inv.ravel()
+        n = np.bincount(inv, minlength=len(uk)).astype(np.int32)
+        mu = np.zeros((len(uk), 3))
+        np.add.at(mu, inv, p)
+        mu /= n[:, None]
+        c = p - mu[inv]
+        m2 = np.zeros((len(uk), 3, 3))
+        np.add.at(m2, inv, c[:, :, None] * c[:, None, :])
+        return uk, n, mu, m2
+
+    def w2_batch(self, mu1, s1, n1, mu2, s2, n2):
+        import oracle
+
+        return np.array([oracle.w2_gaussian(mu1[i], s1[i], int(n1[i]), mu2[i], s2[i], int(n2[i])) for i in range(len(n1))])
+
+    def scs_table(self, keys, w, radius=5):
+        import oracle
+
+        return oracle.scs(keys, w, radius)
+
+
+def _slab_worker(rank, world, port, est, gt, T, q):
+    import torch
+    import torch.distributed as dist
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Param
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=0.5, initial_matrix_=T)
+        res = medist.suite_step_slab(OracleSlabEngine(), dist, torch.device("cpu"), est, gt, P, rank, world, halo=0.3)
+        q.put((rank, {k: (v if not isinstance(v, dict) else {kk: np.asarray(vv) for kk, vv in v.items()}) for k, v in res.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_suite_gloo_equals_single_process_oracle(world):
+    import torch.multiprocessing as mp
+
+    import oracle
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.cube_pair(12000, seed=33)
+    est, gt = est.numpy() * 0.5, gt.numpy()[:11000] * 0.5
+    est = np.concatenate([est, est[:60] + np.array([0.9, 0.0, 1.5])])  # their nearest GT point is in another slab
+    T = np.eye(4)
+    T[:3, 3] = [0.004, -0.003, 0.002]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, est, gt, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    est_t = oracle.transform(est, T)
+    o_eg = oracle.reg_stats(est_t, gt, 1.0, 0, TRUNC)
+    o_ge = oracle.reg_stats(gt, est_t, 1.0, 0, TRUNC)
+    o_me = oracle.mme(est_t, 0.1, 10)
+    o_mg = oracle.mme(gt, 0.1, 5)
+    o_v = oracle.awd_scs(oracle.VoxelMap(gt, 0.5), oracle.VoxelMap(est_t, 0.5))
+    for rank in range(world):
+        r = results[rank]
+        assert r["n_cross_rank_queries"] > 0  # the protocol's cross-rank step was exercised
+        for got, exp in ((r["est_gt"], o_eg), (r["gt_est"], o_ge)):
+            assert got["n_corr"] == exp.n_corr
+            assert np.array_equal(got["number"], exp.number)
+            assert np.array_equal(got["fitness"], exp.fitness)
+            for k in ("mean", "rmse", "sigma"):
+                np.testing.assert_allclose(got[k], getattr(exp, k), rtol=1e-12)
+        np.testing.assert_allclose(r["cd"], oracle.chamfer(est_t, gt), rtol=1e-12)
+        assert r["mme_valid"] == o_me[3]
+        np.testing.assert_allclose(r["mme_est"], o_me[0], rtol=1e-12)
+        np.testing.assert_allclose(r["mme_gt"], o_mg[0], rtol=1e-12)
+        assert r["n_w"] == len(o_v["rows"])
+        np.testing.assert_allclose(r["awd"], o_v["awd"], rtol=1e-9)
+        np.testing.assert_allclose(r["scs"], o_v["scs"], rtol=1e-9)
+
+
+def test_merge_voxel_partials_is_chan_exact():
+    """Splitting a voxel's points over ranks and merging the partials reproduces the whole-voxel Gaussian."""
+    from cloud_map_evaluation_amd.dist import merge_voxel_partials
+
+    rng = np.random.default_rng(0)
+    p = rng.normal(0, 0.3, (5000, 3)) + np.array([7.0, -3.0, 1.0])
+    e = OracleSlabEngine()
+    rows = []
+    for part in np.array_split(p, 4):
+        e.cloud[0], e.owned[0] = part, np.ones(len(part), bool)
+        k, n, mu, m2 = e.voxel_partials(0, 1.0)
+        rows.append(np.concatenate([k.astype(float), n[:, None].astype(float), mu, m2.reshape(-1, 9)], 1))
+    keys, n, mu, sig = merge_voxel_partials(np.concatenate(rows))
+    e.cloud[0], e.owned[0] = p, np.ones(len(p), bool)
+    k2, n2, mu2, m22 = e.voxel_partials(0, 1.0)
+    assert np.array_equal(keys, k2) and np.array_equal(n, n2)
+    np.testing.assert_allclose(mu, mu2, rtol=1e-13)
+    exp = m22.copy()
+    big = n2 > 10
+    exp[big] = exp[big] / (n2[big] - 1.0)[:, None, None] / (n2[big] - 1.0)[:, None, None]
+    np.testing.assert_allclose(sig, exp, rtol=1e-10, atol=1e-18)
