@@ -131,6 +131,19 @@ int me_download_cloud(me_ctx *ctx, int slot, double *xyz_host) {
     return ME_OK;
 }
 
+int me_voxel_downsample(me_ctx *ctx, int slot, double voxel_size, int64_t *n_out) {
+    if (!ctx) return ME_ERR_ARG;
+    long long n = 0;
+    const int rc = me::voxel_downsample(ctx, slot, voxel_size, &n);
+    if (n_out) *n_out = n;
+    return rc;
+}
+
+int me_transform_cloud(me_ctx *ctx, int slot, const double *T) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::cloud_transform(ctx, slot, T);
+}
+
 int me_nn1(me_ctx *ctx, int query_slot, int ref_slot, int32_t *idx, double *d2) {
     if (!ctx) return ME_ERR_ARG;
     if ((idx || d2) && query_slot >= 0 && query_slot <= 1 && ctx->cloud[query_slot].slab.axis >= 0)

@@ -330,7 +330,20 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
             return ME_OK;
         }
     }
-    n = c.n;
+    c.cell_size_req = cell_size;
+    return cloud_finish(ctx, slot);
+}
+
+// bbox of the points now in c.xyz, then the index (shared by upload, in-place down-sampling and in-place transform)
+int cloud_finish(me_ctx *ctx, int slot) {
+    Cloud &c = ctx->cloud[slot];
+    const long long n = c.n;
+    c.uploaded = false;
+    c.index_valid = false;
+    c.nn_ref_slot = -1;
+    c.vox_valid = false;
+    c.n_vox = 0;
+    ctx->cloud[1 - slot].nn_ref_slot = -1;
     // bbox
     const unsigned int nb = (unsigned int) std::min<long long>(1024, (n + 255) / 256);
     ME_CHECK(ctx, ctx->red.ensure((size_t) nb * 6 * sizeof(double)));
@@ -350,13 +363,28 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
         c.bbox_hi[d] = hi;
     }
     c.uploaded = true;
-    return cloud_build_index(ctx, slot, cell_size);
+    return cloud_build_index(ctx, slot, c.cell_size_req);
+}
+
+// *map_3d_ = map_3d_->Transform(T) (map_eval.cpp:1206) on the cloud already on the device
+int cloud_transform(me_ctx *ctx, int slot, const double *T) {
+    if (slot < 0 || slot > 1 || !T) return ctx->fail(ME_ERR_ARG, "me_transform_cloud: bad argument");
+    Cloud &c = ctx->cloud[slot];
+    if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "cloud not uploaded");
+    if (c.slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_transform_cloud: not available in slab mode (pass T to the upload)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    if (c.n == 0) return ME_OK;
+    Mat4 m;
+    std::memcpy(m.m, T, sizeof(m.m));
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(c.n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), c.n, m);
+    return cloud_finish(ctx, slot);
 }
 
 int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     Cloud &c = ctx->cloud[slot];
     if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "cloud not uploaded");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
+    c.cell_size_req = cell_size;
     const long long n = c.n;
     double extent = 0;
     for (int d = 0; d < 3; ++d) extent = std::fmax(extent, c.bbox_hi[d] - c.bbox_lo[d]);

@@ -117,6 +117,7 @@ struct Cloud {
     // Morton frame
     double origin[3] = {0, 0, 0};
     double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
+    double cell_size_req = 0;  // cell size the caller asked for (<= 0: automatic)
     double cell_h = 0;   // radius-grid cell edge
     double fine_h = 0;   // cell_h / 2^shift
     int shift = 0;
@@ -221,6 +222,9 @@ int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n);
 int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, long long n, const double *T,
                  double cell_size);
 int cloud_build_index(me_ctx *ctx, int slot, double cell_size);
+int cloud_finish(me_ctx *ctx, int slot);
+int cloud_transform(me_ctx *ctx, int slot, const double *T);
+int voxel_downsample(me_ctx *ctx, int slot, double voxel_size, long long *n_out);
 
 // ---- me_nn.hip ----
 int nn_search(me_ctx *ctx, int qslot, int rslot);

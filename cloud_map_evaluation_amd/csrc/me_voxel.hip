@@ -400,6 +400,43 @@ __global__ void k_unpack_keys(const unsigned long long *__restrict__ k, long lon
     out[3 * i + 2] = z;
 }
 
+// ---- VoxelDownSample (open3d::geometry::PointCloud::VoxelDownSample, map_eval.cpp:38-39) ----
+// voxel index = floor((p - (min_bound - vs/2)) / vs)  [Open3D, upstream]; keys are non-negative here.
+__global__ void k_vds_keys(const double *__restrict__ xyz, long long n, double vs, double mx, double my, double mz,
+                           unsigned long long *__restrict__ keys, unsigned int *__restrict__ iota, int *__restrict__ err) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double fx = floor((xyz[3 * i] - mx) / vs), fy = floor((xyz[3 * i + 1] - my) / vs), fz = floor((xyz[3 * i + 2] - mz) / vs);
+    const double lim = 2097151.0;
+    if (!(fx >= 0 && fy >= 0 && fz >= 0 && fx <= lim && fy <= lim && fz <= lim)) {
+        *err = 1;
+        keys[i] = 0;
+    } else {
+        keys[i] = ((unsigned long long) fx << 42) | ((unsigned long long) fy << 21) | (unsigned long long) fz;
+    }
+    iota[i] = (unsigned int) i;
+}
+
+// one thread per voxel: sum in ORIGINAL cloud order (the radix sort is stable), divide by the count — exactly the
+// AccumulatedPoint arithmetic of Open3D, so every output point is bit-identical to the CPU path
+__global__ void k_vds_mean(const double *__restrict__ xyz, const unsigned int *__restrict__ perm,
+                           const unsigned int *__restrict__ seg_start, long long n_vox, double *__restrict__ out) {
+    const long long v = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vox) return;
+    const long long b = seg_start[v], e = seg_start[v + 1];
+    double sx = 0, sy = 0, sz = 0;
+    for (long long j = b; j < e; ++j) {
+        const long long s = perm[j];
+        sx += xyz[3 * s];
+        sy += xyz[3 * s + 1];
+        sz += xyz[3 * s + 2];
+    }
+    const double cnt = (double) (e - b);
+    out[3 * v] = sx / cnt;
+    out[3 * v + 1] = sy / cnt;
+    out[3 * v + 2] = sz / cnt;
+}
+
 static inline unsigned int grid_for(long long n, int block = 256) { return (unsigned int) std::max<long long>(1, (n + block - 1) / block); }
 
 // SCS over a device-resident sparse W table: writes sum(scs_i) and #voxels-with-neighbours to d_sum / d_count
@@ -683,6 +720,61 @@ int awd_scs(me_ctx *ctx, double voxel_size, int min_pts, int scs_radius, double 
     if (awd) *awd = h_s[0] / (double) h_c[0];
     if (scs) *scs = h_s[1] / (double) h_c[1];  // 0/0 -> NaN when no voxel has a neighbour (:387)
     return ME_OK;
+}
+
+int voxel_downsample(me_ctx *ctx, int slot, double voxel_size, long long *n_out) {
+    if (slot < 0 || slot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
+    if (!(voxel_size > 0)) return ctx->fail(ME_ERR_ARG, "me_voxel_downsample: voxel_size must be > 0");
+    Cloud &c = ctx->cloud[slot];
+    if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "me_voxel_downsample: cloud not uploaded");
+    if (c.slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_voxel_downsample: not available in slab mode (down-sample before sharding)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    const long long n = c.n;
+    DevBuf &keys_in = ctx->tmp[0], &iota = ctx->tmp[1], &keys = ctx->tmp[2], &perm = ctx->tmp[3], &flags = ctx->tmp[4];
+    ME_CHECK(ctx, keys_in.ensure((size_t) n * 8));
+    ME_CHECK(ctx, iota.ensure((size_t) n * 4));
+    ME_CHECK(ctx, keys.ensure((size_t) n * 8));
+    ME_CHECK(ctx, perm.ensure((size_t) n * 4));
+    ME_CHECK(ctx, flags.ensure((size_t) n * 4));
+    ME_CHECK(ctx, ctx->red.ensure(64));
+    int *d_err = ctx->red.as<int>();
+    ME_CHECK(ctx, hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    // voxel_min_bound = GetMinBound() - voxel_size / 2  [Open3D, upstream]
+    const double mx = c.bbox_lo[0] - voxel_size * 0.5, my = c.bbox_lo[1] - voxel_size * 0.5, mz = c.bbox_lo[2] - voxel_size * 0.5;
+    TimerScope ts(ctx, "downsample");
+    hipLaunchKernelGGL(k_vds_keys, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, voxel_size, mx, my, mz,
+                       keys_in.as<unsigned long long>(), iota.as<unsigned int>(), d_err);
+    ME_TRY(sort_pairs_u64_u32(ctx, keys_in.as<unsigned long long>(), keys.as<unsigned long long>(), iota.as<unsigned int>(),
+                              perm.as<unsigned int>(), n, 0, 63));
+    DevBuf &pos = ctx->tmp[1];
+    hipLaunchKernelGGL(k_head_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream, keys.as<unsigned long long>(), n,
+                       flags.as<unsigned int>());
+    ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), n));
+    unsigned int last_pos = 0, last_flag = 0;
+    int h_err = 0;
+    ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_err) return ctx->fail(ME_ERR_ARG, "voxel_size is too small for the cloud extent (more than 2^21 voxels per axis)");
+    const long long V = (long long) last_pos + last_flag;
+    DevBuf &seg_start = ctx->tmp[0], seg_key, out;
+    ME_CHECK(ctx, seg_start.ensure((size_t) (V + 1) * 4));
+    ME_CHECK(ctx, seg_key.ensure((size_t) V * 8));
+    ME_CHECK(ctx, out.ensure((size_t) V * 24));
+    hipLaunchKernelGGL(k_seg_scatter, dim3(grid_for(n)), dim3(256), 0, ctx->stream, keys.as<unsigned long long>(),
+                       flags.as<unsigned int>(), pos.as<unsigned int>(), n, seg_key.as<unsigned long long>(),
+                       seg_start.as<unsigned int>());
+    hipLaunchKernelGGL(k_set_u32v, dim3(1), dim3(1), 0, ctx->stream, seg_start.as<unsigned int>(), V, (unsigned int) n);
+    hipLaunchKernelGGL(k_vds_mean, dim3(grid_for(V)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), perm.as<unsigned int>(),
+                       seg_start.as<unsigned int>(), V, out.as<double>());
+    ME_CHECK(ctx, hipMemcpyAsync(c.xyz.p, out.p, (size_t) V * 24, hipMemcpyDeviceToDevice, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_CHECK(ctx, hipGetLastError());
+    c.n = V;
+    c.n_total = V;
+    if (n_out) *n_out = V;
+    return cloud_finish(ctx, slot);  // output order: ascending voxel index (Open3D: hash-map iteration order)
 }
 
 }  // namespace me

@@ -115,6 +115,17 @@ class Engine:
         self._ck(fn(self._ctx, slot, _addr(xyz), int(xyz.shape[0]), _addr(Tm), float(cell_size)))
         self._keepalive = xyz
 
+    def voxel_downsample(self, slot: int, voxel_size: float) -> int:
+        """open3d VoxelDownSample (map_eval.cpp:38-39) on the uploaded cloud, in place; returns the new point count."""
+        n = C.c_int64(0)
+        self._ck(self._L.me_voxel_downsample(self._ctx, slot, float(voxel_size), C.byref(n)))
+        return n.value
+
+    def transform_cloud(self, slot: int, T):
+        """*cloud = cloud->Transform(T) (map_eval.cpp:1206) on the device."""
+        Tm = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        self._ck(self._L.me_transform_cloud(self._ctx, slot, _addr(Tm)))
+
     def size(self, slot: int) -> int:
         return int(self._L.me_cloud_size(self._ctx, slot))
 

@@ -168,42 +168,6 @@ int MapEval::fail(const std::string &msg) {
     return -1;
 }
 
-void MapEval::VoxelDownSample(PointCloud &cloud, double voxel_size) {
-    // open3d::geometry::PointCloud::VoxelDownSample [upstream]: voxel index = floor((p - (min_bound - vs/2)) / vs), output =
-    // mean of the points of each voxel.  Output order here: ascending voxel index (Open3D: hash-map iteration order).
-    if (!(voxel_size > 0) || cloud.IsEmpty()) return;
-    const size_t n = cloud.size();
-    double mn[3] = {cloud.points_[0], cloud.points_[1], cloud.points_[2]};
-    for (size_t i = 1; i < n; ++i)
-        for (int d = 0; d < 3; ++d) mn[d] = std::min(mn[d], cloud.points_[3 * i + d]);
-    for (int d = 0; d < 3; ++d) mn[d] -= voxel_size * 0.5;
-    std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
-    for (size_t i = 0; i < n; ++i) {
-        uint64_t key = 0;
-        for (int d = 0; d < 3; ++d) {
-            const double r = std::floor((cloud.points_[3 * i + d] - mn[d]) / voxel_size);
-            if (r < 0 || r >= 2097152.0) throw std::runtime_error("VoxelDownSample: voxel_size too small for the cloud extent");
-            key = (key << 21) | (uint64_t) r;
-        }
-        keyed[i] = {key, (uint32_t) i};
-    }
-    std::sort(keyed.begin(), keyed.end());
-    std::vector<double> out;
-    out.reserve(n / 2 * 3);
-    size_t i = 0;
-    while (i < n) {
-        size_t j = i;
-        double s[3] = {0, 0, 0};
-        while (j < n && keyed[j].first == keyed[i].first) {
-            for (int d = 0; d < 3; ++d) s[d] += cloud.points_[3 * (size_t) keyed[j].second + d];
-            ++j;
-        }
-        for (int d = 0; d < 3; ++d) out.push_back(s[d] / (double) (j - i));
-        i = j;
-    }
-    cloud.points_.swap(out);
-}
-
 int MapEval::process() {
     TicToc tic_toc;
     std::string err;
@@ -220,30 +184,39 @@ int MapEval::process() {
     if (!success) return fail("Failed to load point cloud from the specified path.");
     if (map_3d_->IsEmpty() || gt_3d_->IsEmpty()) return fail("One or both point clouds are empty!");
 
-    VoxelDownSample(*map_3d_, param_.downsample_size);  // (:38-39)
-    VoxelDownSample(*gt_3d_, param_.downsample_size);
+    // ---- the GPU engine: no CPU fallback ----
+    ctx_ = me_create(param_.gpu_device, 0);
+    if (!ctx_) {
+        file_result << std::fixed << std::setprecision(15) << "Estimated-Ground Truth point count: " << map_3d_->size() << " / "
+                    << gt_3d_->size() << std::endl;
+        return fail(std::string("GPU engine unavailable: ") + me_last_error(nullptr));
+    }
+    me_timers_enable(ctx_, 1);
+    if (me_upload_cloud(ctx_, ME_SLOT_GT, gt_3d_->points_.data(), (int64_t) gt_3d_->size(), nullptr, param_.nn_radius_) != ME_OK ||
+        me_upload_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data(), (int64_t) map_3d_->size(), nullptr, param_.nn_radius_) != ME_OK)
+        return fail(me_last_error(ctx_));
+    // map_3d_ = map_3d_->VoxelDownSample(downsample_size) (:38-39), on the device
+    if (param_.downsample_size > 0) {
+        int64_t ne = 0, ng = 0;
+        if (me_voxel_downsample(ctx_, ME_SLOT_EST, param_.downsample_size, &ne) != ME_OK ||
+            me_voxel_downsample(ctx_, ME_SLOT_GT, param_.downsample_size, &ng) != ME_OK)
+            return fail(me_last_error(ctx_));
+        map_3d_->points_.resize((size_t) ne * 3);
+        gt_3d_->points_.resize((size_t) ng * 3);
+        me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data());
+        me_download_cloud(ctx_, ME_SLOT_GT, gt_3d_->points_.data());
+    }
     file_result << std::fixed << std::setprecision(15) << "Estimated-Ground Truth point count: " << map_3d_->size() << " / "
                 << gt_3d_->size() << std::endl;
     if (param_.enable_debug)
         std::cout << "INFO: Loaded point clouds: " << map_3d_->size() << " points (Map), " << gt_3d_->size()
                   << " points (Ground Truth)." << std::endl;
     t1 = tic_toc.toc();
-
-    // ---- the GPU engine: no CPU fallback ----
-    ctx_ = me_create(param_.gpu_device, 0);
-    if (!ctx_) return fail(std::string("GPU engine unavailable: ") + me_last_error(nullptr));
-    me_timers_enable(ctx_, 1);
     // The reference computes MME on the map as loaded (:56) and transforms it afterwards, inside
-    // calculateMetricsWithInitialMatrix (:1206).  With an identity initial_matrix (the shipped configs) one upload serves
-    // every metric; otherwise the map is uploaded untransformed for MME and re-uploaded with T for AC/COM/CD/AWD/SCS.
+    // calculateMetricsWithInitialMatrix (:1206): same order here (me_transform_cloud below), skipped for an identity matrix.
     const double *T = param_.evaluate_using_initial_ ? param_.initial_matrix_.data() : nullptr;
     bool identity = true;
     for (int i = 0; i < 16 && T; ++i) identity = identity && (T[i] == ((i % 5 == 0) ? 1.0 : 0.0));
-    const bool mme_before_transform = param_.evaluate_mme_ && T && !identity;
-    if (me_upload_cloud(ctx_, ME_SLOT_GT, gt_3d_->points_.data(), (int64_t) gt_3d_->size(), nullptr, param_.nn_radius_) != ME_OK ||
-        me_upload_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data(), (int64_t) map_3d_->size(), mme_before_transform ? nullptr : T,
-                        param_.nn_radius_) != ME_OK)
-        return fail(me_last_error(ctx_));
 
     if (param_.evaluate_mme_) {
         if (param_.enable_debug) std::cout << "INFO: Starting MME calculation..." << std::endl;
@@ -258,10 +231,10 @@ int MapEval::process() {
 
     if (param_.evaluate_using_initial_) {
         if (param_.enable_debug) std::cout << "INFO: Using initial matrix without registration." << std::endl;
-        if (mme_before_transform &&
-            me_upload_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data(), (int64_t) map_3d_->size(), T, param_.nn_radius_) != ME_OK)
-            return fail(me_last_error(ctx_));
-        if (T) me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data());  // *map_3d_ = map_3d_->Transform(...) (:1206)
+        if (T && !identity) {  // *map_3d_ = map_3d_->Transform(param_.initial_matrix_) (:1206)
+            if (me_transform_cloud(ctx_, ME_SLOT_EST, T) != ME_OK) return fail(me_last_error(ctx_));
+            me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data());
+        }
         calculateMetricsWithInitialMatrix();
         if (!last_error.empty()) return -1;
     } else {

@@ -66,8 +66,6 @@ public:
     void saveMmeResults();                                 // map_eval.cpp:392-421
     void saveRegistrationResults();                        // map_eval.cpp:424-482 (text lines; renderers out of scope)
 
-    static void VoxelDownSample(PointCloud &cloud, double voxel_size);  // open3d VoxelDownSample (map_eval.cpp:38-39)
-
     Param param_;
     // results, same names as the reference (map_eval.h:328-353)
     std::vector<Vector5d> est_gt_results, gt_est_results;

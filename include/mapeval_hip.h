@@ -114,6 +114,14 @@ int me_upload_cloud(me_ctx *ctx, int slot, const double *xyz_host, int64_t n, co
                     double cell_size);
 int me_upload_cloud_device(me_ctx *ctx, int slot, const double *xyz_device, int64_t n,
                            const double *T_rowmajor4x4, double cell_size);
+/* open3d::geometry::PointCloud::VoxelDownSample (map_eval.cpp:38-39) on the cloud already on the device, in place:
+ * voxel index = floor((p - (min_bound - voxel_size/2)) / voxel_size), one output point per occupied voxel = the mean of
+ * its points accumulated in cloud order (bit-identical to the CPU arithmetic).  Output order: ascending voxel index
+ * (Open3D: hash-map iteration order).  The index is rebuilt; *n_out = points kept.   */
+int me_voxel_downsample(me_ctx *ctx, int slot, double voxel_size, int64_t *n_out);
+/* *cloud = cloud->Transform(T) (map_eval.cpp:1206, :1392) on the cloud already on the device (row-major 4x4); the index
+ * is rebuilt.  Lets MME run on the map as loaded and AC/COM/CD/AWD on the transformed map, as the reference does. */
+int me_transform_cloud(me_ctx *ctx, int slot, const double *T_rowmajor4x4);
 int64_t me_cloud_size(me_ctx *ctx, int slot);
 /* transformed points back to the host (N x 3), original order — what map_3d_->points_ holds after :1206 */
 int me_download_cloud(me_ctx *ctx, int slot, double *xyz_host);

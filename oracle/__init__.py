@@ -73,6 +73,8 @@ def lib():
         L.orc_kdtree_nn1.argtypes = [C.c_void_p, dp, C.c_int64, ip, dp, C.c_int]
         L.orc_kdtree_radius_count.argtypes = [C.c_void_p, dp, C.c_int64, C.c_double, ip, C.c_int]
         L.orc_transform.argtypes = [dp, C.c_int64, dp]
+        L.orc_voxel_downsample.restype = C.c_int64
+        L.orc_voxel_downsample.argtypes = [dp, C.c_int64, C.c_double, dp, C.c_int64]
         L.orc_reg_stats_run.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_double, C.c_int, dp,
                                         C.POINTER(_RegStats), C.c_int]
         L.orc_chamfer.restype = C.c_double
@@ -130,6 +132,15 @@ def radius_count(ref, query, r: float, threads: int = 0):
     lib().orc_kdtree_radius_count(t, _dp(query), query.shape[0], float(r), _ip(cnt), threads)
     lib().orc_kdtree_free(t)
     return cnt
+
+
+def voxel_downsample(xyz, voxel_size: float) -> np.ndarray:
+    """open3d VoxelDownSample (map_eval.cpp:38-39); output in ascending voxel-index order."""
+    xyz = _pts(xyz)
+    n = lib().orc_voxel_downsample(_dp(xyz), xyz.shape[0], float(voxel_size), None, 0)
+    out = np.empty((n, 3), np.float64)
+    lib().orc_voxel_downsample(_dp(xyz), xyz.shape[0], float(voxel_size), _dp(out), n)
+    return out
 
 
 def transform(xyz, T) -> np.ndarray:

@@ -836,4 +836,37 @@ double orc_scs(const int32_t *keys, const double *w, int64_t n, int radius) {
     return scs_from_map(wd, radius);
 }
 
+int64_t orc_voxel_downsample(const double *xyz, int64_t n, double voxel_size, double *out, int64_t capacity) {
+    // open3d::geometry::PointCloud::VoxelDownSample [upstream] (called at map_eval.cpp:38-39):
+    //   voxel_min_bound = GetMinBound() - voxel_size * 0.5
+    //   voxel_index     = floor((p - voxel_min_bound) / voxel_size)   (per component, int)
+    //   AccumulatedPoint: point_ += p (cloud order), output = point_ / num_of_points_
+    // Output order here: ascending (ix, iy, iz); Open3D's is its hash map's iteration order.
+    if (n <= 0 || !(voxel_size > 0)) return 0;
+    double mn[3] = {xyz[0], xyz[1], xyz[2]};
+    for (int64_t i = 1; i < n; ++i)
+        for (int d = 0; d < 3; ++d) mn[d] = std::min(mn[d], xyz[3 * i + d]);
+    for (int d = 0; d < 3; ++d) mn[d] -= voxel_size * 0.5;
+    struct Acc {
+        double s[3] = {0, 0, 0};
+        int64_t c = 0;
+    };
+    std::unordered_map<Key3, Acc, KeyHash> acc;
+    for (int64_t i = 0; i < n; ++i) {
+        Key3 k;
+        for (int d = 0; d < 3; ++d) k.v[d] = (int32_t) std::floor((xyz[3 * i + d] - mn[d]) / voxel_size);
+        Acc &a = acc[k];
+        for (int d = 0; d < 3; ++d) a.s[d] += xyz[3 * i + d];
+        a.c++;
+    }
+    std::vector<std::pair<Key3, const Acc *>> v;
+    v.reserve(acc.size());
+    for (const auto &kv : acc) v.emplace_back(kv.first, &kv.second);
+    std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return key_less(a.first, b.first); });
+    if (out)
+        for (size_t i = 0; i < v.size() && (int64_t) i < capacity; ++i)
+            for (int d = 0; d < 3; ++d) out[3 * i + d] = v[i].second->s[d] / (double) v[i].second->c;
+    return (int64_t) v.size();
+}
+
 }  // extern "C"

@@ -53,6 +53,10 @@ void orc_kdtree_nn1(const orc_kdtree *t, const double *q, int64_t m, int32_t *id
 void orc_kdtree_radius_count(const orc_kdtree *t, const double *q, int64_t m, double r, int32_t *count,
                              int threads);
 
+/* ---- VoxelDownSample (map_eval.cpp:38-39; Open3D PointCloud::VoxelDownSample) -> number of output points;
+ *      out (capacity x 3, may be NULL) receives them in ascending voxel-index order ---- */
+int64_t orc_voxel_downsample(const double *xyz, int64_t n, double voxel_size, double *out, int64_t capacity);
+
 /* ---- Transform (map_eval.cpp:1206; Open3D PointCloud::Transform, homogeneous divide) ---- */
 void orc_transform(double *xyz, int64_t n, const double T_rowmajor[16]);
 

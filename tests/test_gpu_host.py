@@ -24,7 +24,7 @@ def _write_pcd(path, pts):
         f.write(np.ascontiguousarray(pts, dtype="<f8").tobytes())
 
 
-def _cfg(est_dir, gt_path, T, mme=True, gt_mme=True, strict=False):
+def _cfg(est_dir, gt_path, T, mme=True, gt_mme=True, strict=False, downsample=0.0):
     rows = "\n".join("  - [" + ", ".join(repr(float(v)) for v in T[i]) + "]" for i in range(4))
     return f"""registration_methods: 2
 icp_max_distance: 1.0
@@ -42,7 +42,7 @@ nn_radius: 0.1
 evaluate_using_initial: true
 evaluate_noise_gt: false
 vmd_voxel_size: 0.5
-downsample_size: 0.0
+downsample_size: {downsample}
 use_visualization: false
 enable_debug: true
 strict_reference: {'true' if strict else 'false'}
@@ -123,3 +123,27 @@ def test_strict_reference_reproduces_zero_full_cd(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     res, _ = _parse_results(est_dir / "map_results" / "map_results.txt")
     assert res["FULL CD"] == [0.0] and "MME" not in res
+
+
+def test_host_run_with_voxel_downsample(tmp_path):
+    """downsample_size > 0: the host down-samples both clouds on the device (map_eval.cpp:38-39) before any metric."""
+    import oracle
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.cube_pair(100_000, seed=4)
+    est, gt = est.numpy(), gt.numpy()
+    est_dir = tmp_path / "est"
+    est_dir.mkdir()
+    _write_pcd(est_dir / "map.pcd", est)
+    _write_pcd(tmp_path / "gt.pcd", gt)
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(_cfg(est_dir, tmp_path / "gt.pcd", np.eye(4), mme=True, gt_mme=False, downsample=0.05))
+    r = subprocess.run([EXE, str(cfg)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res, _ = _parse_results(est_dir / "map_results" / "map_results.txt")
+    e_ds, g_ds = oracle.voxel_downsample(est, 0.05), oracle.voxel_downsample(gt, 0.05)
+    assert res["counts"] == (len(e_ds), len(g_ds))
+    o = oracle.reg_stats(e_ds, g_ds, 1.0, 0, TRUNC)
+    np.testing.assert_allclose(res["RMSE/AC"], o.rmse, rtol=0, atol=2e-15)
+    np.testing.assert_allclose(res["Comp"], o.fitness, rtol=0, atol=2e-15)
+    np.testing.assert_allclose(res["MME"][0], oracle.mme(e_ds, 0.1, 10)[0], atol=6e-6)

@@ -315,3 +315,51 @@ def test_device_sqrt_is_correctly_rounded(eng):
     _, d2 = eng.nn1(0, 1)
     p = eng.nn_partial_sums(0, -1.0, 0, TRUNC)
     np.testing.assert_allclose(p.sum_sqrt_all, np.sqrt(d2).sum(), rtol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# "next" row of SURVEY.md section 8f, rank 1: VoxelDownSample (map_eval.cpp:38-39) and the in-place transform (:1206)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("vs", [0.05, 0.01, 0.37])
+def test_voxel_downsample_bit_exact(eng, campus, vs):
+    import oracle
+
+    est, _ = campus
+    eng.upload(0, est)
+    n = eng.voxel_downsample(0, vs)
+    got = eng.download(0)
+    exp = oracle.voxel_downsample(est, vs)
+    assert n == len(exp) == len(got)
+    assert np.array_equal(got, exp)  # same voxels, same order, means accumulated in cloud order: bit-identical
+    # the down-sampled cloud is a fully indexed cloud: metrics run on it
+    eng.upload(1, exp)
+    _, d2 = eng.nn1(0, 1)
+    assert np.all(d2 == 0.0)
+
+
+def test_voxel_downsample_too_small_voxel_is_an_error(eng):
+    from cloud_map_evaluation_amd.engine import MapEvalError
+
+    eng.upload(0, np.array([[0.0, 0, 0], [5000.0, 1, 1], [1.0, 2, 3]]))
+    with pytest.raises(MapEvalError):
+        eng.voxel_downsample(0, 1e-4)  # > 2^21 voxels per axis (Open3D: "voxel_size is too small")
+
+
+def test_transform_cloud_in_place(eng, cube):
+    import oracle
+
+    est, gt = cube
+    T = np.eye(4)
+    T[:3, :3] = [[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]
+    T[:3, 3] = [0.5, -0.25, 0.125]
+    eng.upload(0, est, cell_size=0.1)
+    eng.upload(1, gt, cell_size=0.1)
+    before = eng.mme(0, 0.1, 10)
+    eng.transform_cloud(0, T)
+    est_t = oracle.transform(est, T)
+    assert np.array_equal(eng.download(0), est_t)
+    after = eng.mme(0, 0.1, 10)  # MME is invariant under a rigid transform (up to rounding)
+    assert after[3] == before[3]
+    np.testing.assert_allclose(after[0], before[0], rtol=1e-9)
+    _, d2 = eng.nn1(0, 1)
+    assert np.array_equal(d2, oracle.nn1(gt, est_t)[1])
