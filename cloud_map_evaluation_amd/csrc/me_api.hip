@@ -154,6 +154,11 @@ int me_nn1(me_ctx *ctx, int query_slot, int ref_slot, int32_t *idx, double *d2) 
     return ME_OK;
 }
 
+int me_icp_p2p_sums(me_ctx *ctx, int query_slot, double max_distance, me_icp_sums *out) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::icp_p2p_sums(ctx, query_slot, max_distance, out);
+}
+
 int me_nn_partial_sums(me_ctx *ctx, int query_slot, double gate, int gate_mode, const double trunc[5], me_nn_partial *out) {
     if (!ctx) return ME_ERR_ARG;
     return me::nn_partial(ctx, query_slot, gate, gate_mode, trunc, out);

@@ -655,4 +655,80 @@ int nn_sigma(me_ctx *ctx, int qslot, double gate, int gate_mode, const double me
     return ME_OK;
 }
 
+// ---- point-to-point ICP: correspondence + reduction step (Open3D TransformationEstimationPointToPoint) ----
+constexpr int kIcpD = 16;  // sum_p[3], sum_q[3], sum_pq[9], sum_d2
+
+__global__ void __launch_bounds__(256)
+k_icp_p2p(const SPoint *__restrict__ qsp, const double *__restrict__ d2s, const int *__restrict__ idxs,
+          const double *__restrict__ ref_xyz, long long n, double gate2, double cx, double cy, double cz,
+          double *__restrict__ pd, long long *__restrict__ pc) {
+    double s[kIcpD];
+#pragma unroll
+    for (int k = 0; k < kIcpD; ++k) s[k] = 0;
+    long long cnt = 0;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        const double d2 = d2s[i];
+        if (d2 >= 0.0 && d2 < gate2) {  // SearchHybrid(q, max, 1): d2 < max^2 [Open3D, upstream]
+            const long long j = idxs[i];
+            // coordinates relative to a common origin: keeps sum(p q^T) - n pbar qbar^T well conditioned
+            const double px = qsp[i].x - cx, py = qsp[i].y - cy, pz = qsp[i].z - cz;
+            const double qx = ref_xyz[3 * j] - cx, qy = ref_xyz[3 * j + 1] - cy, qz = ref_xyz[3 * j + 2] - cz;
+            s[0] += px; s[1] += py; s[2] += pz;
+            s[3] += qx; s[4] += qy; s[5] += qz;
+            s[6] = fma(px, qx, s[6]); s[7] = fma(px, qy, s[7]); s[8] = fma(px, qz, s[8]);
+            s[9] = fma(py, qx, s[9]); s[10] = fma(py, qy, s[10]); s[11] = fma(py, qz, s[11]);
+            s[12] = fma(pz, qx, s[12]); s[13] = fma(pz, qy, s[13]); s[14] = fma(pz, qz, s[14]);
+            s[15] += d2;
+            ++cnt;
+        }
+    }
+    __shared__ double smd[4];
+    __shared__ long long smi[4];
+#pragma unroll
+    for (int k = 0; k < kIcpD; ++k) {
+        const double r = block_sum_256(s[k], smd);
+        if (threadIdx.x == 0) pd[(long long) blockIdx.x * kIcpD + k] = r;
+    }
+    const long long rc = block_sum_256_ll(cnt, smi);
+    if (threadIdx.x == 0) pc[blockIdx.x] = rc;
+}
+
+int icp_p2p_sums(me_ctx *ctx, int qslot, double max_distance, me_icp_sums *out) {
+    if (qslot < 0 || qslot > 1 || !out || !(max_distance > 0)) return ctx->fail(ME_ERR_ARG, "me_icp_p2p_sums: bad argument");
+    Cloud &q = ctx->cloud[qslot];
+    if (q.nn_ref_slot < 0) return ctx->fail(ME_ERR_STATE, "me_icp_p2p_sums: call me_nn1(query_slot, ref_slot) first");
+    if (q.slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_icp_p2p_sums: not available in slab mode");
+    Cloud &r = ctx->cloud[q.nn_ref_slot];
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    const long long n = q.n;
+    const int nb = (int) std::max<long long>(1, std::min<long long>(1024, (n + 255) / 256));
+    const size_t bytes_d = (size_t) (nb + 1) * kIcpD * 8;
+    ME_CHECK(ctx, ctx->red.ensure(bytes_d + (size_t) (nb + 1) * 8));
+    double *pd = ctx->red.as<double>();
+    long long *pc = reinterpret_cast<long long *>(ctx->red.as<char>() + bytes_d);
+    const double cx = r.origin[0], cy = r.origin[1], cz = r.origin[2];
+    {
+        TimerScope ts(ctx, "icp");
+        hipLaunchKernelGGL(k_icp_p2p, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), q.nn_d2.as<double>(), q.nn_idx.as<int>(),
+                           r.xyz.as<double>(), n, max_distance * max_distance, cx, cy, cz, pd, pc);
+        hipLaunchKernelGGL(k_final_sum_d, dim3(1), dim3(64), 0, ctx->stream, pd, nb, kIcpD, pd + (size_t) nb * kIcpD);
+        hipLaunchKernelGGL(k_final_sum_i, dim3(1), dim3(64), 0, ctx->stream, pc, nb, 1, pc + nb);
+    }
+    double hd[kIcpD];
+    long long hc = 0;
+    ME_CHECK(ctx, hipMemcpyAsync(hd, pd + (size_t) nb * kIcpD, sizeof(hd), hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(&hc, pc + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    out->n_corr = hc;
+    out->n_source = n;
+    for (int k = 0; k < 3; ++k) {
+        out->sum_p[k] = hd[k];
+        out->sum_q[k] = hd[3 + k];
+        out->origin[k] = r.origin[k];
+    }
+    for (int k = 0; k < 9; ++k) out->sum_pq[k] = hd[6 + k];
+    out->sum_d2 = hd[15];
+    return ME_OK;
+}
+
 }  // namespace me

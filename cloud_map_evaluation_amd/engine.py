@@ -169,6 +169,17 @@ class Engine:
         self._L.me_nn_finalize(C.byref(total), _addr(s), int(n_src_total), C.byref(out))
         return RegStats.from_c(out)
 
+    def icp_p2p_sums(self, query_slot: int, max_distance: float) -> _lib.IcpSums:
+        """Sums of the point-to-point ICP step over the correspondences (d2 < max^2) of the last nn1(query_slot, ...)."""
+        out = _lib.IcpSums()
+        self._ck(self._L.me_icp_p2p_sums(self._ctx, query_slot, float(max_distance), C.byref(out)))
+        return out
+
+    def performICPRegistration(self, max_distance: float, **criteria):
+        """map_eval.cpp:1369-1371, registration_methods 0 (point-to-point); see icp.icp_point_to_point."""
+        from .icp import icp_point_to_point
+        return icp_point_to_point(self, max_distance, **criteria)
+
     def computeChamferDistance(self) -> float:
         """map_eval.cpp:1398-1431 on the uploaded pair."""
         cd = C.c_double()

@@ -238,12 +238,14 @@ int MapEval::process() {
         calculateMetricsWithInitialMatrix();
         if (!last_error.empty()) return -1;
     } else {
-        // performRegistration (map_eval.cpp:191-237) = Open3D ICP / GICP: a third-party optimiser, outside the GPU hot path
-        // (SURVEY.md section 8f rank 2).  Align the map first and evaluate with evaluate_using_initial: true.
-        return fail("evaluate_using_initial: false needs ICP registration, which this build does not provide; "
-                    "pass the alignment as initial_matrix and set evaluate_using_initial: true");
+        // performRegistration (map_eval.cpp:191-237).  Point-to-point ICP (registration_methods: 0) runs on the device-side
+        // correspondence + reduction step; point-to-plane (1) and GICP (2) are Open3D optimisers this build does not provide.
+        if (param_.evaluation_method_ != 0)
+            return fail("registration_methods 1 (point-to-plane) / 2 (GICP) are not provided: use 0 (point-to-point ICP), or pass "
+                        "the alignment as initial_matrix and set evaluate_using_initial: true");
+        if (performRegistration() != 0) return -1;
     }
-    t5 = t4 = t3 = tic_toc.toc();
+    if (param_.evaluate_using_initial_) t5 = t4 = t3 = tic_toc.toc();
 
     calculateVMD();
     if (!last_error.empty()) return -1;
@@ -251,6 +253,172 @@ int MapEval::process() {
     if (param_.save_immediate_result_) saveRegistrationResults();
     if (param_.enable_debug) std::cout << "INFO: Results saved successfully." << std::endl;
     return 0;
+}
+
+namespace {
+
+// symmetric n x n Jacobi eigen-decomposition (n <= 4): eigenvalues in d, eigenvectors in the columns of V
+void jacobi_sym(int n, double *a, double *d, double *V) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[n * i + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) off += a[n * p + q] * a[n * p + q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[n * p + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[n * q + q] - a[n * p + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = a[n * k + p], akq = a[n * k + q];
+                    a[n * k + p] = c * akp - sn * akq;
+                    a[n * k + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = a[n * p + k], aqk = a[n * q + k];
+                    a[n * p + k] = c * apk - sn * aqk;
+                    a[n * q + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[n * k + p], vkq = V[n * k + q];
+                    V[n * k + p] = c * vkp - sn * vkq;
+                    V[n * k + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) d[i] = a[n * i + i];
+}
+
+// Optimal rigid update (row-major 4x4, absolute coordinates) from the me_icp_sums block: Horn's closed form, which gives
+// the same rotation as Eigen::umeyama without scaling (TransformationEstimationPointToPoint [Open3D, upstream]).
+void kabsch_from_sums(const me_icp_sums &s, double T[16]) {
+    const double n = (double) s.n_corr;
+    double pb[3], qb[3], S[9];
+    for (int k = 0; k < 3; ++k) {
+        pb[k] = s.sum_p[k] / n;
+        qb[k] = s.sum_q[k] / n;
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) S[3 * r + c] = s.sum_pq[3 * r + c] - n * pb[r] * qb[c];  // sum (p-pb)(q-qb)^T
+    double N[16] = {S[0] + S[4] + S[8], S[5] - S[7],        S[6] - S[2],         S[1] - S[3],
+                    S[5] - S[7],        S[0] - S[4] - S[8], S[1] + S[3],         S[6] + S[2],
+                    S[6] - S[2],        S[1] + S[3],        -S[0] + S[4] - S[8], S[5] + S[7],
+                    S[1] - S[3],        S[6] + S[2],        S[5] + S[7],         -S[0] - S[4] + S[8]};
+    double d[4], V[16];
+    jacobi_sym(4, N, d, V);
+    int best = 0;
+    for (int i = 1; i < 4; ++i)
+        if (d[i] > d[best]) best = i;
+    const double w = V[best], x = V[4 + best], y = V[8 + best], z = V[12 + best];
+    const double R[9] = {w * w + x * x - y * y - z * z, 2 * (x * y - w * z),           2 * (x * z + w * y),
+                         2 * (x * y + w * z),           w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
+                         2 * (x * z - w * y),           2 * (y * z + w * x),           w * w - x * x - y * y + z * z};
+    // x -> o + R (x - o - pb) + qb
+    for (int i = 0; i < 16; ++i) T[i] = (i == 15) ? 1.0 : 0.0;
+    for (int r = 0; r < 3; ++r) {
+        double t = s.origin[r] + qb[r];
+        for (int c = 0; c < 3; ++c) {
+            T[4 * r + c] = R[3 * r + c];
+            t -= R[3 * r + c] * (s.origin[c] + pb[c]);
+        }
+        T[4 * r + 3] = t;
+    }
+}
+
+void matmul4(const double A[16], const double B[16], double C[16]) {
+    double out[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double acc = 0;
+            for (int k = 0; k < 4; ++k) acc += A[4 * r + k] * B[4 * k + c];
+            out[4 * r + c] = acc;
+        }
+    for (int i = 0; i < 16; ++i) C[i] = out[i];
+}
+
+}  // namespace
+
+int MapEval::performRegistration() {
+    // RegistrationICP(*map_3d_, *gt_3d_, icp_max_distance_, initial_matrix_, PointToPoint, ICPConvergenceCriteria())
+    // (map_eval.cpp:1369-1371): relative_fitness = relative_rmse = 1e-6, max_iteration = 30 [Open3D defaults, upstream]
+    TicToc tic_toc;
+    for (int i = 0; i < 16; ++i) trans[i] = param_.initial_matrix_[i];
+    bool identity = true;
+    for (int i = 0; i < 16; ++i) identity = identity && (trans[i] == ((i % 5 == 0) ? 1.0 : 0.0));
+    if (!identity && me_transform_cloud(ctx_, ME_SLOT_EST, trans.data()) != ME_OK) return fail(me_last_error(ctx_));
+    me_icp_sums s;
+    auto evaluate = [&](double &fit, double &rmse) -> bool {
+        if (me_nn1(ctx_, ME_SLOT_EST, ME_SLOT_GT, nullptr, nullptr) != ME_OK ||
+            me_icp_p2p_sums(ctx_, ME_SLOT_EST, param_.icp_max_distance_, &s) != ME_OK)
+            return false;
+        fit = s.n_source ? (double) s.n_corr / (double) s.n_source : 0.0;
+        rmse = s.n_corr ? std::sqrt(s.sum_d2 / (double) s.n_corr) : 0.0;
+        return true;
+    };
+    double fit = 0, rmse = 0;
+    if (!evaluate(fit, rmse)) return fail(me_last_error(ctx_));
+    int it = 0;
+    for (it = 1; it <= 30; ++it) {
+        if (s.n_corr < 3) break;
+        double upd[16];
+        kabsch_from_sums(s, upd);
+        matmul4(upd, trans.data(), trans.data());
+        if (me_transform_cloud(ctx_, ME_SLOT_EST, upd) != ME_OK) return fail(me_last_error(ctx_));
+        const double pf = fit, pr = rmse;
+        if (!evaluate(fit, rmse)) return fail(me_last_error(ctx_));
+        if (std::fabs(pf - fit) < 1e-6 && std::fabs(pr - rmse) < 1e-6) break;
+    }
+    t3 = 0;  // no mesh stage
+    t4 = tic_toc.toc();
+    me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data());  // *map_3d_ = map_3d_->Transform(trans) (:1392)
+    std::cout << "INFO: ICP registration time: " << t4 / 1000.0 << " [s]" << std::endl;
+    std::cout << "INFO: Aligned transformation: \n";
+    for (int r = 0; r < 4; ++r)
+        std::cout << trans[4 * r] << " " << trans[4 * r + 1] << " " << trans[4 * r + 2] << " " << trans[4 * r + 3] << std::endl;
+    std::cout << "INFO: ICP overlap ratio: " << fit << std::endl;
+    std::cout << "INFO: ICP correspondences RMSE: " << rmse << std::endl;
+    std::cout << "INFO: ICP correspondences size: " << s.n_corr << std::endl;
+    // "Aligned cloud:" / "Aligned results:" lines (map_eval.cpp:223-225)
+    file_result << std::fixed << std::setprecision(5) << "Aligned cloud: ";
+    for (int r = 0; r < 4; ++r) {
+        for (int c = 0; c < 4; ++c) file_result << (c ? " " : "") << trans[4 * r + c];
+        file_result << std::endl;
+    }
+    file_result << std::fixed << std::setprecision(5) << "Aligned results: " << fit << " " << s.n_corr << std::endl;
+    calculateMetrics();
+    t5 = tic_toc.toc();
+    return last_error.empty() ? 0 : -1;
+}
+
+void MapEval::calculateMetrics() {
+    // map_eval.cpp:1147-1202: statistics on ICP's final correspondence set (est -> gt, d2 < max^2), then
+    // EvaluateRegistration(gt -> map, max) (:1168), cd_vec (:1171) and the full Chamfer distance (:1194).
+    TicToc tt;
+    me_nn_stats_out eg, ge;
+    if (me_nn1(ctx_, ME_SLOT_EST, ME_SLOT_GT, nullptr, nullptr) != ME_OK ||
+        me_nn_stats(ctx_, ME_SLOT_EST, param_.icp_max_distance_, ME_GATE_LT_SQUARED, param_.trunc_dist_.data(), &eg) != ME_OK) {
+        fail(me_last_error(ctx_));
+        return;
+    }
+    t_acc = tt.toc() / 1000.0;
+    if (me_nn1(ctx_, ME_SLOT_GT, ME_SLOT_EST, nullptr, nullptr) != ME_OK ||
+        me_nn_stats(ctx_, ME_SLOT_GT, param_.icp_max_distance_, ME_GATE_LT_SQUARED, param_.trunc_dist_.data(), &ge) != ME_OK) {
+        fail(me_last_error(ctx_));
+        return;
+    }
+    push_results(est_gt_results, eg);
+    push_results(gt_est_results, ge);
+    for (int i = 0; i < 5; ++i) cd_vec[i] = est_gt_results[1][i] + gt_est_results[1][i];  // (:1171)
+    std::cout << "INFO: RMSE/AC: " << eigen_row(est_gt_results[1], 6) << std::endl;
+    std::cout << "INFO: Fitness/Overlap: " << eigen_row(est_gt_results[2], 6) << std::endl;
+    TicToc t1_;
+    full_chamfer_dist = eg.mean_nn_dist + ge.mean_nn_dist;  // computeChamferDistance (:1194, :1429): same two searches
+    t_fcd = t1_.toc() / 1000.0 + (tt.toc() / 1000.0 - t_acc);
+    std::cout << "INFO: Full Chamfer distance: " << full_chamfer_dist << std::endl;
 }
 
 void MapEval::computeMME(PointCloud &cloud, PointCloud &gt) {
@@ -396,8 +564,12 @@ void MapEval::saveRegistrationResults() {
     file_result << std::fixed << std::setprecision(5) << "FULL CD: " << full_chamfer_dist << std::endl;
     file_result << std::fixed << std::setprecision(5) << "VMD: " << vmd << std::endl;
     file_result << std::fixed << std::setprecision(5) << "SCS: " << scs_overall << std::endl;
-    file_result << "Time load-MME-mesh-ICP-Metric-AC-FCD: " << t1 / 1000.0 << " " << (t2 - t1) / 1000.0 << " " << 0.0 << " "
-                << 0.0 << " " << (t5 - t2) / 1000.0 << " " << t_acc << " " << t_fcd << std::endl;
+    if (param_.evaluate_using_initial_)
+        file_result << "Time load-MME-mesh-ICP-Metric-AC-FCD: " << t1 / 1000.0 << " " << (t2 - t1) / 1000.0 << " " << 0.0 << " "
+                    << 0.0 << " " << (t5 - t2) / 1000.0 << " " << t_acc << " " << t_fcd << std::endl;
+    else  // t3..t5 come from performRegistration's own clock (map_eval.cpp:192, :465-467)
+        file_result << "Time load-MME-mesh-ICP-Metric-AC-FCD: " << t1 / 1000.0 << " " << (t2 - t1) / 1000.0 << " " << t3 / 1000.0
+                    << " " << (t4 - t3) / 1000.0 << " " << (t5 - t4) / 1000.0 << " " << t_acc << " " << t_fcd << std::endl;
     file_result << "VMD Time voxelization-WD-CDF-SCS: " << t_v / 1000.0 << " " << (t_vmd - t_v) / 1000.0 << " "
                 << (t_cdf - t_vmd) / 1000.0 << " " << (t_scs - t_cdf) / 1000.0 << std::endl;
     file_result << "AC+MME Time: " << t_acc + (t2 - t1) / 1000.0 << std::endl;

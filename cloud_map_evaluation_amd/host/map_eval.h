@@ -61,6 +61,8 @@ public:
     int process();                                         // map_eval.cpp:4-102
     void computeMME(PointCloud &cloud, PointCloud &gt);    // map_eval.cpp:149-189
     void calculateMetricsWithInitialMatrix();              // map_eval.cpp:1204-1260
+    int performRegistration();                             // map_eval.cpp:191-237 (point-to-point ICP only)
+    void calculateMetrics();                               // map_eval.cpp:1147-1202
     double computeChamferDistance();                       // map_eval.cpp:1398-1431
     void calculateVMD();                                   // map_eval.cpp:240-390
     void saveMmeResults();                                 // map_eval.cpp:392-421
@@ -70,6 +72,7 @@ public:
     // results, same names as the reference (map_eval.h:328-353)
     std::vector<Vector5d> est_gt_results, gt_est_results;
     Vector5d f1_vec{{0, 0, 0, 0, 0}}, cd_vec{{0, 0, 0, 0, 0}}, iou_vec{{0, 0, 0, 0, 0}};
+    std::array<double, 16> trans{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};  // ICP result (row-major), map_eval.h:332
     double vmd = 0.0, full_chamfer_dist = 0.0, scs_overall = 0.0;
     double mme_est = 0.0, mme_gt = 0.0, max_abs_entropy = 0.0, min_abs_entropy = 0.0;
     std::vector<double> est_entropies, gt_entropies;

@@ -145,6 +145,23 @@ int me_nn_sigma_sums(me_ctx *ctx, int query_slot, double gate, int gate_mode, co
 void me_nn_finalize(const me_nn_partial *total, const double sigma_num[5], int64_t n_src_total,
                     me_nn_stats_out *out);
 
+/* One point-to-point ICP correspondence + reduction step: what an iteration of Open3D's
+ * RegistrationICP(.., TransformationEstimationPointToPoint) (called at map_eval.cpp:1369-1371) needs from the clouds.
+ * Over the correspondences of the last me_nn1(query_slot, ref) with d2 < max_distance^2 (Open3D SearchHybrid semantics):
+ * the count, sum p, sum q, sum p q^T (row-major, p = source, q = target; all RELATIVE TO `origin`) and sum d2
+ * (fitness = n_corr / n_source, inlier_rmse = sqrt(sum_d2 / n_corr)).  The 3x3 Umeyama / Kabsch solve stays on the host;
+ * me_transform_cloud applies the update. */
+typedef struct me_icp_sums {
+    int64_t n_corr;
+    int64_t n_source;
+    double origin[3];
+    double sum_p[3];
+    double sum_q[3];
+    double sum_pq[9];
+    double sum_d2;
+} me_icp_sums;
+int me_icp_p2p_sums(me_ctx *ctx, int query_slot, double max_distance, me_icp_sums *out);
+
 /* computeChamferDistance (map_eval.cpp:1398-1431): both directions, no gate.  Runs me_nn1 both ways. */
 int me_chamfer(me_ctx *ctx, double *cd);
 
