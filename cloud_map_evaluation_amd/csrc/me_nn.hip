@@ -19,6 +19,13 @@
 
 namespace me {
 
+// v_min_f64 without the NaN canonicalisation the compiler wraps around fmin() (squared distances are never NaN)
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ double box_lower_bound(const float *__restrict__ b, double qx, double qy, double qz) {
     const double dx = fmax(fmax((double) b[0] - qx, qx - (double) b[3]), 0.0);
     const double dy = fmax(fmax((double) b[1] - qy, qy - (double) b[4]), 0.0);
@@ -50,7 +57,8 @@ __device__ __forceinline__ double box_upper_bound(const float *__restrict__ b, d
 // loses; Chebyshev-1 groups serialise a wave into ~5 rounds on a fine grid and lose as well.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, GridView g,
+k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
+          GridView g,
           FrameView fr, SlabView slab, double *__restrict__ d2_out, int *__restrict__ idx_out,
           unsigned int *__restrict__ list, unsigned int *__restrict__ list_count) {
     const int lane = threadIdx.x & 63;
@@ -88,30 +96,42 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         }
     }
     double best = INFINITY;
-    long long best_i = 0x7fffffffffffffffLL;
+    int best_j = -1;  // position in the sorted reference array (wave-uniform per candidate: no per-candidate idx load)
     bool done = !active || !in_grid;
 
-    auto test = [&](const SPoint &p) {
+    // The hot loop keeps only (best, position of the GROUP of <= 4 stream-consecutive candidates that produced it):
+    // 8 fp64 ops per candidate for the distance plus 7 per group, instead of a compare and three selects per candidate.
+    // The epilogue re-tests that one group per lane to name the winner.  Strict <: the first group in stream order
+    // wins ties, and inside it the first position, so coincident reference points (one stable-sorted run) still
+    // resolve to the smallest original index.
+    auto test1 = [&](const SPoint &p, int j) {
         const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
-        // strict <: coincident reference points sit in one stable-sorted run, the first (smallest index) wins
-        if (d < best) {
-            best = d;
-            best_i = p.idx;
-        }
+        const bool lt = d < best;
+        best = lt ? d : best;
+        best_j = lt ? j : best_j;
     };
-    auto stream_run = [&](int cs, int ce, bool in) {
+    auto test4 = [&](const SPoint &a, const SPoint &b, const SPoint &c, const SPoint &e, int j) {
+        const double d0 = dist2_exact(qx, qy, qz, a.x, a.y, a.z), d1 = dist2_exact(qx, qy, qz, b.x, b.y, b.z);
+        const double d2 = dist2_exact(qx, qy, qz, c.x, c.y, c.z), d3 = dist2_exact(qx, qy, qz, e.x, e.y, e.z);
+        const double m = vmin_f64(vmin_f64(d0, d1), vmin_f64(d2, d3));
+        const bool lt = m < best;
+        best = vmin_f64(best, m);
+        best_j = lt ? j : best_j;
+    };
+    // Every candidate is a real reference point, so lanes outside the current group (or already done) may test it as
+    // well: an extra candidate can only lower their bound.  No per-lane predicate means no exec juggling in the loop;
+    // the kernel issues about as many scalar as vector instructions, so the scalar side is kept lean: one pointer
+    // walk, four wave-uniform fetches in flight.
+    auto stream_run = [&](int cs, int ce) {
+        const SPoint *p = rsp + cs;
         int j = cs;
-        for (; j + 1 < ce; j += 2) {  // two wave-uniform (scalar) fetches in flight
-            const SPoint p0 = rsp[j];
-            const SPoint p1 = rsp[j + 1];
-            if (in) {
-                test(p0);
-                test(p1);
-            }
+        for (; j + 4 <= ce; j += 4, p += 4) {
+            const SPoint p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+            test4(p0, p1, p2, p3, j);
         }
-        if (j < ce) {
-            const SPoint p0 = rsp[j];
-            if (in) test(p0);
+        for (; j < ce; ++j, ++p) {
+            const SPoint p0 = p[0];
+            test1(p0, j);
         }
     };
     // (the candidate set of a round is a superset of the lane's own 3x3x3 block; extra candidates only help)
@@ -121,7 +141,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         GroupBox bx;
         int nk = 0;
         const bool in = wave_group_table<1>(!done, mcx, mcy, mcz, g, cell_lim, lane, tab, bx, &nk);
-        wave_for_each_run(tab, nk, lane, [&](int cs, int ce) { stream_run(cs, ce, in); });
+        wave_for_each_run(tab, nk, lane, [&](int cs, int ce) { stream_run(cs, ce); });
         if (in) done = true;
         __builtin_amdgcn_wave_barrier();
     }
@@ -140,7 +160,20 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             unresolved = !(gmin > 0.0 && best < gmin * gmin);
         }
         d2_out[i] = best;  // final if resolved, initial bound otherwise
-        idx_out[i] = (best_i == 0x7fffffffffffffffLL) ? -1 : (int) best_i;
+        int best_i = -1;
+        if (best_j >= 0) {  // name the winner inside its group: the first position whose distance IS the minimum
+            // (positions past the group's run belong to cells outside the candidate set; for a resolved lane they are
+            //  strictly farther than `best`, for an unresolved one any exact match is an equally valid bound)
+#pragma unroll
+            for (int t = 3; t >= 0; --t) {
+                const long long pos = (long long) best_j + t;
+                if (pos < nr) {
+                    const SPoint p = rsp[pos];
+                    if (dist2_exact(qx, qy, qz, p.x, p.y, p.z) == best) best_i = (int) p.idx;
+                }
+            }
+        }
+        idx_out[i] = best_i;
     }
     // wave-aggregated append of the unresolved lanes
     const unsigned long long um = __ballot(unresolved);
@@ -493,7 +526,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         {
             TimerScope ts(ctx, "nn_grid");
             hipLaunchKernelGGL(k_nn_grid, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
-                               r.nn_grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
+                               r.n, r.nn_grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
         }
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)
