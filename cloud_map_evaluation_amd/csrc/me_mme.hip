@@ -58,10 +58,13 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
 
     const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
 
-    auto test = [&](const SPoint &p) {
+    // r2e = r2 for the lanes of the current group, -1 for the others: the group predicate rides on the radius
+    // compare, so the loop needs no exec juggling of its own (the scalar side of this kernel is nearly as busy as the
+    // vector side: one pointer walk, four wave-uniform fetches in flight)
+    auto test = [&](const SPoint &p, double r2e) {
         const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
         const double d2 = (dx * dx + dy * dy) + dz * dz;  // bit-identical to the CPU path (no FMA)
-        if (d2 < r2) {                                    // strict, nanoflann RadiusResultSet [upstream]
+        if (d2 < r2e) {                                   // strict, nanoflann RadiusResultSet [upstream]
             ++k;
             s1x += dx;
             s1y += dy;
@@ -74,19 +77,19 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
             szz = fma(dz, dz, szz);
         }
     };
-    auto stream_run = [&](int cs, int ce, bool in) {
+    auto stream_run = [&](int cs, int ce, double r2e) {
+        const SPoint *p = sp + cs;
         int j = cs;
-        for (; j + 1 < ce; j += 2) {  // two wave-uniform (scalar) fetches in flight
-            const SPoint p0 = sp[j];
-            const SPoint p1 = sp[j + 1];
-            if (in) {
-                test(p0);
-                test(p1);
-            }
+        for (; j + 4 <= ce; j += 4, p += 4) {
+            const SPoint p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+            test(p0, r2e);
+            test(p1, r2e);
+            test(p2, r2e);
+            test(p3, r2e);
         }
-        if (j < ce) {
-            const SPoint p0 = sp[j];
-            if (in) test(p0);
+        for (; j < ce; ++j, ++p) {
+            const SPoint p0 = p[0];
+            test(p0, r2e);
         }
     };
 
@@ -94,19 +97,20 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
     while (__ballot(!done)) {
         int rs0, rc0, rs1, rc1;
         const bool in = wave_group_runs(!done, cx, cy, cz, g, cell_lim, lane, rs0, rc0, rs1, rc1);
+        const double r2e = in ? r2 : -1.0;
         unsigned long long m = __ballot(rc0 > 0);
         while (m) {
             const int n = __ffsll((long long) m) - 1;
             m &= m - 1;
             const int cs = readlane_i(rs0, n);
-            stream_run(cs, cs + readlane_i(rc0, n), in);
+            stream_run(cs, cs + readlane_i(rc0, n), r2e);
         }
         m = __ballot(rc1 > 0);
         while (m) {
             const int n = __ffsll((long long) m) - 1;
             m &= m - 1;
             const int cs = readlane_i(rs1, n);
-            stream_run(cs, cs + readlane_i(rc1, n), in);
+            stream_run(cs, cs + readlane_i(rc1, n), r2e);
         }
         if (in) done = true;
     }
@@ -132,143 +136,6 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
             }
         }
         ent_s[i] = H;                       // 0.0 where invalid (:1614)
-        valid_s[i] = ok ? 1 : 0;
-    }
-    __shared__ double smd[4];
-    __shared__ long long smi[4];
-    const double bs = block_sum_256(H, smd);
-    const long long bc = block_sum_256_ll(ok ? 1LL : 0LL, smi);
-    if (threadIdx.x == 0) {
-        part_sum[blockIdx.x] = bs;
-        part_cnt[blockIdx.x] = bc;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Sliced variant: a wavefront owns G = 64/S consecutive sorted points, each replicated over S lanes ("slices");
-// lane (q, s) tests the candidates S*t + s of every run.  The candidate set of a wave is the cell box of only G
-// queries grown by one, which holds far fewer points than the box of 64 queries (bench scene: 349 vs 665 for G = 16),
-// so the fp64 tests per query drop by the same factor; the price is a vector load of S distinct consecutive records
-// per step instead of a scalar one, and a cross-slice butterfly at the end.
-// ------------------------------------------------------------------------------------------------------------
-template <int S>
-__global__ void __launch_bounds__(256)
-k_mme_sliced(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
-             GridView g, SlabView slab, double r2, int min_k, double *__restrict__ ent_s, unsigned char *__restrict__ valid_s,
-             double *__restrict__ part_sum, long long *__restrict__ part_cnt) {
-    constexpr int G = 64 / S;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ql = lane % G, sl = lane / G;
-    const unsigned int per = gridDim.x / 8;  // XCD-aware chunking, gridDim.x is a multiple of 8
-    const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    const long long i = i_begin + ((long long) vb * 4 + wv) * G + ql;
-    bool active = i < i_end;
-    const int shift3 = 3 * g.shift;
-    const int cell_lim = 1 << (kMortonBits - g.shift);
-
-    double qx = 0, qy = 0, qz = 0;
-    unsigned long long mycell = ~0ULL;
-    if (active) {
-        const SPoint q = sp[i];
-        qx = q.x;
-        qy = q.y;
-        qz = q.z;
-        mycell = codes[i] >> shift3;
-        if (!slab_owned(slab, qx, qy, qz)) {  // slab mode: halo points are neighbours only, never queries
-            if (sl == 0) {
-                ent_s[i] = 0.0;
-                valid_s[i] = 0;
-            }
-            active = false;
-        }
-    }
-    int k = 0;
-    double s1x = 0, s1y = 0, s1z = 0;
-    double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-    bool done = !active;
-    const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
-
-    auto test = [&](double px, double py, double pz, bool ok) {
-        const double dx = px - qx, dy = py - qy, dz = pz - qz;
-        const double d2 = (dx * dx + dy * dy) + dz * dz;  // bit-identical to the CPU path (no FMA)
-        if (ok && d2 < r2) {                              // strict, nanoflann RadiusResultSet [upstream]
-            ++k;
-            s1x += dx;
-            s1y += dy;
-            s1z += dz;
-            sxx = fma(dx, dx, sxx);
-            sxy = fma(dx, dy, sxy);
-            sxz = fma(dx, dz, sxz);
-            syy = fma(dy, dy, syy);
-            syz = fma(dy, dz, syz);
-            szz = fma(dz, dz, szz);
-        }
-    };
-    auto stream_run = [&](int cs, int ce, bool in) {
-        int j0 = cs;
-        for (; j0 + S < ce; j0 += 2 * S) {  // two fetches in flight
-            const int ja = j0 + sl, jb = j0 + S + sl;
-            const bool oka = ja < ce, okb = jb < ce;
-            const SPoint *pa = sp + (oka ? ja : cs), *pb = sp + (okb ? jb : cs);
-            const double ax = pa->x, ay = pa->y, az = pa->z;
-            const double bx = pb->x, by = pb->y, bz = pb->z;
-            test(ax, ay, az, in && oka);
-            test(bx, by, bz, in && okb);
-        }
-        if (j0 < ce) {
-            const int ja = j0 + sl;
-            const bool oka = ja < ce;
-            const SPoint *pa = sp + (oka ? ja : cs);
-            test(pa->x, pa->y, pa->z, in && oka);
-        }
-    };
-
-    __shared__ int2 s_tab[4][kGroupTab + 1];
-    int2 *tab = s_tab[wv];
-    while (__ballot(!done)) {
-        GroupBox bx;
-        int nk = 0;
-        const bool in = wave_group_table<1>(!done, cx, cy, cz, g, cell_lim, lane, tab, bx, &nk);
-        wave_for_each_run(tab, nk, lane, [&](int cs, int ce) { stream_run(cs, ce, in); });
-        if (in) done = true;
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    // cross-slice butterfly: afterwards every slice lane of a query holds the totals
-#pragma unroll
-    for (int off = G; off < 64; off <<= 1) {
-        k += __shfl_xor(k, off, 64);
-        s1x += __shfl_xor(s1x, off, 64);
-        s1y += __shfl_xor(s1y, off, 64);
-        s1z += __shfl_xor(s1z, off, 64);
-        sxx += __shfl_xor(sxx, off, 64);
-        sxy += __shfl_xor(sxy, off, 64);
-        sxz += __shfl_xor(sxz, off, 64);
-        syy += __shfl_xor(syy, off, 64);
-        syz += __shfl_xor(syz, off, 64);
-        szz += __shfl_xor(szz, off, 64);
-    }
-
-    double H = 0.0;
-    bool ok = false;
-    if (active && sl == 0) {
-        const int kk = k - 1;  // drop the query itself (map_eval.cpp:1672-1673)
-        if (kk >= min_k) {     // (:1675 k >= 10, :1458 k >= 5)
-            const double inv_k = 1.0 / (double) kk, inv_km1 = 1.0 / (double) (kk - 1);
-            const double cxx = (sxx - s1x * s1x * inv_k) * inv_km1;
-            const double cxy = (sxy - s1x * s1y * inv_k) * inv_km1;
-            const double cxz = (sxz - s1x * s1z * inv_k) * inv_km1;
-            const double cyy = (syy - s1y * s1y * inv_k) * inv_km1;
-            const double cyz = (syz - s1y * s1z * inv_k) * inv_km1;
-            const double czz = (szz - s1z * s1z * inv_k) * inv_km1;
-            const double det = cxx * (cyy * czz - cyz * cyz) - cxy * (cxy * czz - cyz * cxz) + cxz * (cxy * cyz - cyy * cxz);
-            const double h = 0.5 * log(2.0 * M_PI * M_E * det);  // ComputeEntropy (:1656)
-            if (!isnan(h) && !isinf(h)) {                         // (:1692)
-                H = h;
-                ok = true;
-            }
-        }
-        ent_s[i] = H;  // 0.0 where invalid (:1614)
         valid_s[i] = ok ? 1 : 0;
     }
     __shared__ double smd[4];
@@ -340,11 +207,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     DevBuf &ent_s = ctx->tmp[0], &val_s = ctx->tmp[1];
     ME_CHECK(ctx, ent_s.ensure((size_t) n * 8));
     ME_CHECK(ctx, val_s.ensure((size_t) n));
-    // slices per query (see k_mme_sliced): 1 = the wave-shared scalar stream, 2/4/8 = sub-wave groups
-    static const int slices = std::getenv("ME_MME_SLICES") ? std::atoi(std::getenv("ME_MME_SLICES")) : 4;
-    const int S = (slices == 2 || slices == 4 || slices == 8) ? slices : 1;
-    const long long qpb = 256 / S;  // queries per block
-    const unsigned int nb = (unsigned int) std::max<long long>(8, ((e - b + qpb - 1) / qpb + 7) / 8 * 8);
+    const unsigned int nb = (unsigned int) std::max<long long>(8, ((e - b + 255) / 256 + 7) / 8 * 8);
     constexpr int kStage = 256;
     ME_CHECK(ctx, ctx->red.ensure((size_t) (nb + kStage + 1) * 16 + 64));
     double *ps = ctx->red.as<double>();
@@ -356,14 +219,8 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     const double r2 = radius * radius;  // Open3D SearchRadius -> nanoflann radiusSearch(q, r*r) [upstream]
     {
         TimerScope ts(ctx, "mme");
-#define ME_MME_LAUNCH(KERNEL)                                                                                                  \
-    hipLaunchKernelGGL(KERNEL, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e, \
-                       c.grid, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc)
-        if (S == 2) ME_MME_LAUNCH(k_mme_sliced<2>);
-        else if (S == 4) ME_MME_LAUNCH(k_mme_sliced<4>);
-        else if (S == 8) ME_MME_LAUNCH(k_mme_sliced<8>);
-        else ME_MME_LAUNCH(k_mme);
-#undef ME_MME_LAUNCH
+        hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
+                           c.grid, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc);
     }
     const long long chunk = ((long long) nb + kStage - 1) / kStage;
     hipLaunchKernelGGL(k_mme_final, dim3(kStage), dim3(256), 0, ctx->stream, ps, pc, (long long) nb, chunk, ps2, pc2);

@@ -190,6 +190,16 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
 // [q_begin, q_end); otherwise the queries q_begin + list[t], t < *list_count, starting from the bound the grid pass
 // left behind.
 // ------------------------------------------------------------------------------------------------------------
+// Eight lanes ("octet") cooperate on one query: lane c bounds child c of the current node (one 32-byte record each,
+// one coalesced 256-byte burst per octet), a 3-step butterfly picks the nearest admissible child, and a leaf cell is
+// scanned eight points at a time.  The queries that reach this kernel are the rare far ones (0.1 % of the bench scene,
+// but each sweeps hundreds of nodes): with one lane per query the whole launch waited on a handful of serial walks.
+__device__ __forceinline__ double octet_min(double v) {
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) v = fmin(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
 __global__ void __launch_bounds__(256)
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
       OctView oct, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
@@ -200,94 +210,126 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
     const int L = oct.n_levels - 1;  // root level
     const ONode *__restrict__ nodes = oct.nodes;
     const long long n_items = list ? (long long) *list_count : (q_end - q_begin);
-    for (long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < n_items; t += (long long) gridDim.x * blockDim.x) {
-        const long long i = q_begin + (list ? (long long) list[t] : t);
+    const int sub = threadIdx.x & 7;
+    const long long octets_per_pass = (long long) gridDim.x * (blockDim.x >> 3);
+    for (long long t = (long long) blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);; t += octets_per_pass) {
+        const bool alive = t < n_items;
+        if (!__ballot(alive)) break;  // wave-uniform exit
+        const long long i = q_begin + (alive ? (list ? (long long) list[t] : t) : 0);
         const SPoint q = qsp[i];
         const double qx = q.x, qy = q.y, qz = q.z;
         double best = INFINITY;
         long long best_i = 0x7fffffffffffffffLL;
-        if (list) {
+        if (list && alive) {
             best = d2_out[i];
             const int bi = idx_out[i];
             if (bi >= 0) best_i = bi;
         }
-        auto scan_cell = [&](long long leaf) {  // leaf cell = points [begin, next.begin)
-            const long long b = nodes[leaf].begin, e = nodes[leaf + 1].begin;
-            for (long long j = b; j < e; ++j) {
-                const SPoint p = rsp[j];
-                const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
-                if (d < best || (d == best && p.idx < best_i)) {  // ties -> smallest reference index (as the oracle)
-                    best = d;
-                    best_i = p.idx;
+        // scan of one leaf cell by the octets flagged `go` (the shuffles run converged over the whole wave)
+        auto scan_cells = [&](bool go, long long leaf) {
+            long long jb = 0, je = 0;
+            if (go) {
+                jb = nodes[leaf].begin;
+                je = nodes[leaf + 1].begin;
+            }
+            double lb = best;
+            long long li = best_i;
+            for (long long j = jb + sub; __ballot(j < je); j += 8) {
+                if (j < je) {
+                    const SPoint p = rsp[j];
+                    const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
+                    if (d < lb || (d == lb && p.idx < li)) {  // ties -> smallest reference index (as the oracle)
+                        lb = d;
+                        li = p.idx;
+                    }
                 }
+            }
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {
+                const double od = __shfl_xor(lb, m, 64);
+                const long long oi = __shfl_xor(li, m, 64);
+                if (od < lb || (od == lb && oi < li)) {
+                    lb = od;
+                    li = oi;
+                }
+            }
+            if (go) {
+                best = lb;
+                best_i = li;
             }
         };
         if (L == 0) {
-            scan_cell(0);  // the whole cloud is one cell
+            scan_cells(alive, 0);  // the whole cloud is one cell
         } else {
             int l = L;          // current node = (l, n); its children live on level l-1
             long long n = 0;
             // "children already entered" of the current node of every level on the path: one byte per level
             unsigned long long taken_lo = 0, taken_hi = 0;  // levels 1..8 / 9..16
             double bound = best;  // pruning bound: min(best found, tightest box upper bound seen)
-            for (;;) {
+            bool walking = alive;
+            while (__ballot(walking)) {
                 const ONode *__restrict__ me = nodes + s_off[l] + n;
                 const long long cb = me[0].begin;
                 const int cnt = (int) (me[1].begin - cb);  // 1..8 children, contiguous on the level below
-                const ONode *__restrict__ ch = nodes + s_off[l - 1] + cb;
-                // one burst: up to 8 child records (32 B each; the buffer has 8 records of slack, short groups are masked)
-                float f[48];
-                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(ch);
-#pragma unroll
-                for (int c = 0; c < kFan; ++c) {
-                    const float4 a = g[2 * c], bb = g[2 * c + 1];
-                    f[6 * c] = a.x;
-                    f[6 * c + 1] = a.y;
-                    f[6 * c + 2] = a.z;
-                    f[6 * c + 3] = a.w;
-                    f[6 * c + 4] = bb.x;
-                    f[6 * c + 5] = bb.y;
-                }
+                const unsigned int parent = me[0].parent;
+                // lane `sub` owns child `sub` (the buffer has 8 records of slack: short groups are masked, not skipped)
+                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(nodes + s_off[l - 1] + cb + sub);
+                const float4 a = g[0], bb = g[1];
+                const float f[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
+                const bool mine = sub < cnt;
                 const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
                                                  : (unsigned int) (taken_hi >> (8 * (l - 9))) & 0xffu;
                 // every child box also yields an UPPER bound on the answer (some point lies inside it, no farther than
                 // its farthest corner): keeps the depth-first walk from sweeping a wide region on a loose `best`
+                bound = fmin(bound, octet_min(mine ? box_upper_bound(f, qx, qy, qz) : INFINITY));
+                const double lbd = box_lower_bound(f, qx, qy, qz);
+                const bool ok = mine && !((tk >> sub) & 1u) && lbd <= bound;  // <=: ties may hold a smaller index
+                double kd = ok ? lbd : INFINITY;
+                int kc = ok ? sub : 8;
 #pragma unroll
-                for (int c = 0; c < kFan; ++c)
-                    if (c < cnt) bound = fmin(bound, box_upper_bound(&f[6 * c], qx, qy, qz));
-                double bd = INFINITY;
-                int bc = -1;
-#pragma unroll
-                for (int c = 0; c < kFan; ++c) {
-                    const double lb = box_lower_bound(&f[6 * c], qx, qy, qz);
-                    const bool ok = (c < cnt) && !((tk >> c) & 1u) && lb <= bound;  // <=: ties may hold a smaller index
-                    if (ok && lb < bd) {
-                        bd = lb;
-                        bc = c;
+                for (int m = 1; m < 8; m <<= 1) {
+                    const double od = __shfl_xor(kd, m, 64);
+                    const int oc = __shfl_xor(kc, m, 64);
+                    if (od < kd || (od == kd && oc < kc)) {
+                        kd = od;
+                        kc = oc;
                     }
                 }
-                if (bc < 0) {  // nothing left under this node: return to the parent
-                    if (l == L) break;
-                    n = me[0].parent;
-                    ++l;
-                    continue;
+                bool go = false;
+                long long leaf = 0;
+                if (walking) {
+                    if (kc >= 8) {  // nothing left under this node: return to the parent
+                        if (l == L) {
+                            walking = false;
+                        } else {
+                            n = parent;
+                            ++l;
+                        }
+                    } else {
+                        if (l <= 8) taken_lo |= 1ULL << (8 * (l - 1) + kc);
+                        else taken_hi |= 1ULL << (8 * (l - 9) + kc);
+                        if (l == 1) {
+                            go = true;
+                            leaf = s_off[0] + cb + kc;
+                        } else {
+                            --l;
+                            n = cb + kc;
+                            if (l <= 8) taken_lo &= ~(0xffULL << (8 * (l - 1)));  // fresh node on the level below
+                            else taken_hi &= ~(0xffULL << (8 * (l - 9)));
+                        }
+                    }
                 }
-                if (l <= 8) taken_lo |= 1ULL << (8 * (l - 1) + bc);
-                else taken_hi |= 1ULL << (8 * (l - 9) + bc);
-                if (l == 1) {
-                    scan_cell(s_off[0] + cb + bc);
+                if (__ballot(go)) {
+                    scan_cells(go, leaf);
                     bound = fmin(bound, best);
-                } else {
-                    --l;
-                    n = cb + bc;
-                    if (l <= 8) taken_lo &= ~(0xffULL << (8 * (l - 1)));  // fresh node on the level below
-                    else taken_hi &= ~(0xffULL << (8 * (l - 9)));
                 }
             }
         }
-        d2_out[i] = best;
-        idx_out[i] = (int) best_i;
-    }  // grid-stride loop over queries
+        if (alive && sub == 0) {
+            d2_out[i] = best;
+            idx_out[i] = (int) best_i;
+        }
+    }  // grid-stride loop over octets
 }
 
 // ---- un-permute results to the caller's (original) query order ----
