@@ -139,6 +139,7 @@ struct Cloud {
     double vox_size = 0;
     long long n_vox = 0;
     bool vox_valid = false, vox_raw = false;
+    DevBuf vox_tmp;    // build scratch (segment starts when they outgrow the shared scratch)
     DevBuf vox_key;    // uint64[V] packed key
     DevBuf vox_n;      // int32[V]
     DevBuf vox_mu;     // double[V][3]

@@ -6,8 +6,8 @@
 //   MapEval::calculateVMD (AWD mean, CDF, SCS)             map_eval.cpp:240-390
 //
 // The reference inserts every point into an unordered_map with an XOR hash (99 % of its AWD stage time) and updates
-// a streaming Welford mean/M2.  Here: pack floor(p/voxel) into a 63-bit key, radix-sort (key, index), and give each
-// voxel (one contiguous segment) to one wavefront for a two-pass mean / M2.  Tables come out in ascending
+// a streaming Welford mean/M2.  Here: pack floor(p/voxel) into a 63-bit key and reduce the Morton-sorted cloud run by run
+// (see "voxel statistics straight from the Morton-sorted cloud" below): two-pass mean / M2.  Tables come out in ascending
 // (ix,iy,iz) order; est/gt are joined by binary search, W is one voxel pair per lane, SCS is one wavefront per
 // voxel over the (2r+1)^3 stencil with hash probes.
 #include <cmath>
@@ -30,25 +30,167 @@ __device__ __host__ __forceinline__ void unpack_key(unsigned long long k, int &k
 
 constexpr unsigned long long kVoxSentinel = 0x7fffffffffffffffULL;  // sorts after every real key
 
-__global__ void k_voxel_keys(const double *__restrict__ xyz, long long n, double vs, SlabView slab,
-                             unsigned long long *__restrict__ keys, unsigned int *__restrict__ iota, int *__restrict__ err) {
-    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (!slab_owned(slab, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])) {  // slab mode: halo points belong to another rank
-        keys[i] = kVoxSentinel;
-        iota[i] = (unsigned int) i;
-        return;
-    }
-    // getVoxelIndex (voxel_calculator.cpp:241-245): floor(x / voxel_size) — IEEE division, not a reciprocal multiply
-    const double fx = floor(xyz[3 * i] / vs), fy = floor(xyz[3 * i + 1] / vs), fz = floor(xyz[3 * i + 2] / vs);
+__device__ __forceinline__ double wave_allsum(double v);  // xor butterfly: every lane gets the (fixed-tree) total
+
+// getVoxelIndex (voxel_calculator.cpp:241-245): floor(x / voxel_size) — IEEE division, not a reciprocal multiply
+__device__ __forceinline__ unsigned long long voxel_key_of(double x, double y, double z, double vs, const SlabView &slab,
+                                                           int *__restrict__ err) {
+    if (!slab_owned(slab, x, y, z)) return kVoxSentinel;  // slab mode: halo points belong to another rank
+    const double fx = floor(x / vs), fy = floor(y / vs), fz = floor(z / vs);
     const double lim = (double) (kKeyBias - 16);
     if (!(fabs(fx) < lim && fabs(fy) < lim && fabs(fz) < lim)) {
         *err = 1;
-        keys[i] = 0;
-    } else {
-        keys[i] = pack_key((int) fx, (int) fy, (int) fz);
+        return 0;
     }
-    iota[i] = (unsigned int) i;
+    return pack_key((int) fx, (int) fy, (int) fz);
+}
+
+// ---- voxel statistics straight from the Morton-sorted cloud ----------------------------------------------------
+// A voxel is large next to the search cell, so Morton-consecutive points mostly share their voxel: every wavefront
+// (64 consecutive sorted points) splits into a few RUNS of equal key.  Pass 1 reduces (n, sum p) per run with a
+// segmented butterfly and emits one record per run; the records (about n/60 of them, not n) are radix-sorted by key,
+// one wavefront per voxel adds its records up in that fixed order -> mean; pass 2 emits sum (p-mean)(p-mean)^T per run
+// the same way.  No per-point sort, no gather through a permutation, and the work per voxel no longer depends on its
+// population (one wavefront used to walk a 100 k-point voxel alone).  Deterministic: fixed trees, stable sort.
+struct RunLane {
+    unsigned long long key;
+    bool valid, head;
+    int run_local;  // index of the lane's run inside the wave
+    int seg;        // id used by the segmented butterfly (unique per run, distinct for invalid lanes)
+};
+
+__device__ __forceinline__ RunLane wave_runs(const SPoint *__restrict__ sp, long long i, long long n, double vs,
+                                            const SlabView &slab, int *__restrict__ err, int lane, double &x, double &y,
+                                            double &z) {
+    RunLane r;
+    r.valid = i < n;
+    x = y = z = 0.0;
+    r.key = ~0ULL;
+    if (r.valid) {
+        const SPoint p = sp[i];
+        x = p.x;
+        y = p.y;
+        z = p.z;
+        r.key = voxel_key_of(x, y, z, vs, slab, err);
+    }
+    const unsigned long long prev = __shfl_up(r.key, 1, 64);
+    r.head = r.valid && (lane == 0 || r.key != prev);
+    const unsigned long long hm = __ballot(r.head);
+    r.run_local = __popcll(hm & ((2ULL << lane) - 1ULL)) - 1;
+    r.seg = r.valid ? r.run_local : 64 + lane;
+    return r;
+}
+
+// sum over the lanes of the same (contiguous) segment, delivered to the segment's first lane
+__device__ __forceinline__ double seg_sum_to_head(double v, int seg, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double ov = __shfl_down(v, o, 64);
+        const int os = __shfl_down(seg, o, 64);
+        if (lane + o < 64 && os == seg) v += ov;
+    }
+    return v;
+}
+__device__ __forceinline__ int seg_sum_to_head_i(int v, int seg, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ov = __shfl_down(v, o, 64);
+        const int os = __shfl_down(seg, o, 64);
+        if (lane + o < 64 && os == seg) v += ov;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+k_vox_count_runs(const SPoint *__restrict__ sp, long long n, double vs, SlabView slab, unsigned int *__restrict__ wave_runs_out,
+                 int *__restrict__ err) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    double x, y, z;
+    const RunLane r = wave_runs(sp, i, n, vs, slab, err, lane, x, y, z);
+    const unsigned long long hm = __ballot(r.head);
+    if (lane == 0 && r.valid) wave_runs_out[i >> 6] = (unsigned int) __popcll(hm);
+}
+
+__global__ void __launch_bounds__(256)
+k_vox_pass1(const SPoint *__restrict__ sp, long long n, double vs, SlabView slab, const unsigned int *__restrict__ wave_off,
+            unsigned long long *__restrict__ rec_key, unsigned int *__restrict__ rec_iota, int *__restrict__ rec_n,
+            double *__restrict__ rec_sum, int *__restrict__ err) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    double x, y, z;
+    const RunLane r = wave_runs(sp, i, n, vs, slab, err, lane, x, y, z);
+    const int cnt = seg_sum_to_head_i(r.valid ? 1 : 0, r.seg, lane);
+    const double sx = seg_sum_to_head(x, r.seg, lane), sy = seg_sum_to_head(y, r.seg, lane), sz = seg_sum_to_head(z, r.seg, lane);
+    if (r.head) {
+        const long long rid = (long long) wave_off[i >> 6] + r.run_local;
+        rec_key[rid] = r.key;
+        rec_iota[rid] = (unsigned int) rid;
+        rec_n[rid] = cnt;
+        rec_sum[3 * rid] = sx;
+        rec_sum[3 * rid + 1] = sy;
+        rec_sum[3 * rid + 2] = sz;
+    }
+}
+
+// one wavefront per voxel: add the run records up (fixed order) -> population and mean; tag the records with the voxel
+__global__ void __launch_bounds__(256)
+k_vox_mean(const unsigned int *__restrict__ perm_r, const unsigned int *__restrict__ seg_start, long long n_vox,
+           const int *__restrict__ rec_n, const double *__restrict__ rec_sum, unsigned int *__restrict__ rec_vox,
+           int *__restrict__ vn, double *__restrict__ vmu) {
+    const int lane = threadIdx.x & 63;
+    const long long v = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_vox) return;
+    const long long b = seg_start[v], e = seg_start[v + 1];
+    long long cnt = 0;
+    double sx = 0, sy = 0, sz = 0;
+    for (long long j = b + lane; j < e; j += 64) {
+        const unsigned int r = perm_r[j];
+        cnt += rec_n[r];
+        sx += rec_sum[3 * (long long) r];
+        sy += rec_sum[3 * (long long) r + 1];
+        sz += rec_sum[3 * (long long) r + 2];
+        rec_vox[r] = (unsigned int) v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    const double mx = wave_allsum(sx) / (double) cnt, my = wave_allsum(sy) / (double) cnt, mz = wave_allsum(sz) / (double) cnt;
+    if (lane == 0) {
+        vn[v] = (int) cnt;
+        vmu[3 * v] = mx;
+        vmu[3 * v + 1] = my;
+        vmu[3 * v + 2] = mz;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_vox_pass2(const SPoint *__restrict__ sp, long long n, double vs, SlabView slab, const unsigned int *__restrict__ wave_off,
+            const unsigned int *__restrict__ rec_vox, const double *__restrict__ vmu, double *__restrict__ rec_m2,
+            int *__restrict__ err) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    double x, y, z;
+    const RunLane r = wave_runs(sp, i, n, vs, slab, err, lane, x, y, z);
+    const long long rid = r.valid ? (long long) wave_off[i >> 6] + r.run_local : 0;
+    double dx = 0, dy = 0, dz = 0;
+    if (r.valid && r.key != kVoxSentinel) {
+        const long long v = rec_vox[rid];
+        dx = x - vmu[3 * v];
+        dy = y - vmu[3 * v + 1];
+        dz = z - vmu[3 * v + 2];
+    }
+    const double cxx = seg_sum_to_head(dx * dx, r.seg, lane), cxy = seg_sum_to_head(dx * dy, r.seg, lane);
+    const double cxz = seg_sum_to_head(dx * dz, r.seg, lane), cyy = seg_sum_to_head(dy * dy, r.seg, lane);
+    const double cyz = seg_sum_to_head(dy * dz, r.seg, lane), czz = seg_sum_to_head(dz * dz, r.seg, lane);
+    if (r.head) {
+        double *o = rec_m2 + 6 * rid;
+        o[0] = cxx;
+        o[1] = cxy;
+        o[2] = cxz;
+        o[3] = cyy;
+        o[4] = cyz;
+        o[5] = czz;
+    }
 }
 
 __global__ void k_head_flags(const unsigned long long *__restrict__ keys, long long n, unsigned int *__restrict__ flags) {
@@ -79,38 +221,29 @@ __device__ __forceinline__ double det3_rowmajor(const double *m) {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
 }
 
-// one wavefront per voxel
+// one wavefront per voxel: M2 = sum of the run records' M2 (fixed order), then the reference's finalisation
 __global__ void __launch_bounds__(256)
-k_voxel_gauss(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, const unsigned int *__restrict__ seg_start,
-              long long n_vox, int raw, int *__restrict__ vn, double *__restrict__ vmu, double *__restrict__ vsig,
-              double *__restrict__ vent) {
+k_vox_final(const unsigned int *__restrict__ perm_r, const unsigned int *__restrict__ seg_start, long long n_vox,
+            const double *__restrict__ rec_m2, const int *__restrict__ vn, int raw, double *__restrict__ vsig,
+            double *__restrict__ vent) {
     const int lane = threadIdx.x & 63;
     const long long v = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= n_vox) return;
     const long long b = seg_start[v], e = seg_start[v + 1];
-    const long long cnt = e - b;
-    double sx = 0, sy = 0, sz = 0;
-    for (long long j = b + lane; j < e; j += 64) {
-        const long long s = perm[j];
-        sx += xyz[3 * s];
-        sy += xyz[3 * s + 1];
-        sz += xyz[3 * s + 2];
-    }
-    const double mx = wave_allsum(sx) / (double) cnt, my = wave_allsum(sy) / (double) cnt, mz = wave_allsum(sz) / (double) cnt;
     double cxx = 0, cxy = 0, cxz = 0, cyy = 0, cyz = 0, czz = 0;
     for (long long j = b + lane; j < e; j += 64) {
-        const long long s = perm[j];
-        const double dx = xyz[3 * s] - mx, dy = xyz[3 * s + 1] - my, dz = xyz[3 * s + 2] - mz;
-        cxx = fma(dx, dx, cxx);
-        cxy = fma(dx, dy, cxy);
-        cxz = fma(dx, dz, cxz);
-        cyy = fma(dy, dy, cyy);
-        cyz = fma(dy, dz, cyz);
-        czz = fma(dz, dz, czz);
+        const double *m = rec_m2 + 6 * (long long) perm_r[j];
+        cxx += m[0];
+        cxy += m[1];
+        cxz += m[2];
+        cyy += m[3];
+        cyz += m[4];
+        czz += m[5];
     }
     cxx = wave_allsum(cxx); cxy = wave_allsum(cxy); cxz = wave_allsum(cxz);
     cyy = wave_allsum(cyy); cyz = wave_allsum(cyz); czz = wave_allsum(czz);
     if (lane == 0) {
+        const long long cnt = vn[v];
         double S[9] = {cxx, cxy, cxz, cxy, cyy, cyz, cxz, cyz, czz};  // M2 = sum (p-mu)(p-mu)^T (Welford's S, :41)
         double ent = 0.0;
         if (cnt > 10 && !raw) {  // (:47); raw = keep M2 undivided (multi-GPU partials)
@@ -125,10 +258,6 @@ k_voxel_gauss(const double *__restrict__ xyz, const unsigned int *__restrict__ p
                 ent = 0.5 * log(pow(2 * PI * exp(1.0), 3.0) * det);  // (:109)
             }
         }
-        vn[v] = (int) cnt;
-        vmu[3 * v] = mx;
-        vmu[3 * v + 1] = my;
-        vmu[3 * v + 2] = mz;
 #pragma unroll
         for (int k = 0; k < 9; ++k) vsig[9 * v + k] = S[k];
         vent[v] = ent;
@@ -554,61 +683,83 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
         return ME_OK;
     }
     ME_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!c.index_valid) ME_TRY(cloud_build_index(ctx, slot, c.cell_size_req));
     const long long n = c.n;
-    DevBuf &keys_in = ctx->tmp[0], &iota = ctx->tmp[1], &keys = ctx->tmp[2], &perm = ctx->tmp[3], &flags = ctx->tmp[4];
-    ME_CHECK(ctx, keys_in.ensure((size_t) n * 8));
-    ME_CHECK(ctx, iota.ensure((size_t) n * 4));
-    ME_CHECK(ctx, keys.ensure((size_t) n * 8));
-    ME_CHECK(ctx, perm.ensure((size_t) n * 4));
+    const long long nw = (n + 63) / 64;
+    const SPoint *sp = c.sp.as<SPoint>();
     ME_CHECK(ctx, ctx->red.ensure(64));
     int *d_err = ctx->red.as<int>();
     ME_CHECK(ctx, hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    // --- runs per wavefront -> record offsets ---
+    DevBuf &wbuf = ctx->tmp[0];
+    ME_CHECK(ctx, wbuf.ensure((size_t) nw * 8));
+    unsigned int *wave_runs = wbuf.as<unsigned int>(), *wave_off = wave_runs + nw;
     {
-        TimerScope ts(ctx, "voxel_keys");
-        hipLaunchKernelGGL(k_voxel_keys, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, voxel_size, c.slab,
-                           keys_in.as<unsigned long long>(), iota.as<unsigned int>(), d_err);
+        TimerScope ts(ctx, "voxel");
+        hipLaunchKernelGGL(k_vox_count_runs, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sp, n, voxel_size, c.slab, wave_runs, d_err);
     }
-    // radix sort is stable: cloud order is preserved inside every voxel
-    ME_TRY(sort_pairs_u64_u32(ctx, keys_in.as<unsigned long long>(), keys.as<unsigned long long>(), iota.as<unsigned int>(),
-                              perm.as<unsigned int>(), n, 0, 63));
-    // segment heads (keys_in / iota are dead -> reuse as flags / positions)
-    DevBuf &pos = ctx->tmp[1];
-    ME_CHECK(ctx, flags.ensure((size_t) n * 4));
-    hipLaunchKernelGGL(k_head_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream, keys.as<unsigned long long>(), n,
-                       flags.as<unsigned int>());
-    ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), n));
-    unsigned int last_pos = 0, last_flag = 0;
+    ME_TRY(exclusive_scan_u32(ctx, wave_runs, wave_off, nw));
+    unsigned int last_off = 0, last_runs = 0;
     int h_err = 0;
-    ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(&last_off, wave_off + (nw - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(&last_runs, wave_runs + (nw - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
     ME_CHECK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (h_err) return ctx->fail(ME_ERR_ARG, "voxel index out of range (|floor(p/voxel_size)| must be < 2^20)");
-    long long V = (long long) last_pos + last_flag;
-    if (c.slab.axis >= 0) {  // the halo points were keyed with the sentinel: their segment (the last one) is dropped
-        unsigned long long last_key = 0;
-        ME_CHECK(ctx, hipMemcpy(&last_key, keys.as<unsigned long long>() + (n - 1), 8, hipMemcpyDeviceToHost));
-        if (last_key == kVoxSentinel) V -= 1;
-    }
-    DevBuf &seg_start = ctx->tmp[0];
-    ME_CHECK(ctx, seg_start.ensure((size_t) (V + 1) * 4));
-    ME_CHECK(ctx, c.vox_key.ensure((size_t) (V + 1) * 8));
-    ME_CHECK(ctx, c.vox_n.ensure((size_t) V * 4));
-    ME_CHECK(ctx, c.vox_mu.ensure((size_t) V * 24));
-    ME_CHECK(ctx, c.vox_sigma.ensure((size_t) V * 72));
-    ME_CHECK(ctx, c.vox_entropy.ensure((size_t) V * 8));
-    hipLaunchKernelGGL(k_seg_scatter, dim3(grid_for(n)), dim3(256), 0, ctx->stream, keys.as<unsigned long long>(),
-                       flags.as<unsigned int>(), pos.as<unsigned int>(), n, c.vox_key.as<unsigned long long>(),
-                       seg_start.as<unsigned int>());
-    if (c.slab.axis < 0)  // (in slab mode entry V is the start of the dropped sentinel segment or, if none, set here)
-        hipLaunchKernelGGL(k_set_u32v, dim3(1), dim3(1), 0, ctx->stream, seg_start.as<unsigned int>(), V, (unsigned int) n);
-    else if (V == (long long) last_pos + last_flag)
-        hipLaunchKernelGGL(k_set_u32v, dim3(1), dim3(1), 0, ctx->stream, seg_start.as<unsigned int>(), V, (unsigned int) n);
+    const long long R = (long long) last_off + last_runs;  // run records
+    // --- pass 1: (key, n, sum p) per run ---
+    DevBuf &kbuf = ctx->tmp[1], &sbuf = ctx->tmp[2], &ibuf = ctx->tmp[3], &mbuf = ctx->tmp[4];  // (tmp[5]: sort/scan scratch)
+    ME_CHECK(ctx, kbuf.ensure((size_t) R * 16));          // rec_key | sorted keys
+    ME_CHECK(ctx, sbuf.ensure((size_t) R * 24));          // rec_sum
+    ME_CHECK(ctx, ibuf.ensure((size_t) R * 16));          // iota | perm_r | rec_n | rec_vox
+    ME_CHECK(ctx, mbuf.ensure((size_t) R * 48 + 64));     // rec_m2; before pass 2 also the head flags | positions
+    unsigned long long *rec_key = kbuf.as<unsigned long long>(), *skey = rec_key + R;
+    double *rec_sum = sbuf.as<double>(), *rec_m2 = mbuf.as<double>();
+    unsigned int *iota = ibuf.as<unsigned int>(), *perm_r = iota + R, *rec_vox = perm_r + 2 * R;
+    int *rec_n = reinterpret_cast<int *>(perm_r + R);
+    unsigned int *flags = mbuf.as<unsigned int>(), *pos = flags + R;
     {
         TimerScope ts(ctx, "voxel");
-        if (V > 0)
-            hipLaunchKernelGGL(k_voxel_gauss, dim3((unsigned int) ((V + 3) / 4)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
-                           perm.as<unsigned int>(), seg_start.as<unsigned int>(), V, raw ? 1 : 0, c.vox_n.as<int>(), c.vox_mu.as<double>(),
+        hipLaunchKernelGGL(k_vox_pass1, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sp, n, voxel_size, c.slab, wave_off, rec_key,
+                           iota, rec_n, rec_sum, d_err);
+    }
+    // radix sort is stable: Morton order is preserved inside every voxel (fixed summation order)
+    ME_TRY(sort_pairs_u64_u32(ctx, rec_key, skey, iota, perm_r, R, 0, 63));
+    hipLaunchKernelGGL(k_head_flags, dim3(grid_for(R)), dim3(256), 0, ctx->stream, skey, R, flags);
+    ME_TRY(exclusive_scan_u32(ctx, flags, pos, R));
+    unsigned int last_pos = 0, last_flag = 0;
+    unsigned long long last_key = 0;
+    ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos + (R - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags + (R - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(&last_key, skey + (R - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    long long V = (long long) last_pos + last_flag;
+    const bool has_sentinel = c.slab.axis >= 0 && last_key == kVoxSentinel;
+    if (has_sentinel) V -= 1;  // the halo points were keyed with the sentinel: their segment (the last one) is dropped
+    DevBuf &seg = wbuf;        // wave_runs is dead (wave_off lives in the upper half)
+    unsigned int *seg_start = wave_runs;
+    if ((size_t) (V + 2) * 4 > (size_t) nw * 4) {  // (V + 1 <= R <= n, but not necessarily <= nw)
+        ME_CHECK(ctx, c.vox_tmp.ensure((size_t) (V + 2) * 4));
+        seg_start = c.vox_tmp.as<unsigned int>();
+    }
+    (void) seg;
+    ME_CHECK(ctx, c.vox_key.ensure((size_t) (V + 1) * 8));
+    ME_CHECK(ctx, c.vox_n.ensure((size_t) std::max<long long>(V, 1) * 4));
+    ME_CHECK(ctx, c.vox_mu.ensure((size_t) std::max<long long>(V, 1) * 24));
+    ME_CHECK(ctx, c.vox_sigma.ensure((size_t) std::max<long long>(V, 1) * 72));
+    ME_CHECK(ctx, c.vox_entropy.ensure((size_t) std::max<long long>(V, 1) * 8));
+    hipLaunchKernelGGL(k_seg_scatter, dim3(grid_for(R)), dim3(256), 0, ctx->stream, skey, flags, pos, R,
+                       c.vox_key.as<unsigned long long>(), seg_start);
+    if (!has_sentinel)  // (with a sentinel segment, entry V is its start, written by the scatter)
+        hipLaunchKernelGGL(k_set_u32v, dim3(1), dim3(1), 0, ctx->stream, seg_start, V, (unsigned int) R);
+    if (V > 0) {
+        TimerScope ts(ctx, "voxel");
+        const dim3 gv((unsigned int) ((V + 3) / 4));
+        hipLaunchKernelGGL(k_vox_mean, gv, dim3(256), 0, ctx->stream, perm_r, seg_start, V, rec_n, rec_sum, rec_vox, c.vox_n.as<int>(),
+                           c.vox_mu.as<double>());
+        hipLaunchKernelGGL(k_vox_pass2, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sp, n, voxel_size, c.slab, wave_off, rec_vox,
+                           c.vox_mu.as<double>(), rec_m2, d_err);
+        hipLaunchKernelGGL(k_vox_final, gv, dim3(256), 0, ctx->stream, perm_r, seg_start, V, rec_m2, c.vox_n.as<int>(), raw ? 1 : 0,
                            c.vox_sigma.as<double>(), c.vox_entropy.as<double>());
     }
     ME_CHECK(ctx, hipGetLastError());
