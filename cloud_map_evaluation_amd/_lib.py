@@ -19,7 +19,7 @@ SYMBOLS = [
     "me_nn_unresolved", "me_nn_points", "me_nn_patch", "me_voxel_partials",
     "me_upload_cloud", "me_upload_cloud_device", "me_cloud_size", "me_download_cloud", "me_voxel_downsample",
     "me_transform_cloud",
-    "me_nn1", "me_icp_p2p_sums", "me_nn_stats", "me_nn_partial_sums", "me_nn_sigma_sums", "me_nn_finalize", "me_chamfer",
+    "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats", "me_nn_partial_sums", "me_nn_sigma_sums", "me_nn_finalize", "me_chamfer",
     "me_mme", "me_voxel_gaussians", "me_awd_scs", "me_w2_batch", "me_scs_table", "me_run_suite",
     "me_timers_enable", "me_timers_reset", "me_timer_get",
 ]
@@ -129,6 +129,11 @@ def load():
     L.me_nn1.argtypes = [vp, C.c_int, C.c_int, ip, dp]
     L.me_icp_p2p_sums.argtypes = [vp, C.c_int, C.c_double, C.POINTER(IcpSums)]
     L.me_icp_p2p_sums.restype = C.c_int
+    L.me_render_distance.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp]
+    L.me_render_distance.restype = C.c_int
+    L.me_render_entropy.argtypes = [vp, C.c_int, vp, vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double)]
+    L.me_render_entropy.restype = C.c_int
     L.me_nn_stats.argtypes = [vp, C.c_int, C.c_double, C.c_int, dp, C.POINTER(NNStatsOut)]
     L.me_nn_partial_sums.argtypes = [vp, C.c_int, C.c_double, C.c_int, dp, C.POINTER(NNPartial)]
     L.me_nn_sigma_sums.argtypes = [vp, C.c_int, C.c_double, C.c_int, dp, dp]
@@ -145,7 +150,7 @@ def load():
     L.me_timers_enable.argtypes = [vp, C.c_int]
     L.me_timers_reset.argtypes = [vp]
     L.me_timer_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    for f in ("me_voxel_downsample", "me_transform_cloud", "me_set_slab", "me_nn_unresolved", "me_nn_points", "me_nn_patch", "me_voxel_partials", "me_set_shard", "me_upload_cloud", "me_upload_cloud_device", "me_download_cloud", "me_nn1", "me_icp_p2p_sums", "me_nn_stats",
+    for f in ("me_voxel_downsample", "me_transform_cloud", "me_set_slab", "me_nn_unresolved", "me_nn_points", "me_nn_patch", "me_voxel_partials", "me_set_shard", "me_upload_cloud", "me_upload_cloud_device", "me_download_cloud", "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats",
               "me_nn_partial_sums", "me_nn_sigma_sums", "me_chamfer", "me_mme", "me_voxel_gaussians", "me_awd_scs",
               "me_run_suite", "me_w2_batch", "me_scs_table", "me_timers_enable", "me_timers_reset", "me_timer_get"):
         getattr(L, f).restype = C.c_int

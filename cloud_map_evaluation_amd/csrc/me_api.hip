@@ -159,6 +159,20 @@ int me_icp_p2p_sums(me_ctx *ctx, int query_slot, double max_distance, me_icp_sum
     return me::icp_p2p_sums(ctx, query_slot, max_distance, out);
 }
 
+int me_render_distance(me_ctx *ctx, int query_slot, double dis, double gate, int gate_mode, double *rgb, uint8_t *inlier) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::render_distance(ctx, query_slot, dis, gate, gate_mode, rgb, inlier);
+}
+
+int me_render_entropy(me_ctx *ctx, int slot, double *xyz, double *rgb, int64_t capacity, int64_t *n_valid, double *min_abs,
+                      double *max_abs) {
+    if (!ctx) return ME_ERR_ARG;
+    long long nv = 0;
+    const int rc = me::render_entropy(ctx, slot, xyz, rgb, capacity, &nv, min_abs, max_abs);
+    if (n_valid) *n_valid = nv;
+    return rc;
+}
+
 int me_nn_partial_sums(me_ctx *ctx, int query_slot, double gate, int gate_mode, const double trunc[5], me_nn_partial *out) {
     if (!ctx) return ME_ERR_ARG;
     return me::nn_partial(ctx, query_slot, gate, gate_mode, trunc, out);

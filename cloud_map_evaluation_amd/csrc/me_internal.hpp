@@ -139,6 +139,8 @@ struct Cloud {
     double vox_size = 0;
     long long n_vox = 0;
     bool vox_valid = false, vox_raw = false;
+    DevBuf mme_ent, mme_val;  // last me_mme of this cloud, Morton order: entropy (0 where invalid), validity byte
+    bool mme_have = false;
     DevBuf vox_tmp;    // build scratch (segment starts when they outgrow the shared scratch)
     DevBuf vox_key;    // uint64[V] packed key
     DevBuf vox_n;      // int32[V]
@@ -240,6 +242,11 @@ int nn_sigma(me_ctx *ctx, int qslot, double gate, int gate_mode, const double me
 // ---- me_mme.hip ----
 int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, uint8_t *valid, double *sum_H,
             long long *n_valid);
+
+// ---- me_render.hip ----
+int render_distance(me_ctx *ctx, int qslot, double dis, double gate, int gate_mode, double *rgb, uint8_t *inlier);
+int render_entropy(me_ctx *ctx, int slot, double *xyz_out, double *rgb_out, long long capacity, long long *n_valid,
+                   double *min_abs_out, double *max_abs_out);
 
 // ---- me_voxel.hip ----
 int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw);

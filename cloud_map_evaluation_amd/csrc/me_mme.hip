@@ -204,7 +204,8 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     const long long n = c.n;
     long long b, e;
     ctx->shard_range(n, b, e);
-    DevBuf &ent_s = ctx->tmp[0], &val_s = ctx->tmp[1];
+    DevBuf &ent_s = c.mme_ent, &val_s = c.mme_val;  // kept for me_render_entropy
+    c.mme_have = false;
     ME_CHECK(ctx, ent_s.ensure((size_t) n * 8));
     ME_CHECK(ctx, val_s.ensure((size_t) n));
     const unsigned int nb = (unsigned int) std::max<long long>(8, ((e - b + 255) / 256 + 7) / 8 * 8);
@@ -246,6 +247,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
+    c.mme_have = true;
     if (sum_H) *sum_H = hs;
     if (n_valid) *n_valid = hc;
     return ME_OK;

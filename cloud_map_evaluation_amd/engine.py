@@ -175,6 +175,24 @@ class Engine:
         self._ck(self._L.me_icp_p2p_sums(self._ctx, query_slot, float(max_distance), C.byref(out)))
         return out
 
+    def renderDistanceOnPointCloud(self, query_slot: int, dis: float, gate: float = -1.0, gate_mode: int = 0):
+        """map_eval.cpp:586-607 for the last nn1(query_slot, ...) -> (rgb (N,3), inlier (N,) bool)."""
+        n = self.size(query_slot)
+        rgb = np.empty((n, 3), np.float64)
+        inl = np.empty(n, np.uint8)
+        self._ck(self._L.me_render_distance(self._ctx, query_slot, float(dis), float(gate), int(gate_mode), _addr(rgb), _addr(inl)))
+        return rgb, inl.astype(bool)
+
+    def ColorPointCloudByMME(self, slot: int):
+        """map_eval.cpp:686-735 for the last mme(slot) -> (xyz_valid (M,3), rgb (M,3), min_abs, max_abs)."""
+        m, mn, mx = C.c_int64(0), C.c_double(), C.c_double()
+        self._ck(self._L.me_render_entropy(self._ctx, slot, 0, 0, 0, C.byref(m), C.byref(mn), C.byref(mx)))
+        xyz = np.empty((m.value, 3), np.float64)
+        rgb = np.empty((m.value, 3), np.float64)
+        if m.value:
+            self._ck(self._L.me_render_entropy(self._ctx, slot, _addr(xyz), _addr(rgb), m.value, C.byref(m), C.byref(mn), C.byref(mx)))
+        return xyz, rgb, mn.value, mx.value
+
     def performICPRegistration(self, max_distance: float, **criteria):
         """map_eval.cpp:1369-1371, registration_methods 0 (point-to-point); see icp.icp_point_to_point."""
         from .icp import icp_point_to_point

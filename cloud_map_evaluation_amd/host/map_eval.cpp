@@ -421,6 +421,37 @@ void MapEval::calculateMetrics() {
     std::cout << "INFO: Full Chamfer distance: " << full_chamfer_dist << std::endl;
 }
 
+// open3d ColorToUint8 + the packed-float rgb column of open3d::io::WritePointCloud(.pcd)
+static std::vector<float> pack_rgb(const std::vector<double> &rgb) {
+    std::vector<float> out(rgb.size() / 3);
+    for (size_t i = 0; i < out.size(); ++i) {
+        uint32_t c[3];
+        for (int k = 0; k < 3; ++k) c[k] = (uint32_t) std::round(std::min(1.0, std::max(0.0, rgb[3 * i + k])) * 255.0);
+        const uint32_t packed = (c[0] << 16) | (c[1] << 8) | c[2];
+        std::memcpy(&out[i], &packed, 4);
+    }
+    return out;
+}
+
+// ColorPointCloudByMME(cloud, entropies) (map_eval.cpp:686-735) from the entropies the last me_mme left on the device
+bool MapEval::renderEntropy(int slot, std::vector<double> &xyz, std::vector<double> &rgb, bool want_points) {
+    int64_t m = 0;
+    if (me_render_entropy(ctx_, slot, nullptr, nullptr, 0, &m, &min_abs_entropy, &max_abs_entropy) != ME_OK) {
+        fail(me_last_error(ctx_));
+        return false;
+    }
+    xyz.clear();
+    rgb.clear();
+    if (!want_points || m == 0) return true;
+    xyz.resize((size_t) m * 3);
+    rgb.resize((size_t) m * 3);
+    if (me_render_entropy(ctx_, slot, xyz.data(), rgb.data(), m, &m, &min_abs_entropy, &max_abs_entropy) != ME_OK) {
+        fail(me_last_error(ctx_));
+        return false;
+    }
+    return true;
+}
+
 void MapEval::computeMME(PointCloud &cloud, PointCloud &gt) {
     // est: ComputeMeanMapEntropyUsingNormal[TBB] k >= 10 (map_eval.cpp:1675); gt: ComputeMeanMapEntropy k >= 5 (:1458)
     est_entropies.assign(cloud.size(), 0.0);
@@ -432,6 +463,8 @@ void MapEval::computeMME(PointCloud &cloud, PointCloud &gt) {
         return;
     }
     mme_est = nv > 0 ? s / (double) nv : 0.0;
+    // map_3d_entropy = ColorPointCloudByMME(map_3d_, est_entropies) (:136, :179) — on the device, from the entropies it holds
+    if (!renderEntropy(ME_SLOT_EST, map_entropy_xyz, map_entropy_rgb, param_.save_immediate_result_)) return;
     if (param_.enable_debug)
         std::cout << "TBB MME Valid_points " << nv * 100.0 / (double) cloud.size() << "% " << nv << " " << cloud.size() << std::endl;
     if (nv * 100.0 / (double) cloud.size() < 0.6) std::cerr << "valid points is too small, please check the input point cloud" << std::endl;
@@ -443,6 +476,9 @@ void MapEval::computeMME(PointCloud &cloud, PointCloud &gt) {
             return;
         }
         mme_gt = nv > 0 ? s / (double) nv : 0.0;
+        // gt_3d_entropy = ColorPointCloudByMME(gt_3d_, gt_entropies) (:139, :181); like the reference, this call overwrites
+        // min/max_abs_entropy with the GT range (they are members there, :698-699)
+        if (!renderEntropy(ME_SLOT_GT, gt_entropy_xyz, gt_entropy_rgb, param_.save_immediate_result_)) return;
         std::cout << "MME EST-GT: " << mme_est << " " << mme_gt << std::endl;
     } else {
         std::cout << "MME EST: " << mme_est << std::endl;
@@ -551,8 +587,16 @@ void MapEval::saveMmeResults() {
     if (!param_.evaluate_mme_) return;
     file_result << std::fixed << std::setprecision(5) << "MME: " << mme_est << " " << mme_gt << " " << min_abs_entropy << " "
                 << max_abs_entropy << std::endl;  // (:395-396)
-    // map_entropy.pcd / gt_entropy.pcd are colour renderings (ColorPointCloudByMME) — out of scope; the raw entropies
-    // are written instead so that nothing is lost.
+    // map_entropy.pcd / gt_entropy.pcd (:404, :412): valid points + Jet colour of the log-mapped entropy
+    pcio::write_pcd(results_subfolder + "map_entropy.pcd", map_entropy_xyz.data(), map_entropy_xyz.size() / 3,
+                    pack_rgb(map_entropy_rgb).data());
+    std::cout << "INFO: Saved rendered entropy map to " << results_subfolder + "map_entropy.pcd" << std::endl;
+    if (param_.evaluate_gt_mme_) {
+        pcio::write_pcd(results_subfolder + "gt_entropy.pcd", gt_entropy_xyz.data(), gt_entropy_xyz.size() / 3,
+                        pack_rgb(gt_entropy_rgb).data());
+        std::cout << "INFO: Saved rendered entropy ground truth map to " << results_subfolder + "gt_entropy.pcd" << std::endl;
+    }
+    // (extra) the raw per-point entropies, so that nothing is lost to the colour map
     std::ofstream e(results_subfolder + "map_entropy.txt");
     for (size_t i = 0; i < est_entropies.size(); ++i) e << est_entropies[i] << " " << (int) valid_entropy_points[i] << "\n";
 }
@@ -577,4 +621,30 @@ void MapEval::saveRegistrationResults() {
     file_result << "AWD+SCS Time: " << t_v / 1000.0 + (t_vmd - t_v) / 1000.0 + (t_scs - t_cdf) / 1000.0 << std::endl;
     file_result.close();
     if (param_.enable_debug) std::cout << "INFO: Results saved to " << results_subfolder + "map_results.txt" << std::endl;
+    // raw_rendered_dis_map.pcd / inlier_rendered_dis_map.pcd (:485-495): the map coloured by min(d2, trunc[0]) / trunc[0]
+    // (renderDistanceOnPointCloud, :586-607).  The reference runs a serial KD-tree pass for it; the squared distances of
+    // the est -> gt search are still on the device.  Inlier cloud = corresponding_cloud_est, the gated rows (:1086-1087).
+    {
+        const size_t n = map_3d_->size();
+        std::vector<double> rgb(n * 3);
+        std::vector<uint8_t> inl(n);
+        const int mode = param_.evaluate_using_initial_ ? ME_GATE_LE_UNSQUARED : ME_GATE_LT_SQUARED;
+        if (me_render_distance(ctx_, ME_SLOT_EST, param_.trunc_dist_[0], param_.icp_max_distance_, mode, rgb.data(), inl.data()) !=
+            ME_OK) {
+            fail(me_last_error(ctx_));
+            return;
+        }
+        pcio::write_pcd(results_subfolder + "raw_rendered_dis_map.pcd", map_3d_->points_.data(), n, pack_rgb(rgb).data());
+        std::vector<double> ixyz, irgb;
+        for (size_t i = 0; i < n; ++i)
+            if (inl[i])
+                for (int k = 0; k < 3; ++k) {
+                    ixyz.push_back(map_3d_->points_[3 * i + k]);
+                    irgb.push_back(rgb[3 * i + k]);
+                }
+        pcio::write_pcd(results_subfolder + "inlier_rendered_dis_map.pcd", ixyz.data(), ixyz.size() / 3, pack_rgb(irgb).data());
+        if (param_.enable_debug)
+            std::cout << "INFO: Saved raw / inlier distance error maps to " << results_subfolder << "{raw,inlier}_rendered_dis_map.pcd"
+                      << std::endl;
+    }
 }

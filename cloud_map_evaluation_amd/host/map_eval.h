@@ -65,6 +65,7 @@ public:
     void calculateMetrics();                               // map_eval.cpp:1147-1202
     double computeChamferDistance();                       // map_eval.cpp:1398-1431
     void calculateVMD();                                   // map_eval.cpp:240-390
+    bool renderEntropy(int slot, std::vector<double> &xyz, std::vector<double> &rgb, bool want_points);  // :686-735
     void saveMmeResults();                                 // map_eval.cpp:392-421
     void saveRegistrationResults();                        // map_eval.cpp:424-482 (text lines; renderers out of scope)
 
@@ -77,6 +78,7 @@ public:
     double mme_est = 0.0, mme_gt = 0.0, max_abs_entropy = 0.0, min_abs_entropy = 0.0;
     std::vector<double> est_entropies, gt_entropies;
     std::vector<uint8_t> valid_entropy_points;
+    std::vector<double> map_entropy_xyz, map_entropy_rgb, gt_entropy_xyz, gt_entropy_rgb;  // map_3d_entropy / gt_3d_entropy (:330)
     std::string last_error;
 
 private:

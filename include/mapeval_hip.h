@@ -162,6 +162,19 @@ typedef struct me_icp_sums {
 } me_icp_sums;
 int me_icp_p2p_sums(me_ctx *ctx, int query_slot, double max_distance, me_icp_sums *out);
 
+/* renderDistanceOnPointCloud (map_eval.cpp:586-607; raw_rendered_dis_map.pcd / inlier_rendered_dis_map.pcd, :485-495) for
+ * the queries of the last me_nn1(query_slot, ...): rgb[N][3] in the caller's cloud order = ColorMapJet(min(d2, dis) / dis)
+ * (the SQUARED distance against the unsquared `dis`, as the reference does; it repeats a serial KD-tree pass for it,
+ * computePointCloudDistance :568-584 — the numbers are those of me_nn1).  inlier[N] (optional) = the gate of me_nn_stats,
+ * i.e. the rows of corresponding_cloud_est (:1086-1087): their colours are the inlier rendering. */
+int me_render_distance(me_ctx *ctx, int query_slot, double dis, double gate, int gate_mode, double *rgb, uint8_t *inlier);
+
+/* ColorPointCloudByMME(pointcloud, entropies) (map_eval.cpp:686-735; map_entropy.pcd / gt_entropy.pcd) from the last
+ * me_mme(slot): the VALID points in cloud order with their Jet colour of the log-mapped normalised |entropy|; range =
+ * (|max|, |min|) over the non-zero entropies (:696-699).  xyz = rgb = NULL: count and range only. */
+int me_render_entropy(me_ctx *ctx, int slot, double *xyz, double *rgb, int64_t capacity, int64_t *n_valid, double *min_abs,
+                      double *max_abs);
+
 /* computeChamferDistance (map_eval.cpp:1398-1431): both directions, no gate.  Runs me_nn1 both ways. */
 int me_chamfer(me_ctx *ctx, double *cd);
 

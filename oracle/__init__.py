@@ -93,6 +93,10 @@ def lib():
         L.orc_awd_scs.restype = C.c_int
         L.orc_awd_scs.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, dp, dp,
                                   C.POINTER(C.c_int64), dp, dp, C.POINTER(C.c_int64)]
+        L.orc_jet_color.argtypes = [C.c_double, dp]
+        L.orc_render_distance.argtypes = [dp, C.c_int64, C.c_double, dp]
+        L.orc_render_entropy.restype = C.c_int64
+        L.orc_render_entropy.argtypes = [dp, dp, C.POINTER(C.c_uint8), C.c_int64, dp, dp, C.c_int64, dp, dp]
         L.orc_scs.restype = C.c_double
         L.orc_scs.argtypes = [ip, dp, C.c_int64, C.c_int]
         _lib = L
@@ -231,3 +235,31 @@ def scs(keys, w, radius: int = 5) -> float:
     keys = np.ascontiguousarray(keys, dtype=np.int32)
     w = np.ascontiguousarray(w, dtype=np.float64)
     return lib().orc_scs(_ip(keys), _dp(w), w.shape[0], radius)
+
+
+def jet_color(value: float) -> np.ndarray:
+    """open3d ColorMapJet.GetColor [upstream]."""
+    out = np.empty(3, np.float64)
+    lib().orc_jet_color(float(value), _dp(out))
+    return out
+
+
+def render_distance(d2, dis: float) -> np.ndarray:
+    """renderDistanceOnPointCloud (map_eval.cpp:586-607): squared NN distances -> (N,3) Jet colours."""
+    d2 = np.ascontiguousarray(d2, dtype=np.float64)
+    out = np.empty((d2.shape[0], 3), np.float64)
+    lib().orc_render_distance(_dp(d2), d2.shape[0], float(dis), _dp(out))
+    return out
+
+
+def render_entropy(xyz, entropies, valid):
+    """ColorPointCloudByMME(pointcloud, entropies) (map_eval.cpp:686-735) -> (xyz_valid, rgb, min_abs, max_abs)."""
+    xyz = _pts(xyz)
+    ent = np.ascontiguousarray(entropies, dtype=np.float64)
+    val = np.ascontiguousarray(valid, dtype=np.uint8)
+    vp = val.ctypes.data_as(C.POINTER(C.c_uint8))
+    mn, mx = C.c_double(), C.c_double()
+    m = lib().orc_render_entropy(_dp(xyz), _dp(ent), vp, xyz.shape[0], None, None, 0, C.byref(mn), C.byref(mx))
+    xo, co = np.empty((m, 3), np.float64), np.empty((m, 3), np.float64)
+    lib().orc_render_entropy(_dp(xyz), _dp(ent), vp, xyz.shape[0], _dp(xo), _dp(co), m, C.byref(mn), C.byref(mx))
+    return xo, co, mn.value, mx.value

@@ -869,4 +869,67 @@ int64_t orc_voxel_downsample(const double *xyz, int64_t n, double voxel_size, do
     return (int64_t) v.size();
 }
 
+// ---- renderers (map_eval.cpp:586-607, :686-735) --------------------------------------------------------------
+// open3d::visualization::ColorMapJet::GetColor [Open3D ColorMap.h/.cpp, upstream — not in the reference tree]:
+//   (JetBase(2v - 1.5), JetBase(2v - 1.0), JetBase(2v - 0.5)), JetBase piecewise linear with
+//   ColorMap::Interpolate(value, y0, x0, y1, x1) = (value - x0) * (y1 - y0) / (x1 - x0) + y0, clamped to [y0, y1] outside.
+static double jet_interpolate(double value, double y0, double x0, double y1, double x1) {
+    if (value < x0) return y0;
+    if (value > x1) return y1;
+    return (value - x0) * (y1 - y0) / (x1 - x0) + y0;
+}
+static double jet_base(double value) {
+    if (value <= -0.75) return 0.0;
+    if (value <= -0.25) return jet_interpolate(value, 0.0, -0.75, 1.0, -0.25);
+    if (value <= 0.25) return 1.0;
+    if (value <= 0.75) return jet_interpolate(value, 1.0, 0.25, 0.0, 0.75);
+    return 0.0;
+}
+void orc_jet_color(double value, double rgb[3]) {
+    rgb[0] = jet_base(value * 2.0 - 1.5);
+    rgb[1] = jet_base(value * 2.0 - 1.0);
+    rgb[2] = jet_base(value * 2.0 - 0.5);
+}
+
+// renderDistanceOnPointCloud (:586-607): eval_dis = SQUARED NN distance (SearchKNN returns d2, :579-580), clamped to
+// `dis` (the unsquared truncation distance, sic), a = eval_dis / dis, colour = Jet(a).  d2[n] -> rgb[n][3].
+void orc_render_distance(const double *d2, int64_t n, double dis, double *rgb) {
+    for (int64_t i = 0; i < n; ++i) {
+        double e = d2[i];
+        if (e > dis) e = dis;  // (:591-595)
+        orc_jet_color(e / dis, rgb + 3 * i);  // (:601-603)
+    }
+}
+
+// ColorPointCloudByMME(pointcloud, entropies) (:686-735): range over the non-zero entropies (max_abs = |min|, min_abs =
+// |max|, :696-699), then for the VALID points only, in cloud order: normalise |H|, log-map with epsilon 0.1, Jet.
+// xyz_out / rgb_out: capacity rows of 3 (may be NULL to count).  Returns the number of valid points.
+int64_t orc_render_entropy(const double *xyz, const double *entropies, const uint8_t *valid, int64_t n, double *xyz_out,
+                           double *rgb_out, int64_t capacity, double *min_abs_out, double *max_abs_out) {
+    double mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = 0; i < n; ++i)
+        if (entropies[i] != 0.0) {
+            mn = std::min(mn, entropies[i]);
+            mx = std::max(mx, entropies[i]);
+        }
+    const double max_abs = std::fabs(mn), min_abs = std::fabs(mx);
+    if (min_abs_out) *min_abs_out = min_abs;
+    if (max_abs_out) *max_abs_out = max_abs;
+    const double epsilon = 1e-1;
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!valid[i]) continue;
+        if (xyz_out && rgb_out && m < capacity) {
+            double ne = (std::fabs(entropies[i]) - min_abs) / (max_abs - min_abs);      // (:714-715)
+            const double mapped = std::log(ne + epsilon);                               // (:719)
+            ne = (mapped - std::log(epsilon)) / (std::log(1.0 + epsilon) - std::log(epsilon));  // (:721)
+            orc_jet_color(ne, rgb_out + 3 * m);
+            for (int d = 0; d < 3; ++d) xyz_out[3 * m + d] = xyz[3 * i + d];
+        }
+        ++m;
+    }
+    return m;
+}
+
+
 }  // extern "C"

@@ -98,6 +98,13 @@ int orc_awd_scs(const orc_voxelmap *gt, const orc_voxelmap *est, double voxel_si
 /* SCS alone from a sparse W table (map_eval.cpp:347-389): keys[n][3], w[n]. */
 double orc_scs(const int32_t *keys, const double *w, int64_t n, int radius);
 
+/* ---- renderers: Open3D ColorMapJet [upstream]; renderDistanceOnPointCloud (map_eval.cpp:586-607);
+ *      ColorPointCloudByMME(pointcloud, entropies) (map_eval.cpp:686-735) ---- */
+void orc_jet_color(double value, double rgb[3]);
+void orc_render_distance(const double *d2, int64_t n, double dis, double *rgb);
+int64_t orc_render_entropy(const double *xyz, const double *entropies, const uint8_t *valid, int64_t n, double *xyz_out,
+                           double *rgb_out, int64_t capacity, double *min_abs_out, double *max_abs_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,176 @@
+"""Renderers: distance / entropy colour maps computed on the device from the arrays the metric
+kernels left there, against the oracle's restatement of renderDistanceOnPointCloud (map_eval.cpp:586-607),
+ColorPointCloudByMME (map_eval.cpp:686-735) and Open3D's ColorMapJet; plus the PCD files the host writes."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "cloud_map_evaluation_amd", "host", "map_eval")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from cloud_map_evaluation_amd.engine import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.campus_pair(80_000, seed=21)
+    return est.numpy(), gt.numpy()
+
+
+@pytest.mark.parametrize("gate,mode", [(0.05, 0), (0.2, 1), (-1.0, 0)])
+def test_render_distance_bit_exact(eng, pair, gate, mode):
+    import oracle
+
+    est, gt = pair
+    eng.upload(0, est)
+    eng.upload(1, gt)
+    _, d2 = eng.nn1(0, 1)
+    rgb, inl = eng.renderDistanceOnPointCloud(0, 0.2, gate, mode)
+    assert np.array_equal(rgb, oracle.render_distance(d2, 0.2))  # same IEEE operations on both sides: bit-exact
+    exp = np.ones(len(d2), bool) if gate < 0 else (d2 <= gate if mode == 0 else d2 < gate * gate)
+    assert np.array_equal(inl, exp)
+    assert rgb.min() >= 0.0 and rgb.max() <= 1.0 and len(np.unique(rgb, axis=0)) > 100
+
+
+def test_render_distance_needs_a_search_first(eng, pair):
+    from cloud_map_evaluation_amd.engine import MapEvalError
+
+    est, _ = pair
+    eng.upload(0, est)  # a fresh upload discards the previous search
+    with pytest.raises(MapEvalError):
+        eng.renderDistanceOnPointCloud(0, 0.2)
+
+
+@pytest.mark.parametrize("min_k", [10, 5])
+def test_render_entropy_parity(eng, pair, min_k):
+    import oracle
+
+    est, _ = pair
+    eng.upload(0, est, cell_size=0.1)
+    res = eng.mme(0, 0.1, min_k)
+    xyz, rgb, mn, mx = eng.ColorPointCloudByMME(0)
+    _, o_ent, o_valid, _, _ = oracle.mme(est, 0.1, min_k)
+    oxyz, orgb, omn, omx = oracle.render_entropy(est, o_ent, o_valid)
+    assert len(xyz) == len(oxyz) == int(o_valid.sum()) == res[3]
+    assert np.array_equal(xyz, oxyz)  # the valid points, in cloud order
+    np.testing.assert_allclose([mn, mx], [omn, omx], rtol=1e-12)
+    np.testing.assert_allclose(rgb, orgb, rtol=0, atol=1e-9)
+    assert len(np.unique(np.round(rgb, 6), axis=0)) > 50
+
+
+def test_render_entropy_is_discarded_by_a_transform(eng, pair):
+    from cloud_map_evaluation_amd.engine import MapEvalError
+
+    est, _ = pair
+    eng.upload(0, est, cell_size=0.1)
+    eng.mme(0, 0.1, 10, per_point=False)
+    eng.ColorPointCloudByMME(0)
+    T = np.eye(4)
+    T[0, 3] = 1.0
+    eng.transform_cloud(0, T)  # re-sorts the cloud: the per-point entropies no longer line up
+    with pytest.raises(MapEvalError):
+        eng.ColorPointCloudByMME(0)
+
+
+def _read_pcd_xyz_rgb(path):
+    raw = open(path, "rb").read()
+    head, _, body = raw.partition(b"DATA binary\n")
+    hdr = {l.split()[0]: l.split()[1:] for l in head.decode().splitlines() if l and not l.startswith("#")}
+    assert hdr["FIELDS"] == ["x", "y", "z", "rgb"], hdr
+    sizes = [int(s) for s in hdr["SIZE"]]
+    n = int(hdr["POINTS"][0])
+    stride = sum(sizes)
+    fmt = {8: "d", 4: "f"}
+    xyz = np.empty((n, 3))
+    rgb = np.empty((n, 3), np.uint8)
+    for i in range(n):
+        rec = body[i * stride:(i + 1) * stride]
+        x, y, z = struct.unpack("<" + "".join(fmt[s] for s in sizes[:3]), rec[:sum(sizes[:3])])
+        (packed,) = struct.unpack("<I", rec[sum(sizes[:3]):])
+        xyz[i] = (x, y, z)
+        rgb[i] = ((packed >> 16) & 255, (packed >> 8) & 255, packed & 255)
+    return xyz, rgb
+
+
+def test_host_writes_the_rendered_pcds(tmp_path):
+    """save_immediate_result: the host writes raw / inlier distance maps (map_eval.cpp:485-495) and the entropy maps
+    (:404, :412) as PCD files with a packed rgb column, like open3d::io::WritePointCloud."""
+    import oracle
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.cube_pair(20_000, seed=13)
+    est, gt = est.numpy(), gt.numpy()
+    est_dir = tmp_path / "est"
+    est_dir.mkdir()
+
+    def write_pcd(path, pts):
+        hdr = (f"# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 8 8 8\nTYPE F F F\nCOUNT 1 1 1\nWIDTH {len(pts)}\nHEIGHT 1\n"
+               f"VIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(pts)}\nDATA binary\n")
+        with open(path, "wb") as f:
+            f.write(hdr.encode())
+            f.write(np.ascontiguousarray(pts, dtype="<f8").tobytes())
+
+    write_pcd(est_dir / "map.pcd", est)
+    write_pcd(tmp_path / "gt.pcd", gt)
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(f"""registration_methods: 2
+icp_max_distance: 0.002
+accuracy_level: [0.2, 0.1, 0.08, 0.05, 0.01]
+initial_matrix:
+  - [1.0, 0.0, 0.0, 0.0]
+  - [0.0, 1.0, 0.0, 0.0]
+  - [0.0, 0.0, 1.0, 0.0]
+  - [0.0, 0.0, 0.0, 1.0]
+estimate_map_path: {est_dir}
+gt_map_path: {tmp_path / 'gt.pcd'}
+scene_name: cube_render
+save_immediate_result: true
+evaluate_mme: true
+evaluate_gt_mme: true
+nn_radius: 0.1
+evaluate_using_initial: true
+evaluate_noise_gt: false
+vmd_voxel_size: 0.5
+downsample_size: 0.0
+use_visualization: false
+enable_debug: true
+""")
+    r = subprocess.run([EXE, str(cfg)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = est_dir / "map_results"
+
+    def u8(c):  # open3d ColorToUint8
+        return np.round(np.clip(c, 0.0, 1.0) * 255.0).astype(np.uint8)
+
+    _, d2 = oracle.nn1(gt, est)
+    col = oracle.render_distance(d2, 0.2)
+    xyz, rgb = _read_pcd_xyz_rgb(out / "raw_rendered_dis_map.pcd")
+    assert np.array_equal(xyz, est) and np.array_equal(rgb, u8(col))
+    inl = d2 <= 0.002  # the (sic) gate of calculateMetricsWithInitialMatrix (:1219)
+    assert 0 < inl.sum() < len(est)
+    xyz, rgb = _read_pcd_xyz_rgb(out / "inlier_rendered_dis_map.pcd")
+    assert np.array_equal(xyz, est[inl]) and np.array_equal(rgb, u8(col[inl]))
+
+    for name, cloud, k in (("map_entropy.pcd", est, 10), ("gt_entropy.pcd", gt, 5)):
+        _, ent, valid, _, _ = oracle.mme(cloud, 0.1, k)
+        oxyz, orgb, _, _ = oracle.render_entropy(cloud, ent, valid)
+        xyz, rgb = _read_pcd_xyz_rgb(out / name)
+        assert np.array_equal(xyz, oxyz)
+        assert np.abs(rgb.astype(int) - u8(orgb).astype(int)).max() <= 1  # log() may differ in the last ulp

@@ -121,3 +121,39 @@ def test_mme_modes_agree_and_no_valid_points():
     assert r0[3] == r1[3] == r2[3]
     sparse = oracle.mme(p[:50] * 100, 0.1, 10)
     assert sparse[0] == 0.0 and sparse[3] == 0  # returns 0 when nothing is valid (map_eval.cpp:1720-1724)
+
+
+# ---- renderers (map_eval.cpp:586-607, :686-735; Open3D ColorMapJet) ----
+def test_jet_colormap_known_values():
+    """ColorMapJet [Open3D]: dark blue -> cyan -> green-ish -> yellow -> dark red; piecewise linear, clamped."""
+    np.testing.assert_allclose(oracle.jet_color(0.0), [0.0, 0.0, 0.5])
+    np.testing.assert_allclose(oracle.jet_color(0.125), [0.0, 0.0, 1.0])
+    np.testing.assert_allclose(oracle.jet_color(0.375), [0.0, 1.0, 1.0])
+    np.testing.assert_allclose(oracle.jet_color(0.5), [0.5, 1.0, 0.5])
+    np.testing.assert_allclose(oracle.jet_color(0.625), [1.0, 1.0, 0.0])
+    np.testing.assert_allclose(oracle.jet_color(0.875), [1.0, 0.0, 0.0])
+    np.testing.assert_allclose(oracle.jet_color(1.0), [0.5, 0.0, 0.0])
+    np.testing.assert_allclose(oracle.jet_color(-3.0), [0.0, 0.0, 0.0])
+    np.testing.assert_allclose(oracle.jet_color(7.0), [0.0, 0.0, 0.0])
+
+
+def test_render_distance_clamps_squared_distance_against_unsquared_threshold():
+    d2 = np.array([0.0, 0.05, 0.2, 0.3, 4.0])
+    rgb = oracle.render_distance(d2, 0.2)
+    for i, v in enumerate([0.0, 0.25, 1.0, 1.0, 1.0]):  # min(d2, dis) / dis (map_eval.cpp:591-603)
+        np.testing.assert_allclose(rgb[i], oracle.jet_color(v))
+
+
+def test_render_entropy_range_and_compaction():
+    rng = np.random.default_rng(5)
+    xyz = rng.normal(size=(50, 3))
+    ent = -rng.uniform(5.0, 9.0, 50)
+    valid = rng.random(50) < 0.6
+    ent[~valid] = 0.0
+    xo, co, mn, mx = oracle.render_entropy(xyz, ent, valid)
+    assert len(xo) == valid.sum() and np.array_equal(xo, xyz[valid])
+    assert mn == abs(ent[valid].max()) and mx == abs(ent[valid].min())  # (:698-699)
+    ne = (np.abs(ent[valid]) - mn) / (mx - mn)
+    ne = (np.log(ne + 0.1) - np.log(0.1)) / (np.log(1.1) - np.log(0.1))
+    for i in range(len(xo)):
+        np.testing.assert_allclose(co[i], oracle.jet_color(ne[i]), atol=1e-12)
