@@ -192,7 +192,20 @@ def main():
                     traffic = json.load(open(tpath)).get(dom)
                 except Exception:
                     traffic = None
-            line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # What actually limits the kernel (reported next to the contractual HBM figure, not instead of it): fp64
+            # VALU issue.  Instructions per wavefront come from the committed rocprofv3 SQ pass (same scene density),
+            # the launch time is measured live; 256 CUs x 4 SIMDs, one VALU instruction per SIMD per 4 cycles, 2.4 GHz.
+            valu = None
+            spath = os.path.join(ROOT, "profiles", "r01_sq_per_wave.json")
+            if os.path.exists(spath) and dom in ("mme", "nn_grid"):
+                try:
+                    per_wave = json.load(open(spath))[f"me::k_{dom}"]["SQ_INSTS_VALU"]
+                    issue_cycles = per_wave * (units / 64.0) * 4.0
+                    valu = {"valu_insts_per_wave": per_wave, "frac_of_valu_issue_peak":
+                            issue_cycles / (avg_ms * 1e-3 * 2.4e9 * 1024.0), "source": "profiles/r01_sq_per_wave.json"}
+                except Exception:
+                    valu = None
+            line["roofline"] = {"bound": "hbm", "kernel": dom, "valu_issue": valu, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
                                 "units_per_launch": units, "algorithmic_bytes_per_launch": alg_bytes,
                                 "kernel_ms_per_step": {k: v[0] for k, v in fam.items()},

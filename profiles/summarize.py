@@ -62,6 +62,29 @@ def main(src, out):
         d["hbm_bytes_per_launch_raw"] = f_ + w_
         d["hbm_bytes_per_launch_fetch_x2"] = 2 * f_ + w_
     json.dump(traffic, open(out + "_hbm_traffic.json", "w"), indent=1, sort_keys=True)
+    # per-family figure bench.py reports as roofline.traffic (raw FETCH+WRITE per launch)
+    fam = {k.replace("me::k_", ""): v["hbm_bytes_per_launch_raw"] for k, v in traffic.items()
+           if k in ("me::k_nn_grid", "me::k_mme", "me::k_nn1")}
+    fam["_note"] = ("HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes "
+                    "(<tag>_hbm_traffic.json also lists the gfx950 FETCH x2 figure); workload = bench.py default")
+    json.dump(fam, open(out + "_traffic.json", "w"), indent=1)
+    # SQ counters per wavefront (10 M-point run)
+    sq = defaultdict(lambda: defaultdict(float))
+    for sub in ("pmc_sq_a", "pmc_sq_b"):
+        for f in glob.glob(f"{src}/{sub}/*/*_counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if k in ("me::k_nn_grid", "me::k_mme", "me::k_nn1"):
+                    sq[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    sqo = {}
+    for k, d in sq.items():
+        w = d.get("SQ_WAVES", 0) or 1.0
+        sqo[k] = {c: v / w for c, v in d.items() if c != "SQ_WAVES"}
+        sqo[k]["SQ_WAVES"] = w
+        if d.get("SQ_WAVE_CYCLES") and d.get("SQ_ACTIVE_INST_VALU"):
+            sqo[k]["active_valu_over_wave_cycles"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
+    json.dump(sqo, open(out + "_sq_per_wave.json", "w"), indent=1, sort_keys=True)
+    print(json.dumps(sqo, indent=1, sort_keys=True))
     print(open(out + "_kernel_stats.csv").read()[:1500])
     print(json.dumps({k: v for k, v in traffic.items() if k in ("me::k_nn1", "me::k_mme")}, indent=1))
 
