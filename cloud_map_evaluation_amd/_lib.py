@@ -16,7 +16,7 @@ ME_GATE_LT_SQUARED = 1
 # every symbol include/mapeval_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "me_create", "me_destroy", "me_last_error", "me_version", "me_set_shard", "me_set_slab",
-    "me_nn_unresolved", "me_nn_points", "me_nn_patch", "me_voxel_partials",
+    "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_patch", "me_voxel_partials",
     "me_upload_cloud", "me_upload_cloud_device", "me_cloud_size", "me_download_cloud", "me_voxel_downsample",
     "me_transform_cloud",
     "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats", "me_nn_partial_sums", "me_nn_sigma_sums", "me_nn_finalize", "me_chamfer",
@@ -115,8 +115,9 @@ def load():
     L.me_version.restype = C.c_int
     L.me_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.me_set_slab.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double]
-    L.me_nn_unresolved.argtypes = [vp, C.c_int, dp, C.c_int64, C.POINTER(C.c_int64)]
+    L.me_nn_unresolved.argtypes = [vp, C.c_int, dp, dp, C.c_int64, C.POINTER(C.c_int64)]
     L.me_nn_points.argtypes = [vp, C.c_int, dp, C.c_int64, dp]
+    L.me_nn_points_bounded.argtypes = [vp, C.c_int, dp, C.c_int64, dp]
     L.me_nn_patch.argtypes = [vp, C.c_int, dp, C.c_int64]
     L.me_voxel_partials.argtypes = [vp, C.c_int, C.c_double, ip, ip, dp, dp, C.POINTER(C.c_int64)]
     L.me_voxel_downsample.argtypes = [vp, C.c_int, C.c_double, C.POINTER(C.c_int64)]
@@ -150,7 +151,7 @@ def load():
     L.me_timers_enable.argtypes = [vp, C.c_int]
     L.me_timers_reset.argtypes = [vp]
     L.me_timer_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    for f in ("me_voxel_downsample", "me_transform_cloud", "me_set_slab", "me_nn_unresolved", "me_nn_points", "me_nn_patch", "me_voxel_partials", "me_set_shard", "me_upload_cloud", "me_upload_cloud_device", "me_download_cloud", "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats",
+    for f in ("me_voxel_downsample", "me_transform_cloud", "me_set_slab", "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_patch", "me_voxel_partials", "me_set_shard", "me_upload_cloud", "me_upload_cloud_device", "me_download_cloud", "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats",
               "me_nn_partial_sums", "me_nn_sigma_sums", "me_chamfer", "me_mme", "me_voxel_gaussians", "me_awd_scs",
               "me_run_suite", "me_w2_batch", "me_scs_table", "me_timers_enable", "me_timers_reset", "me_timer_get"):
         getattr(L, f).restype = C.c_int

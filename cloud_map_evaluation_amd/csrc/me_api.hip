@@ -263,17 +263,22 @@ int me_set_slab(me_ctx *ctx, int axis, double lo, double hi, double halo) {
     return ME_OK;
 }
 
-int me_nn_unresolved(me_ctx *ctx, int query_slot, double *xyz_device, int64_t capacity, int64_t *count) {
+int me_nn_unresolved(me_ctx *ctx, int query_slot, double *xyz_device, double *d2_device, int64_t capacity, int64_t *count) {
     if (!ctx) return ME_ERR_ARG;
     long long c = 0;
-    const int rc = me::nn_unresolved(ctx, query_slot, xyz_device, capacity, &c);
+    const int rc = me::nn_unresolved(ctx, query_slot, xyz_device, d2_device, capacity, &c);
     if (count) *count = c;
     return rc;
 }
 
 int me_nn_points(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_device) {
     if (!ctx) return ME_ERR_ARG;
-    return me::nn_points(ctx, ref_slot, xyz_device, m, d2_device);
+    return me::nn_points(ctx, ref_slot, xyz_device, m, d2_device, false);
+}
+
+int me_nn_points_bounded(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_inout_device) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::nn_points(ctx, ref_slot, xyz_device, m, d2_inout_device, true);
 }
 
 int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t count) {

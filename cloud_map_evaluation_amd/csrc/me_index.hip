@@ -68,20 +68,38 @@ __global__ void __launch_bounds__(256) k_bbox(const double *__restrict__ xyz, lo
 }
 
 // slab mode: keep the points inside [reg_lo, reg_hi) along the slab axis (owned + halo)
-__global__ void k_slab_flags(const double *__restrict__ xyz, long long n, SlabView s, unsigned int *__restrict__ flags) {
+// Open3D PointCloud::Transform on one point, the arithmetic of k_transform
+__device__ __forceinline__ void transform_point(const Mat4 &T, double x, double y, double z, double *o) {
+    double h[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = ((T.m[4 * r] * x + T.m[4 * r + 1] * y) + T.m[4 * r + 2] * z) + T.m[4 * r + 3];
+    o[0] = h[0] / h[3];
+    o[1] = h[1] / h[3];
+    o[2] = h[2] / h[3];
+}
+
+// slab filter straight from the caller's buffer: flag pass and compaction both apply the optional transform on the fly
+// (no staged copy of the whole cloud; every rank of a multi-GPU job runs this over ALL points, so it is kept lean)
+__global__ void k_slab_flags(const double *__restrict__ xyz, long long n, int has_T, Mat4 T, SlabView s,
+                             unsigned int *__restrict__ flags) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double v = xyz[3 * i + s.axis];
+    double p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    if (has_T) transform_point(T, p[0], p[1], p[2], p);
+    const double v = p[s.axis];
     flags[i] = (v >= s.reg_lo && v < s.reg_hi) ? 1u : 0u;
 }
-__global__ void k_slab_compact(const double *__restrict__ xyz, long long n, const unsigned int *__restrict__ flags,
-                               const unsigned int *__restrict__ pos, double *__restrict__ out) {
+__global__ void k_slab_compact(const double *__restrict__ xyz, long long n, int has_T, Mat4 T,
+                               const unsigned int *__restrict__ flags, const unsigned int *__restrict__ pos,
+                               double *__restrict__ out) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flags[i]) return;
     const long long o = pos[i];
-    out[3 * o] = xyz[3 * i];
-    out[3 * o + 1] = xyz[3 * i + 1];
-    out[3 * o + 2] = xyz[3 * i + 2];
+    double p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    if (has_T) transform_point(T, p[0], p[1], p[2], p);
+    out[3 * o] = p[0];
+    out[3 * o + 1] = p[1];
+    out[3 * o + 2] = p[2];
 }
 
 __global__ void k_morton(const double *__restrict__ xyz, long long n, double ox, double oy, double oz, double fine_h,
@@ -298,20 +316,21 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
             hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, m);
         }
     } else {
-        // slab mode: stage the whole cloud, transform, keep only [reg_lo, reg_hi) along the slab axis (stable order)
+        // slab mode: keep only [reg_lo, reg_hi) along the slab axis of the (transformed) cloud, stable order.  A device
+        // buffer is filtered in place of a copy; a host buffer is staged first.
         DevBuf &stage = ctx->tmp[3], &flags = ctx->tmp[0], &pos = ctx->tmp[1];
-        ME_CHECK(ctx, stage.ensure((size_t) n * 3 * sizeof(double)));
         ME_CHECK(ctx, flags.ensure((size_t) n * 4));
         ME_CHECK(ctx, pos.ensure((size_t) n * 4));
-        ME_CHECK(ctx, hipMemcpyAsync(stage.p, src, (size_t) n * 3 * sizeof(double),
-                                     src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-        if (T) {
-            Mat4 m;
-            std::memcpy(m.m, T, sizeof(m.m));
-            hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(256), 0, ctx->stream, stage.as<double>(), n, m);
+        const double *in = src;
+        if (!src_on_device) {
+            ME_CHECK(ctx, stage.ensure((size_t) n * 3 * sizeof(double)));
+            ME_CHECK(ctx, hipMemcpyAsync(stage.p, src, (size_t) n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            in = stage.as<double>();
         }
+        Mat4 m{};
+        if (T) std::memcpy(m.m, T, sizeof(m.m));
         TimerScope ts(ctx, "slab_filter");
-        hipLaunchKernelGGL(k_slab_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream, stage.as<double>(), n, c.slab,
+        hipLaunchKernelGGL(k_slab_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream, in, n, T ? 1 : 0, m, c.slab,
                            flags.as<unsigned int>());
         ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), n));
         unsigned int last_pos = 0, last_flag = 0;
@@ -320,7 +339,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
         ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const long long kept = (long long) last_pos + last_flag;
         ME_CHECK(ctx, c.xyz.ensure((size_t) std::max<long long>(kept, 1) * 3 * sizeof(double)));
-        hipLaunchKernelGGL(k_slab_compact, dim3(grid_for(n)), dim3(256), 0, ctx->stream, stage.as<double>(), n,
+        hipLaunchKernelGGL(k_slab_compact, dim3(grid_for(n)), dim3(256), 0, ctx->stream, in, n, T ? 1 : 0, m,
                            flags.as<unsigned int>(), pos.as<unsigned int>(), c.xyz.as<double>());
         c.n = kept;
         if (kept == 0) {  // this rank's slab (+halo) holds nothing of this cloud: every pass returns empty partials

@@ -203,7 +203,7 @@ __device__ __forceinline__ double octet_min(double v) {
 __global__ void __launch_bounds__(256)
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
       OctView oct, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
-      const unsigned int *__restrict__ list_count) {
+      const unsigned int *__restrict__ list_count, int use_bound) {
     __shared__ long long s_off[kMaxLevels];
     if (threadIdx.x < kMaxLevels) s_off[threadIdx.x] = oct.off[threadIdx.x];
     __syncthreads();
@@ -224,6 +224,8 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
             best = d2_out[i];
             const int bi = idx_out[i];
             if (bi >= 0) best_i = bi;
+        } else if (use_bound && alive) {
+            best = d2_out[i];  // caller's upper bound (me_nn_points_bounded): only closer points are of interest
         }
         // scan of one leaf cell by the octets flagged `go` (the shuffles run converged over the whole wave)
         auto scan_cells = [&](bool go, long long leaf) {
@@ -507,10 +509,11 @@ __global__ void k_nn_collect_unresolved(const SPoint *__restrict__ qsp, long lon
 }
 
 __global__ void k_nn_export_xyz(const SPoint *__restrict__ qsp, const unsigned int *__restrict__ list, long long m,
-                                double *__restrict__ xyz) {
+                                double *__restrict__ xyz, const double *__restrict__ d2s, double *__restrict__ d2) {
     const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     const SPoint q = qsp[list[t]];
+    if (d2) d2[t] = d2s[list[t]];
     xyz[3 * t] = q.x;
     xyz[3 * t + 1] = q.y;
     xyz[3 * t + 2] = q.z;
@@ -575,7 +578,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
             const unsigned int nbf = (unsigned int) std::min<long long>(nb, 256 * 16);
             TimerScope ts(ctx, "nn1");
             hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
-                               r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
+                               r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0);
         }
         if (ctx->timers_on) {  // fallback share, for the bench report
             unsigned int h = 0;
@@ -599,7 +602,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
     return ME_OK;
 }
 
-int nn_unresolved(me_ctx *ctx, int qslot, double *xyz_device, long long capacity, long long *count) {
+int nn_unresolved(me_ctx *ctx, int qslot, double *xyz_device, double *d2_device, long long capacity, long long *count) {
     if (qslot < 0 || qslot > 1 || !count) return ctx->fail(ME_ERR_ARG, "me_nn_unresolved: bad argument");
     Cloud &q = ctx->cloud[qslot];
     if (q.nn_ref_slot < 0) return ctx->fail(ME_ERR_STATE, "no NN result for this slot (call me_nn1 first)");
@@ -608,12 +611,12 @@ int nn_unresolved(me_ctx *ctx, int qslot, double *xyz_device, long long capacity
     if (capacity < q.n_unres) return ctx->fail(ME_ERR_CAPACITY, "me_nn_unresolved: capacity too small");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_nn_export_xyz, dim3((unsigned int) ((q.n_unres + 255) / 256)), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(),
-                       q.nn_unres.as<unsigned int>(), q.n_unres, xyz_device);
+                       q.nn_unres.as<unsigned int>(), q.n_unres, xyz_device, q.nn_d2.as<double>(), d2_device);
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ME_OK;
 }
 
-int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, double *d2_device) {
+int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, double *d2_device, bool bounded) {
     if (rslot < 0 || rslot > 1 || m < 0 || (m > 0 && (!xyz_device || !d2_device))) return ctx->fail(ME_ERR_ARG, "me_nn_points: bad argument");
     Cloud &r = ctx->cloud[rslot];
     if (!r.uploaded) return ctx->fail(ME_ERR_STATE, "me_nn_points: reference cloud not uploaded");
@@ -621,7 +624,7 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     const unsigned int nb = (unsigned int) ((m + 255) / 256);
     if (r.n == 0) {
-        hipLaunchKernelGGL(k_fill_f64, dim3(nb), dim3(256), 0, ctx->stream, d2_device, m, (double) INFINITY);
+        if (!bounded) hipLaunchKernelGGL(k_fill_f64, dim3(nb), dim3(256), 0, ctx->stream, d2_device, m, (double) INFINITY);
     } else {
         DevBuf &qs = ctx->tmp[0], &qi = ctx->tmp[1];
         ME_CHECK(ctx, qs.ensure((size_t) m * sizeof(SPoint)));
@@ -630,7 +633,7 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
         TimerScope ts(ctx, "nn1");
         hipLaunchKernelGGL(k_nn1, dim3(std::min<unsigned int>(nb, 256 * 16)), dim3(256), 0, ctx->stream, qs.as<SPoint>(), 0LL, m,
                            r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
-                           (const unsigned int *) nullptr);
+                           (const unsigned int *) nullptr, bounded ? 1 : 0);
     }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());

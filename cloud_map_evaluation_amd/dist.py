@@ -98,18 +98,20 @@ def slab_bounds(gt, rank: int, world: int, bins: int = 8192):
     t = gt if isinstance(gt, torch.Tensor) else torch.from_numpy(np.asarray(gt))
     # a deterministic ~1 M-point subsample is plenty to balance the slabs (the outer faces are +-inf anyway) and keeps
     # this step at well under a millisecond on 50 M points
-    t = t[::max(1, t.shape[0] // 1_000_000)]
-    mn, mx = t.min(0).values, t.max(0).values
-    axis = int(torch.argmax(mx - mn).item())
+    # (two host round trips in total: the extent, then the cumulative histogram; the cut search runs on the host)
+    t = t[::max(1, t.shape[0] // 1_000_000)].contiguous()  # (reductions over the strided view are an order slower)
+    ext = torch.stack([t.amin(0), t.amax(0)]).cpu().numpy()
+    mn, mx = ext[0], ext[1]
+    axis = int(np.argmax(mx - mn))
     a, b = float(mn[axis]), float(mx[axis])
     if not b > a:
         return axis, -np.inf, np.inf
     h = torch.histc(t[:, axis].to(torch.float64), bins=bins, min=a, max=b)
-    cum = torch.cumsum(h, 0)
+    cum = torch.cumsum(h, 0).cpu().numpy()
     total = float(cum[-1])
     edges = []
     for k in range(1, world):
-        idx = int(torch.searchsorted(cum, torch.tensor([total * k / world], dtype=cum.dtype, device=cum.device)).item())
+        idx = int(np.searchsorted(cum, total * k / world, side="left"))
         edges.append(a + (b - a) * min(idx + 1, bins) / bins)
     cuts = [-np.inf] + edges + [np.inf]
     return axis, cuts[rank], cuts[rank + 1]
@@ -200,12 +202,16 @@ def suite_step_slab(eng, dist, comm_device, est, gt, P, rank: int, world: int, e
             counts = _all_reduce(onehot, dist, comm_device).tolist()
             cmax = max(counts)
             if cmax > 0:
-                mine = eng.nn_unresolved(q)
-                allq = _all_gather_rows(mine, cmax, dist, comm_device, pad_value=0.0)  # (world*cmax, 3)
-                valid = torch.cat([torch.arange(k * cmax, k * cmax + c) for k, c in enumerate(counts)]).to(allq.device)
-                d2_valid = eng.nn_points(r, allq[valid])  # every rank answers every open query against its own part
-                d2 = torch.full((world * cmax,), float("inf"), dtype=torch.float64, device=d2_valid.device)
-                d2[valid] = d2_valid
+                mine = eng.nn_unresolved(q, with_d2=True)  # xyz + the distance the owner already has (the bound to beat)
+                allq = _all_gather_rows(mine, cmax, dist, comm_device, pad_value=0.0)  # (world*cmax, 4)
+                # every rank answers the OTHER ranks' open queries against its own part (its own ones it has searched
+                # already: their bound is its answer); ranks that hold nothing closer than the bound prune at the root
+                valid = torch.cat([torch.arange(k * cmax, k * cmax + c) for k, c in enumerate(counts) if k != rank]
+                                  + [torch.zeros(0, dtype=torch.int64)]).to(allq.device)
+                d2 = torch.full((world * cmax,), float("inf"), dtype=torch.float64, device=allq.device)
+                d2[rank * cmax: rank * cmax + cnt] = allq[rank * cmax: rank * cmax + cnt, 3]
+                if valid.numel():
+                    d2[valid] = eng.nn_points(r, allq[valid][:, :3], bound=allq[valid][:, 3]).to(d2.device)
                 d2 = _all_reduce(d2, dist, comm_device, dist.ReduceOp.MIN)  # global nearest distance
                 eng.nn_patch(q, d2[rank * cmax: rank * cmax + cnt])
         n_cross += cnt

@@ -290,28 +290,38 @@ class Engine:
 
     def nn_unresolved_count(self, query_slot: int) -> int:
         n = C.c_int64(0)
-        self._ck(self._L.me_nn_unresolved(self._ctx, query_slot, 0, 0, C.byref(n)))
+        self._ck(self._L.me_nn_unresolved(self._ctx, query_slot, 0, 0, 0, C.byref(n)))
         return n.value
 
-    def nn_unresolved(self, query_slot: int):
-        """(count, 3) float64 cuda tensor: owned queries whose 1-NN may live on another rank."""
+    def nn_unresolved(self, query_slot: int, with_d2: bool = False):
+        """(count, 3) float64 cuda tensor: owned queries whose 1-NN may live on another rank; with_d2: (count, 4), the
+        fourth column = their current best squared distance (the bound the other ranks have to beat)."""
         import torch
 
         cnt = self.nn_unresolved_count(query_slot)
-        out = torch.empty((cnt, 3), dtype=torch.float64, device=torch.device("cuda", self.device))
+        dev = torch.device("cuda", self.device)
+        out = torch.empty((cnt, 3), dtype=torch.float64, device=dev)
+        d2 = torch.empty(cnt, dtype=torch.float64, device=dev) if with_d2 else None
         if cnt:
             n = C.c_int64(0)
-            self._ck(self._L.me_nn_unresolved(self._ctx, query_slot, out.data_ptr(), cnt, C.byref(n)))
-        return out
+            self._ck(self._L.me_nn_unresolved(self._ctx, query_slot, out.data_ptr(), d2.data_ptr() if with_d2 else 0, cnt,
+                                              C.byref(n)))
+        return torch.cat([out, d2[:, None]], 1) if with_d2 else out
 
-    def nn_points(self, ref_slot: int, xyz):
-        """Exact squared distance of arbitrary points (cuda tensor (m,3) float64) to this rank's part of ref_slot."""
+    def nn_points(self, ref_slot: int, xyz, bound=None):
+        """Exact squared distance of arbitrary points (cuda tensor (m,3) float64) to this rank's part of ref_slot;
+        bound (m,): upper bounds -> min(bound, nearest here), far ranks prune at once (me_nn_points_bounded)."""
         import torch
 
         xyz = xyz.to(torch.device("cuda", self.device), torch.float64).contiguous()
+        if bound is None:
+            d2 = torch.empty(xyz.shape[0], dtype=torch.float64, device=xyz.device)
+            fn = self._L.me_nn_points
+        else:
+            d2 = bound.to(xyz.device, torch.float64).clone().contiguous()
+            fn = self._L.me_nn_points_bounded
         torch.cuda.current_stream(xyz.device).synchronize()
-        d2 = torch.empty(xyz.shape[0], dtype=torch.float64, device=xyz.device)
-        self._ck(self._L.me_nn_points(self._ctx, ref_slot, xyz.data_ptr(), int(xyz.shape[0]), d2.data_ptr()))
+        self._ck(fn(self._ctx, ref_slot, xyz.data_ptr(), int(xyz.shape[0]), d2.data_ptr()))
         return d2
 
     def nn_patch(self, query_slot: int, d2):

@@ -91,11 +91,16 @@ int me_set_slab(me_ctx *ctx, int axis, double lo, double hi, double halo);
 
 /* Slab mode, 1-NN cross-rank step.  me_nn_unresolved: the owned queries of the last me_nn1(query_slot, ..) whose
  * result is not yet provably global; xyz_device (capacity x 3, device memory) receives their coordinates, *count
- * their number (ME_ERR_CAPACITY if it exceeds capacity; xyz_device may be NULL to query the count). */
-int me_nn_unresolved(me_ctx *ctx, int query_slot, double *xyz_device, int64_t capacity, int64_t *count);
+ * their number (ME_ERR_CAPACITY if it exceeds capacity; xyz_device may be NULL to query the count); d2_device
+ * (optional, capacity doubles) receives their current best squared distances, the bound the other ranks have to beat. */
+int me_nn_unresolved(me_ctx *ctx, int query_slot, double *xyz_device, double *d2_device, int64_t capacity, int64_t *count);
 /* Exact squared distance from each of m arbitrary points (device, m x 3) to the nearest point this context holds of
  * ref_slot (owned + halo) -> d2_device[m]. */
 int me_nn_points(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_device);
+/* Same with an upper bound per point: on entry d2_inout_device[i] bounds the answer (+inf = none), on exit it holds
+ * min(bound, nearest squared distance here).  A rank whose points are all farther prunes at the root, which is what
+ * makes the cross-rank step cheap: the querying rank passes the distance it already has. */
+int me_nn_points_bounded(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_inout_device);
 /* Overwrites the squared distances of the unresolved queries (same order as me_nn_unresolved returned them) with the
  * globally min-reduced values d2_device[count]. */
 int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t count);

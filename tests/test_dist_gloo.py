@@ -240,19 +240,26 @@ class OracleSlabEngine(OracleShardEngine):
     def nn_unresolved_count(self, q):
         return len(self.unres[q])
 
-    def nn_unresolved(self, q):
+    def nn_unresolved(self, q, with_d2=False):
         import torch
 
-        return torch.from_numpy(self.cloud[q][self.unres[q]].copy())
+        xyz = self.cloud[q][self.unres[q]].copy()
+        if with_d2:
+            xyz = np.concatenate([xyz, self.d2[q][self.unres[q]][:, None]], 1)
+        return torch.from_numpy(xyz)
 
-    def nn_points(self, r, xyz):
+    def nn_points(self, r, xyz, bound=None):
         import oracle
         import torch
 
-        pts = xyz.numpy()
+        pts = np.ascontiguousarray(xyz.numpy())
         if len(self.cloud[r]) == 0 or len(pts) == 0:
-            return torch.full((len(pts),), float("inf"), dtype=torch.float64)
-        return torch.from_numpy(oracle.nn1(self.cloud[r], pts)[1])
+            d2 = np.full(len(pts), np.inf)
+        else:
+            d2 = oracle.nn1(self.cloud[r], pts)[1]
+        if bound is not None:
+            d2 = np.minimum(d2, bound.numpy())
+        return torch.from_numpy(d2)
 
     def nn_patch(self, q, d2):
         self.d2[q][self.unres[q]] = np.minimum(self.d2[q][self.unres[q]], d2.numpy())
