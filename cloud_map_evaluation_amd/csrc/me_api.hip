@@ -1,5 +1,6 @@
 // me_api.hip — the extern "C" surface declared in include/mapeval_hip.h (context, timers, call sequencing).
 #include <cmath>
+#include <chrono>
 #include <cstring>
 
 #include "me_internal.hpp"
@@ -308,29 +309,48 @@ int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out) {
     if (!p || !out) return ctx->fail(ME_ERR_ARG, "me_run_suite: NULL argument");
     if (ctx->shard_world != 1 || ctx->slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_run_suite is single-GPU; drive the partial calls when sharded");
     std::memset(out, 0, sizeof(*out));
+    // stage_ms: host wall clock per stage (every stage below ends with a stream synchronisation)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
     // MME first, as MapEval::process (map_eval.cpp:52-66)
     if (p->evaluate_mme) {
         double s = 0;
         int64_t nv = 0;
+        auto t0 = now();
         ME_TRY(me_mme(ctx, ME_SLOT_EST, p->nn_radius, 10, nullptr, nullptr, &s, &nv));  // k >= 10 (:1675)
+        out->stage_ms[4] = ms_since(t0);
         out->mme_est = nv > 0 ? s / (double) nv : 0.0;
         out->mme_est_valid = nv;
         if (p->evaluate_gt_mme) {
+            t0 = now();
             ME_TRY(me_mme(ctx, ME_SLOT_GT, p->nn_radius, 5, nullptr, nullptr, &s, &nv));  // k >= 5 (:1458)
+            out->stage_ms[5] = ms_since(t0);
             out->mme_gt = nv > 0 ? s / (double) nv : 0.0;
             out->mme_gt_valid = nv;
         }
     }
     // AC / COM both directions (:1213-1242) + full CD (:1398-1431) from the same two searches
+    auto t0 = now();
     ME_TRY(me::nn_search(ctx, ME_SLOT_EST, ME_SLOT_GT));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    out->stage_ms[1] = ms_since(t0);
+    t0 = now();
     ME_TRY(me_nn_stats(ctx, ME_SLOT_EST, p->icp_max_distance, p->gate_mode, p->trunc, &out->est_gt));
+    out->stage_ms[3] = ms_since(t0);
+    t0 = now();
     ME_TRY(me::nn_search(ctx, ME_SLOT_GT, ME_SLOT_EST));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    out->stage_ms[2] = ms_since(t0);
+    t0 = now();
     ME_TRY(me_nn_stats(ctx, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &out->gt_est));
+    out->stage_ms[3] += ms_since(t0);
     out->full_chamfer = out->est_gt.mean_nn_dist + out->gt_est.mean_nn_dist;
     // AWD / SCS (:85, :240-390)
     int64_t n_rows = 0;
+    t0 = now();
     ME_TRY(me_awd_scs(ctx, p->vmd_voxel_size, p->min_pts > 0 ? p->min_pts : 100, p->scs_radius > 0 ? p->scs_radius : 5, nullptr,
                       nullptr, &n_rows, &out->awd, &out->scs, nullptr));
+    out->stage_ms[6] = ms_since(t0);
     out->n_w_voxels = n_rows;
     return ME_OK;
 }

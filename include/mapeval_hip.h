@@ -238,7 +238,8 @@ typedef struct me_suite_out {
     int64_t mme_est_valid, mme_gt_valid;
     double awd, scs;        /* vmd / scs_overall */
     int64_t n_w_voxels;
-    double stage_ms[8];     /* device-side stage timers: index, nn e->g, nn g->e, stats, mme est, mme gt, voxel+awd, scs */
+    double stage_ms[8];     /* host wall clock per stage (each ends with a stream sync): [1] nn est->gt, [2] nn gt->est,
+                             * [3] statistics, [4] mme est, [5] mme gt, [6] voxel Gaussians + AWD + CDF + SCS; [0], [7] unused (0) */
 } me_suite_out;
 
 int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out);

@@ -89,6 +89,18 @@ def test_render_entropy_is_discarded_by_a_transform(eng, pair):
         eng.ColorPointCloudByMME(0)
 
 
+def test_run_suite_reports_stage_times(eng, pair):
+    from cloud_map_evaluation_amd.engine import Param
+
+    est, gt = pair
+    eng.upload(0, est, cell_size=0.1)
+    eng.upload(1, gt, cell_size=0.1)
+    out = eng.run_suite(Param(icp_max_distance_=1.0, nn_radius_=0.1, vmd_voxel_size_=3.0))
+    st = list(out.stage_ms)
+    assert all(st[k] > 0.0 for k in (1, 2, 3, 4, 5, 6)) and st[0] == 0.0 and st[7] == 0.0
+    assert sum(st) < 5_000.0
+
+
 def _read_pcd_xyz_rgb(path):
     raw = open(path, "rb").read()
     head, _, body = raw.partition(b"DATA binary\n")
