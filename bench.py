@@ -162,7 +162,7 @@ def main():
         eng.timers_reset()
         suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme)
         fam = {}
-        for name in ("nn_grid", "nn1", "mme", "sort", "morton", "gather", "bvh", "cells", "nn_stats", "voxel_keys", "voxel",
+        for name in ("nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "slab_filter", "voxel",
                      "w2", "scs"):
             ms, cnt = eng.timer(name)
             if cnt:

@@ -374,7 +374,7 @@ int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launc
     if (!ctx || !name) return ME_ERR_ARG;
     ctx->timers_collect();
     if (std::strcmp(name, "nn_fallback_queries") == 0 || std::strcmp(name, "nn_queries") == 0) {
-        // counters, not timers: 1-NN queries that needed the BVH pass / all 1-NN queries since the last reset
+        // counters, not timers: 1-NN queries that needed the octree pass / all 1-NN queries since the last reset
         const long long v = name[3] == 'f' ? ctx->nn_fallback : ctx->nn_queries;
         if (total_ms) *total_ms = 0.0;
         if (launches) *launches = v;

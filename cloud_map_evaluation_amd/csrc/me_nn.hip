@@ -2,7 +2,7 @@
 // threshold statistics of getDiffRegResultWithCorrespondence (map_eval.cpp:1069-1145).
 //
 // Two kernels: a uniform-grid fast path (k_nn_grid) and, for what it cannot settle, a general walk (k_nn1) of a sparse
-// octree over the Morton prefixes: one lane per query, stackless AND nearest-first:
+// octree over the Morton prefixes: eight lanes per query (one per child), stackless AND nearest-first:
 //   state = (level, node, one byte of "children already taken" per level).
 //   At a node the <= 8 child records (contiguous, one burst of loads) are bounded at once; the closest
 //   not-yet-taken child whose lower bound does not exceed the current best is entered; when none is left the
@@ -51,7 +51,7 @@ __device__ __forceinline__ double box_upper_bound(const float *__restrict__ b, d
 // A lane is RESOLVED when its best distance is below its distance to the faces of its own 3x3x3 block: every
 // reference point outside the block is farther, so the minimum is the exact global minimum.  Unresolved lanes
 // (no neighbour within about one cell edge: outliers, non-overlapping map regions, queries outside the reference
-// bbox) are appended to a list, with their best-so-far as the initial bound, for the BVH kernel below.
+// bbox) are appended to a list, with their best-so-far as the initial bound, for the octree kernel below.
 // Measured alternatives (rocprofv3 SQ/TCP counters, profiles/README.md): a per-lane walk of each lane's own 27 runs
 // tests 4x fewer candidates but is bound by vector-L1 tag lookups (~11 distinct lines per load instruction) and
 // loses; Chebyshev-1 groups serialise a wave into ~5 rounds on a fine grid and lose as well.
