@@ -29,6 +29,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 # algorithmic (compulsory) bytes per unit of work
 BYTES_PER_NN_QUERY = 60.0   # 24 B query + 24 B reference point + 12 B result (M = N)
 BYTES_PER_MME_QUERY = 33.0  # 24 B point + 8 B entropy + 1 B valid
+OVERLAP = True  # --no-overlap switches the second lane off (the per-kernel timing pass always runs without it)
 
 
 def parse():
@@ -43,6 +44,7 @@ def parse():
     ap.add_argument("--no-gt-mme", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="GT points of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="single lane: every stage back to back on one stream")
     return ap.parse_args()
 
 
@@ -57,7 +59,9 @@ def suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme):
     if world > 1:
         # spatial slabs: every rank sorts / indexes / searches only its slab (+ 1 m halo) of both clouds
         return medist.suite_step_slab(eng, dist, dev, est_d, gt_d, P, dist.get_rank(), world, evaluate_gt_mme, halo=1.0)
-    return medist.suite_step(eng, None, dev, est_d, gt_d, P, evaluate_gt_mme)
+    # single GPU: the HBM-bound stages (index of the ground truth, both voxel tables) run on the engine's second lane
+    # under the VALU-bound MME / 1-NN kernels (dist._Lane); same calls, same results
+    return medist.suite_step(eng, None, dev, est_d, gt_d, P, evaluate_gt_mme, overlap=OVERLAP)
 
 
 def cpu_baseline(args, P, evaluate_gt_mme):
@@ -85,7 +89,9 @@ def cpu_baseline(args, P, evaluate_gt_mme):
 
 
 def main():
+    global OVERLAP
     args = parse()
+    OVERLAP = not args.no_overlap
     import numpy as np
     import torch
 
@@ -160,6 +166,7 @@ def main():
     if not args.no_roofline:
         eng.timers_enable(True)
         eng.timers_reset()
+        OVERLAP = False  # kernels timed one at a time
         suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme)
         fam = {}
         for name in ("nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "slab_filter", "voxel",

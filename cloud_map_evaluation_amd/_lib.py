@@ -15,7 +15,7 @@ ME_GATE_LT_SQUARED = 1
 
 # every symbol include/mapeval_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "me_create", "me_destroy", "me_last_error", "me_version", "me_set_shard", "me_set_slab",
+    "me_create", "me_destroy", "me_twin", "me_last_error", "me_version", "me_set_shard", "me_set_slab",
     "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_patch", "me_voxel_partials",
     "me_upload_cloud", "me_upload_cloud_device", "me_cloud_size", "me_download_cloud", "me_voxel_downsample",
     "me_transform_cloud",
@@ -110,6 +110,8 @@ def load():
     L.me_create.argtypes = [C.c_int, C.c_int]
     L.me_destroy.argtypes = [vp]
     L.me_destroy.restype = None
+    L.me_twin.argtypes = [vp]
+    L.me_twin.restype = C.c_void_p
     L.me_last_error.restype = C.c_char_p
     L.me_last_error.argtypes = [vp]
     L.me_version.restype = C.c_int

@@ -83,8 +83,40 @@ me_ctx *me_create(int device, int flags) {
     return ctx;
 }
 
+me_ctx *me_twin(me_ctx *ctx) {
+    if (!ctx) return nullptr;
+    if (ctx->is_twin) return ctx;
+    if (ctx->twin) return ctx->twin;
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        ctx->fail(ME_ERR_HIP, "me_twin: hipSetDevice failed");
+        return nullptr;
+    }
+    me_ctx *t = new me_ctx();
+    t->device = ctx->device;
+    t->is_twin = true;
+    t->cloud.p[0] = ctx->cloud.p[0];
+    t->cloud.p[1] = ctx->cloud.p[1];
+    t->shard_rank = ctx->shard_rank;
+    t->shard_world = ctx->shard_world;
+    t->slab = ctx->slab;
+    if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete t;
+        ctx->fail(ME_ERR_HIP, "me_twin: hipStreamCreate failed");
+        return nullptr;
+    }
+    ctx->twin = t;
+    return t;
+}
+
 void me_destroy(me_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->is_twin) return;  // twins belong to their primary context
+    if (ctx->twin) {
+        me_ctx *t = ctx->twin;
+        ctx->twin = nullptr;
+        t->is_twin = false;
+        me_destroy(t);
+    }
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     for (auto &p : ctx->pending) {
@@ -103,6 +135,10 @@ int me_set_shard(me_ctx *ctx, int rank, int world) {
     if (world < 1 || rank < 0 || rank >= world) return ctx->fail(ME_ERR_ARG, "me_set_shard: need 0 <= rank < world");
     ctx->shard_rank = rank;
     ctx->shard_world = world;
+    if (ctx->twin) {
+        ctx->twin->shard_rank = rank;
+        ctx->twin->shard_world = world;
+    }
     return ME_OK;
 }
 
@@ -257,10 +293,12 @@ int me_set_slab(me_ctx *ctx, int axis, double lo, double hi, double halo) {
     if (!ctx) return ME_ERR_ARG;
     if (axis < 0) {
         ctx->slab = me::SlabView{-1, 0, 0, 0, 0};
+        if (ctx->twin) ctx->twin->slab = ctx->slab;
         return ME_OK;
     }
     if (axis > 2 || !(lo < hi) || !(halo >= 0)) return ctx->fail(ME_ERR_ARG, "me_set_slab: need axis in 0..2, lo < hi, halo >= 0");
     ctx->slab = me::SlabView{axis, lo, hi, lo - halo, hi + halo};
+    if (ctx->twin) ctx->twin->slab = ctx->slab;
     return ME_OK;
 }
 

@@ -160,7 +160,19 @@ struct me_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    me::Cloud cloud[2];
+    // The clouds live in `own_cloud` of the PRIMARY context; a twin lane (me_twin) points at the same two objects but has
+    // its own stream, scratch and timers, so that two host threads can drive independent work concurrently.
+    me::Cloud own_cloud[2];
+    struct CloudSet {
+        me::Cloud *p[2];
+        me::Cloud &operator[](int i) const { return *p[i]; }
+    } cloud;
+    me_ctx *twin = nullptr;  // owned by the primary context
+    bool is_twin = false;
+    me_ctx() {
+        cloud.p[0] = &own_cloud[0];
+        cloud.p[1] = &own_cloud[1];
+    }
     me::DevBuf tmp[6];  // scratch
     me::DevBuf red;     // reduction partials
     void *host_pinned = nullptr;

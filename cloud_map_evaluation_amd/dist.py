@@ -250,20 +250,79 @@ def suite_step_slab(eng, dist, comm_device, est, gt, P, rank: int, world: int, e
                 n_est=n_e, n_gt=n_g, n_cross_rank_queries=int(vec[o + 4]), slab=(axis, lo, hi, halo))
 
 
-def suite_step(eng, dist, device, est, gt, P, evaluate_gt_mme: bool = True, upload: bool = True):
+class _Lane:
+    """The second lane of an overlapped step: a host thread driving the engine's twin context (me_twin).  It does the
+    HBM-bound work (index of the ground truth, both voxel tables) while the main lane runs the VALU-bound MME / 1-NN
+    kernels; ctypes calls release the GIL, the two HIP streams overlap on the device."""
+
+    def __init__(self, eng, gt, P, upload_gt):
+        import threading
+
+        self.err = None
+        self.gt_ready = threading.Event()
+        self.est_ready = threading.Event()
+        self._t = threading.Thread(target=self._run, args=(eng.twin(), gt, P, upload_gt), daemon=True)
+        self._t.start()
+
+    def _run(self, lane, gt, P, upload_gt):
+        try:
+            if upload_gt:
+                lane.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
+            self.gt_ready.set()
+            lane.voxel_build(ME_SLOT_GT, P.vmd_voxel_size_)
+            self.est_ready.wait()
+            if self.err is None:
+                lane.voxel_build(ME_SLOT_EST, P.vmd_voxel_size_)
+        except BaseException as e:  # re-raised by join()
+            self.err = e
+            self.gt_ready.set()
+
+    def wait_gt(self):
+        self.gt_ready.wait()
+        if self.err is not None:
+            raise self.err
+
+    def join(self):
+        self.est_ready.set()
+        self._t.join()
+        if self.err is not None:
+            raise self.err
+
+
+def suite_step(eng, dist, device, est, gt, P, evaluate_gt_mme: bool = True, upload: bool = True, overlap: bool = False):
     """One full pass of the hot path (what MapEval::process runs between load and save, map_eval.cpp:52-85).
 
     eng: Engine (or a stand-in with the same methods) already sharded with set_shard(rank, world).
     est / gt: clouds (host arrays or device tensors); P: Param.  Returns the dict of scalars, identical on all ranks.
+    overlap: drive the engine's twin lane from a second host thread (see _Lane); same calls, same results.
     """
-    if upload:
-        eng.upload(ME_SLOT_EST, est, T=np.asarray(P.initial_matrix_, dtype=np.float64), cell_size=P.nn_radius_)
-        eng.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
-    n_e, n_g = eng.size(ME_SLOT_EST), eng.size(ME_SLOT_GT)
+    lane = None
+    if overlap and upload and hasattr(eng, "twin"):
+        lane = _Lane(eng, gt, P, True)
+    try:
+        if upload:
+            eng.upload(ME_SLOT_EST, est, T=np.asarray(P.initial_matrix_, dtype=np.float64), cell_size=P.nn_radius_)
+            if lane is None:
+                eng.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
+        if lane is not None:
+            lane.est_ready.set()
+        res = _suite_after_upload(eng, dist, device, P, evaluate_gt_mme, lane)
+    except BaseException:
+        if lane is not None:
+            lane.err = lane.err or RuntimeError("main lane failed")
+            lane.est_ready.set()
+            lane._t.join()
+        raise
+    return res
+
+
+def _suite_after_upload(eng, dist, device, P, evaluate_gt_mme, lane):
     # --- MME (map_eval.cpp:56): k >= 10 for the estimated map (:1675), k >= 5 for the ground truth (:1458) ---
     if P.evaluate_mme_:
         m = eng.mme(ME_SLOT_EST, P.nn_radius_, 10, per_point=False)
         m_e = (m[4], m[3])
+        if lane is not None:
+            lane.wait_gt()
         if evaluate_gt_mme:
             m = eng.mme(ME_SLOT_GT, P.nn_radius_, 5, per_point=False)
             m_g = (m[4], m[3])
@@ -271,6 +330,9 @@ def suite_step(eng, dist, device, est, gt, P, evaluate_gt_mme: bool = True, uplo
             m_g = (0.0, 0)
     else:
         m_e = m_g = (0.0, 0)
+        if lane is not None:
+            lane.wait_gt()
+    n_e, n_g = eng.size(ME_SLOT_EST), eng.size(ME_SLOT_GT)
     # --- AC / COM / CD (map_eval.cpp:76, :1194): both directions, partial sums over the rank's slab ---
     parts = []
     for q, r in ((ME_SLOT_EST, ME_SLOT_GT), (ME_SLOT_GT, ME_SLOT_EST)):
@@ -290,6 +352,8 @@ def suite_step(eng, dist, device, est, gt, P, evaluate_gt_mme: bool = True, uplo
     mme_est = vec[o] / vec[o + 1] if vec[o + 1] > 0 else 0.0      # (:1720-1724)
     mme_gt = vec[o + 2] / vec[o + 3] if vec[o + 3] > 0 else 0.0
     # --- AWD / SCS (map_eval.cpp:85): O(V) voxel tables, replicated on every rank ---
+    if lane is not None:
+        lane.join()  # both voxel tables are built (and cached on the clouds) by now
     v = eng.calculateVMD(P.vmd_voxel_size_, rows=False)
     return dict(est_gt=s_eg, gt_est=s_ge, ac=s_eg["rmse"], com=s_eg["fitness"], cd=s_eg["mean_nn"] + s_ge["mean_nn"],
                 mme_est=mme_est, mme_gt=mme_gt, mme_valid=int(vec[o + 1]), awd=v["awd"], scs=v["scs"], n_w=v["n_rows"],

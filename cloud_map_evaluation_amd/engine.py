@@ -70,9 +70,27 @@ class Engine:
             raise MapEvalError(self._L.me_last_error(None).decode())
         self.device = device
 
+    def twin(self) -> "Engine":
+        """A second lane on the same clouds (me_twin): its own stream and scratch, so that a second host thread can run
+        independent work concurrently (ctypes calls release the GIL).  Owned by this engine."""
+        if getattr(self, "_twin", None) is None:
+            t = Engine.__new__(Engine)
+            t._L = self._L
+            t._ctx = self._L.me_twin(self._ctx)
+            if not t._ctx:
+                raise MapEvalError(self._L.me_last_error(self._ctx).decode())
+            t.device = self.device
+            t._owned = False
+            t._twin = None
+            self._twin = t
+        return self._twin
+
     def close(self):
         if getattr(self, "_ctx", None):
-            self._L.me_destroy(self._ctx)
+            if getattr(self, "_owned", True):
+                self._L.me_destroy(self._ctx)
+                if getattr(self, "_twin", None) is not None:
+                    self._twin._ctx = None  # freed with the primary context
             self._ctx = None
 
     def __del__(self):
@@ -231,6 +249,12 @@ class Engine:
         return mme_est, mme_gt
 
     # ---- voxels ----
+    def voxel_build(self, slot: int, voxel_size: float) -> int:
+        """Builds (and caches on the cloud) the voxel-Gaussian table without exporting it; returns the voxel count."""
+        nv = C.c_int64(0)
+        self._ck(self._L.me_voxel_gaussians(self._ctx, slot, float(voxel_size), 0, 0, 0, 0, 0, C.byref(nv)))
+        return nv.value
+
     def voxel_gaussians(self, slot: int, voxel_size: float):
         nv = C.c_int64(0)
         self._ck(self._L.me_voxel_gaussians(self._ctx, slot, float(voxel_size), 0, 0, 0, 0, 0, C.byref(nv)))

@@ -73,6 +73,14 @@ void me_destroy(me_ctx *ctx);
 const char *me_last_error(me_ctx *ctx); /* ctx may be NULL: returns the last me_create error */
 int me_version(void);
 
+/* A second LANE on the same clouds: a context that shares both cloud slots with `ctx` (uploads, indexes, NN / MME / voxel
+ * results are common) but owns its stream, scratch memory and timers.  Two host threads may then drive the two
+ * contexts concurrently, e.g. indexing the ground truth (HBM-bound) under the MME pass of the map (VALU-bound).
+ * Rules: never let both lanes upload / re-index / transform the same slot, or write the same product of a slot (its
+ * NN result, MME, voxel table), at the same time; reading a slot's index while the other lane builds the OTHER slot is
+ * fine.  The twin is owned by `ctx` (me_destroy(ctx) frees it; me_destroy(twin) is a no-op).  No reference counterpart. */
+me_ctx *me_twin(me_ctx *ctx);
+
 /* Multi-GPU slab sharding (no reference counterpart; the reference is single-process).  After this call every
  * per-point pass (NN, MME) only processes the `rank`-th of `world` equal slabs of the Morton-sorted query order,
  * and the voxel passes only own voxels whose key index falls in the rank's slab; partial sums are returned for
