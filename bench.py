@@ -58,7 +58,8 @@ def suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme):
     dev = torch.device("cuda", torch.cuda.current_device())
     if world > 1:
         # spatial slabs: every rank sorts / indexes / searches only its slab (+ 1 m halo) of both clouds
-        return medist.suite_step_slab(eng, dist, dev, est_d, gt_d, P, dist.get_rank(), world, evaluate_gt_mme, halo=1.0)
+        return medist.suite_step_slab(eng, dist, dev, est_d, gt_d, P, dist.get_rank(), world, evaluate_gt_mme, halo=1.0,
+                                      overlap=OVERLAP)
     # single GPU: the HBM-bound stages (index of the ground truth, both voxel tables) run on the engine's second lane
     # under the VALU-bound MME / 1-NN kernels (dist._Lane); same calls, same results
     return medist.suite_step(eng, None, dev, est_d, gt_d, P, evaluate_gt_mme, overlap=OVERLAP)

@@ -164,7 +164,15 @@ def awd_scs_from_tables(eng, est_tab, gt_tab, min_pts: int = 100, scs_radius: in
     return dict(awd=float(np.mean(w)), scs=float(eng.scs_table(ek[ie], w, scs_radius)), n_rows=int(len(ie)))
 
 
-def suite_step_slab(eng, dist, comm_device, est, gt, P, rank: int, world: int, evaluate_gt_mme: bool = True, halo: float = 1.0):
+def _partial_rows(eng, slot, voxel_size):
+    k, n, mu, m2 = eng.voxel_partials(slot, voxel_size)
+    if not len(n):
+        return np.zeros((0, 16))
+    return np.concatenate([k.astype(np.float64), n[:, None].astype(np.float64), mu, m2.reshape(-1, 9)], 1)
+
+
+def suite_step_slab(eng, dist, comm_device, est, gt, P, rank: int, world: int, evaluate_gt_mme: bool = True, halo: float = 1.0,
+                    overlap: bool = False):
     """Full suite with SPATIAL slabs: every rank sorts / indexes only ~1/world of each cloud (+ halo).
 
     Collectives per suite: 2 x (all-reduce MAX of a count [+ all-gather of unresolved queries + all-reduce MIN]),
@@ -177,18 +185,39 @@ def suite_step_slab(eng, dist, comm_device, est, gt, P, rank: int, world: int, e
     axis, lo, hi = slab_bounds(gt, rank, world)
     halo = max(float(halo), 1.0001 * float(P.nn_radius_))
     eng.set_slab(axis, lo, hi, halo)
-    eng.upload(ME_SLOT_EST, est, T=np.asarray(P.initial_matrix_, dtype=np.float64), cell_size=P.nn_radius_)
-    eng.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
+    # overlap: the second lane (a host thread on the engine's twin context) filters + indexes the ground truth and builds
+    # both voxel partial tables while this thread runs MME and the searches; collectives stay on this thread
+    lane = _Lane(eng, gt, P, True, partials=True) if (overlap and hasattr(eng, "twin")) else None
+    try:
+        eng.upload(ME_SLOT_EST, est, T=np.asarray(P.initial_matrix_, dtype=np.float64), cell_size=P.nn_radius_)
+        if lane is None:
+            eng.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
+        else:
+            lane.est_ready.set()
+        return _slab_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_e, n_g, lane, (axis, lo, hi, halo))
+    except BaseException:
+        if lane is not None:
+            lane.abort()
+        raise
+
+
+def _slab_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_e, n_g, lane, slab):
+    import torch
+
     # --- MME: exact with halo >= radius ---
     if P.evaluate_mme_:
         m = eng.mme(ME_SLOT_EST, P.nn_radius_, 10, per_point=False)
         m_e = (m[4], m[3])
         m_g = (0.0, 0)
+        if lane is not None:
+            lane.wait_gt()
         if evaluate_gt_mme:
             m = eng.mme(ME_SLOT_GT, P.nn_radius_, 5, per_point=False)
             m_g = (m[4], m[3])
     else:
         m_e = m_g = (0.0, 0)
+        if lane is not None:
+            lane.wait_gt()
     # --- 1-NN: local search, then the cross-rank step for queries whose ball crosses the slab's outer faces ---
     parts = []
     n_cross = 0
@@ -232,11 +261,11 @@ def suite_step_slab(eng, dist, comm_device, est, gt, P, rank: int, world: int, e
     mme_gt = vec[o + 2] / vec[o + 3] if vec[o + 3] > 0 else 0.0
     # --- voxel Gaussians: per-rank partials of the owned points, merged (Chan) after one all-gather per cloud ---
     tabs = []
-    local = []
-    for slot in (ME_SLOT_EST, ME_SLOT_GT):
-        k, n, mu, m2 = eng.voxel_partials(slot, P.vmd_voxel_size_)
-        rows = np.concatenate([k.astype(np.float64), n[:, None].astype(np.float64), mu, m2.reshape(-1, 9)], 1) if len(n) else np.zeros((0, 16))
-        local.append(rows)
+    if lane is not None:
+        lane.join()
+        local = [lane.rows[ME_SLOT_EST], lane.rows[ME_SLOT_GT]]
+    else:
+        local = [_partial_rows(eng, slot, P.vmd_voxel_size_) for slot in (ME_SLOT_EST, ME_SLOT_GT)]
     if dist is not None and world > 1:
         vmax = _all_reduce(torch.tensor([len(local[0]), len(local[1])], dtype=torch.int64), dist, comm_device, dist.ReduceOp.MAX)
         for rows, m in zip(local, vmax.tolist()):
@@ -247,7 +276,7 @@ def suite_step_slab(eng, dist, comm_device, est, gt, P, rank: int, world: int, e
     v = awd_scs_from_tables(eng, tabs[0], tabs[1])
     return dict(est_gt=s_eg, gt_est=s_ge, ac=s_eg["rmse"], com=s_eg["fitness"], cd=s_eg["mean_nn"] + s_ge["mean_nn"],
                 mme_est=mme_est, mme_gt=mme_gt, mme_valid=int(vec[o + 1]), awd=v["awd"], scs=v["scs"], n_w=v["n_rows"],
-                n_est=n_e, n_gt=n_g, n_cross_rank_queries=int(vec[o + 4]), slab=(axis, lo, hi, halo))
+                n_est=n_e, n_gt=n_g, n_cross_rank_queries=int(vec[o + 4]), slab=slab)
 
 
 class _Lane:
@@ -255,10 +284,12 @@ class _Lane:
     HBM-bound work (index of the ground truth, both voxel tables) while the main lane runs the VALU-bound MME / 1-NN
     kernels; ctypes calls release the GIL, the two HIP streams overlap on the device."""
 
-    def __init__(self, eng, gt, P, upload_gt):
+    def __init__(self, eng, gt, P, upload_gt, partials=False):
         import threading
 
         self.err = None
+        self.partials = partials  # slab mode: raw per-rank partial tables instead of the finished voxel tables
+        self.rows = {}
         self.gt_ready = threading.Event()
         self.est_ready = threading.Event()
         self._t = threading.Thread(target=self._run, args=(eng.twin(), gt, P, upload_gt), daemon=True)
@@ -269,13 +300,24 @@ class _Lane:
             if upload_gt:
                 lane.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
             self.gt_ready.set()
-            lane.voxel_build(ME_SLOT_GT, P.vmd_voxel_size_)
+            self._voxel(lane, ME_SLOT_GT, P)
             self.est_ready.wait()
             if self.err is None:
-                lane.voxel_build(ME_SLOT_EST, P.vmd_voxel_size_)
+                self._voxel(lane, ME_SLOT_EST, P)
         except BaseException as e:  # re-raised by join()
             self.err = e
             self.gt_ready.set()
+
+    def _voxel(self, lane, slot, P):
+        if self.partials:
+            self.rows[slot] = _partial_rows(lane, slot, P.vmd_voxel_size_)
+        else:
+            lane.voxel_build(slot, P.vmd_voxel_size_)
+
+    def abort(self):
+        self.err = self.err or RuntimeError("main lane failed")
+        self.est_ready.set()
+        self._t.join()
 
     def wait_gt(self):
         self.gt_ready.wait()
@@ -309,9 +351,7 @@ def suite_step(eng, dist, device, est, gt, P, evaluate_gt_mme: bool = True, uplo
         res = _suite_after_upload(eng, dist, device, P, evaluate_gt_mme, lane)
     except BaseException:
         if lane is not None:
-            lane.err = lane.err or RuntimeError("main lane failed")
-            lane.est_ready.set()
-            lane._t.join()
+            lane.abort()
         raise
     return res
 

@@ -40,7 +40,7 @@ class FakeDist:
         pass
 
 
-def main(points=50_000_000):
+def main(points=50_000_000, overlap=True):
     dev = torch.device("cuda", 0)
     est, gt = synth.campus_pair(points, density=2500.0, seed=100, device=dev)
     P = Param(icp_max_distance_=1.0, nn_radius_=0.1, vmd_voxel_size_=3.0)
@@ -55,18 +55,18 @@ def main(points=50_000_000):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 if world == 1:
-                    medist.suite_step(eng, None, dev, est, gt, P, True)
+                    medist.suite_step(eng, None, dev, est, gt, P, True, overlap=overlap)
                 else:
-                    medist.suite_step_slab(eng, fd, dev, est, gt, P, rank, world, True, halo=1.0)
+                    medist.suite_step_slab(eng, fd, dev, est, gt, P, rank, world, True, halo=1.0, overlap=overlap)
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
             per_rank.append(best * 1e3)
         out[world] = {"max_ms": max(per_rank), "mean_ms": sum(per_rank) / len(per_rank)}
         print(world, out[world], flush=True)
     base = out[1]["max_ms"]
-    print(json.dumps({"points": points, "per_world": out,
+    print(json.dumps({"points": points, "overlap": overlap, "per_world": out,
                       "speedup_vs_1": {w: base / v["max_ms"] for w, v in out.items()}}))
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000, overlap=("--no-overlap" not in sys.argv))

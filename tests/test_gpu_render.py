@@ -186,3 +186,34 @@ enable_debug: true
         xyz, rgb = _read_pcd_xyz_rgb(out / name)
         assert np.array_equal(xyz, oxyz)
         assert np.abs(rgb.astype(int) - u8(orgb).astype(int)).max() <= 1  # log() may differ in the last ulp
+
+
+def test_overlapped_step_equals_sequential_step(eng, pair):
+    """The second lane (me_twin + a host thread) only reorders independent work: every scalar must be identical."""
+    import torch
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Param
+
+    est, gt = pair
+    P = Param(icp_max_distance_=1.0, nn_radius_=0.1, vmd_voxel_size_=3.0)
+    dev = torch.device("cuda", 0)
+    a = medist.suite_step(eng, None, dev, est, gt, P, True, overlap=False)
+    for _ in range(3):
+        b = medist.suite_step(eng, None, dev, est, gt, P, True, overlap=True)
+        for k in ("cd", "mme_est", "mme_gt", "mme_valid", "awd", "scs", "n_w"):
+            assert a[k] == b[k], k
+        for k in ("rmse", "fitness", "sigma", "mean", "number"):
+            assert np.array_equal(a["est_gt"][k], b["est_gt"][k]) and np.array_equal(a["gt_est"][k], b["gt_est"][k])
+
+
+def test_twin_lane_shares_the_clouds(eng, pair):
+    est, gt = pair
+    eng.upload(0, est, cell_size=0.1)
+    lane = eng.twin()
+    assert lane is eng.twin() and lane.size(0) == len(est)
+    lane.upload(1, gt, cell_size=0.1)            # uploaded through the twin ...
+    assert eng.size(1) == len(gt)                # ... visible through the primary context
+    idx, d2 = eng.nn1(0, 1)
+    idx2, d22 = lane.nn1(0, 1)
+    assert np.array_equal(idx, idx2) and np.array_equal(d2, d22)

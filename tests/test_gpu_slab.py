@@ -84,7 +84,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, est, gt, T, q):
+def _worker(rank, world, port, est, gt, T, q, overlap):
     import torch
     import torch.distributed as dist
 
@@ -97,14 +97,15 @@ def _worker(rank, world, port, est, gt, T, q):
     try:
         P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=1.0, initial_matrix_=T)
         with Engine(0) as eng:
-            res = medist.suite_step_slab(eng, dist, torch.device("cpu"), est, gt, P, rank, world, halo=0.5)
+            res = medist.suite_step_slab(eng, dist, torch.device("cpu"), est, gt, P, rank, world, halo=0.5, overlap=overlap)
         q.put((rank, {k: (v if not isinstance(v, dict) else {kk: np.asarray(vv) for kk, vv in v.items()}) for k, v in res.items()}))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_two_process_slab_suite_matches_oracle():
+@pytest.mark.parametrize("overlap", [False, True])  # True: the second lane (me_twin) indexes GT + builds the voxel partials
+def test_two_process_slab_suite_matches_oracle(overlap):
     import torch.multiprocessing as mp
 
     import oracle
@@ -116,7 +117,7 @@ def test_two_process_slab_suite_matches_oracle():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, est, gt, T, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, est, gt, T, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=500) for _ in procs)
