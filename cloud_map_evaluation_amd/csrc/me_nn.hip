@@ -428,20 +428,25 @@ k_nn_sigma(const double *__restrict__ d2s, long long q_begin, long long q_end, S
     }
 }
 
-// deterministic final reduction: component k is summed over the blocks in block order by one lane
-__global__ void k_final_sum_d(const double *__restrict__ part, int nblocks, int ncomp, double *__restrict__ out) {
-    const int k = threadIdx.x;
-    if (k >= ncomp) return;
+// deterministic final reduction: one 256-thread block per component, fixed strided partial sums + fixed tree
+// (a single lane per component used to walk the <= 1024 block partials serially: 0.15 ms of pure latency per call)
+__global__ void __launch_bounds__(256)
+k_final_sum_d(const double *__restrict__ part, int nblocks, int ncomp, double *__restrict__ out) {
+    const int k = blockIdx.x;
     double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += part[(long long) b * ncomp + k];
-    out[k] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(long long) b * ncomp + k];
+    __shared__ double sm[4];
+    const double r = block_sum_256(s, sm);
+    if (threadIdx.x == 0) out[k] = r;
 }
-__global__ void k_final_sum_i(const long long *__restrict__ part, int nblocks, int ncomp, long long *__restrict__ out) {
-    const int k = threadIdx.x;
-    if (k >= ncomp) return;
+__global__ void __launch_bounds__(256)
+k_final_sum_i(const long long *__restrict__ part, int nblocks, int ncomp, long long *__restrict__ out) {
+    const int k = blockIdx.x;
     long long s = 0;
-    for (int b = 0; b < nblocks; ++b) s += part[(long long) b * ncomp + k];
-    out[k] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(long long) b * ncomp + k];
+    __shared__ long long sm[4];
+    const long long r = block_sum_256_ll(s, sm);
+    if (threadIdx.x == 0) out[k] = r;
 }
 
 static StatParams make_params(double gate, int gate_mode, const double trunc[5]) {
@@ -690,8 +695,8 @@ int nn_partial(me_ctx *ctx, int qslot, double gate, int gate_mode, const double 
     {
         TimerScope ts(ctx, "nn_stats");
         hipLaunchKernelGGL(k_nn_partial, dim3(nb), dim3(256), 0, ctx->stream, q.nn_d2.as<double>(), b, e, sp, pd, pi);
-        hipLaunchKernelGGL(k_final_sum_d, dim3(1), dim3(64), 0, ctx->stream, pd, nb, kStatD, pd + (size_t) nb * kStatD);
-        hipLaunchKernelGGL(k_final_sum_i, dim3(1), dim3(64), 0, ctx->stream, pi, nb, kStatI, pi + (size_t) nb * kStatI);
+        hipLaunchKernelGGL(k_final_sum_d, dim3(kStatD), dim3(256), 0, ctx->stream, pd, nb, kStatD, pd + (size_t) nb * kStatD);
+        hipLaunchKernelGGL(k_final_sum_i, dim3(kStatI), dim3(256), 0, ctx->stream, pi, nb, kStatI, pi + (size_t) nb * kStatI);
     }
     double hd[kStatD];
     long long hi[kStatI];
@@ -726,7 +731,7 @@ int nn_sigma(me_ctx *ctx, int qslot, double gate, int gate_mode, const double me
     {
         TimerScope ts(ctx, "nn_stats");
         hipLaunchKernelGGL(k_nn_sigma, dim3(nb), dim3(256), 0, ctx->stream, q.nn_d2.as<double>(), b, e, sp, m, pd);
-        hipLaunchKernelGGL(k_final_sum_d, dim3(1), dim3(64), 0, ctx->stream, pd, nb, 5, pd + (size_t) nb * 5);
+        hipLaunchKernelGGL(k_final_sum_d, dim3(5), dim3(256), 0, ctx->stream, pd, nb, 5, pd + (size_t) nb * 5);
     }
     ME_CHECK(ctx, hipMemcpyAsync(sigma_num, pd + (size_t) nb * 5, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -789,8 +794,8 @@ int icp_p2p_sums(me_ctx *ctx, int qslot, double max_distance, me_icp_sums *out) 
         TimerScope ts(ctx, "icp");
         hipLaunchKernelGGL(k_icp_p2p, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), q.nn_d2.as<double>(), q.nn_idx.as<int>(),
                            r.xyz.as<double>(), n, max_distance * max_distance, cx, cy, cz, pd, pc);
-        hipLaunchKernelGGL(k_final_sum_d, dim3(1), dim3(64), 0, ctx->stream, pd, nb, kIcpD, pd + (size_t) nb * kIcpD);
-        hipLaunchKernelGGL(k_final_sum_i, dim3(1), dim3(64), 0, ctx->stream, pc, nb, 1, pc + nb);
+        hipLaunchKernelGGL(k_final_sum_d, dim3(kIcpD), dim3(256), 0, ctx->stream, pd, nb, kIcpD, pd + (size_t) nb * kIcpD);
+        hipLaunchKernelGGL(k_final_sum_i, dim3(1), dim3(256), 0, ctx->stream, pc, nb, 1, pc + nb);
     }
     double hd[kIcpD];
     long long hc = 0;
