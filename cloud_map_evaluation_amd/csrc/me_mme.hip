@@ -24,7 +24,7 @@
 
 namespace me {
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
       GridView g, SlabView slab, double r2, int min_k, double *__restrict__ ent_s, unsigned char *__restrict__ valid_s,
       double *__restrict__ part_sum, long long *__restrict__ part_cnt) {
