@@ -5,13 +5,17 @@
 // Mapping.  Points are Morton-sorted on a grid whose cell edge is (a hair above) the search radius, so the
 // neighbours of every point of a cell lie in the 3x3x3 block around it, and each cell is one contiguous run of
 // the sorted array.  A wavefront owns 64 consecutive sorted points.  Per round (usually one or two per wave) it
-//   * groups the lanes whose cell is within Chebyshev distance 1 of the leader's and resolves the group's cell box
-//     grown by one (<= 5x5x5 cells) with one hash probe per lane and slot (wave_group_runs),
+//   * groups the lanes whose cell is within Chebyshev distance 2 of the leader's (normally the whole wave) and resolves the
+//     group's cell box grown by one with one hash probe per (lane, slot) into a wave-private LDS run table
+//     (wave_group_table),
 //   * streams every non-empty run ONCE with WAVE-UNIFORM addresses (one fetch feeds all 64 lanes; the compiler turns
 //     it into scalar loads, the candidate sits in SGPRs), every group lane testing it against its own query in fp64.
-// rocprofv3 SQ counters put this kernel at ~90 % VALU issue occupancy (8 waves/SIMD x 11 % each): it is bound by the
-// fp64 candidate tests, not by memory.  A per-lane walk (fewer candidates per lane) was measured slower (vector-L1
-// tag-lookup bound), half-radius cells with a 5x5x5 stencil likewise (same union, 6x the probes).
+// rocprofv3 SQ counters put this kernel at ~80 % of the fp64 VALU issue rate: it is bound by the candidate tests, not by
+// memory.  It is tuned to 64 VGPRs (8 waves per SIMD: the scalar fetches are L2 round trips that only other waves can
+// hide); the run table lives in LDS and the 64-bit point index is rebuilt where needed for that reason, and the four
+// registers the allocator still spills are touched in the prologue / epilogue only.  A per-lane walk (fewer candidates
+// per lane) was measured slower (vector-L1 tag-lookup bound), half-radius cells with a 5x5x5 stencil likewise (same
+// union, 6x the probes), sub-wave groups as well (profiles/README.md).
 // The reference materialises index/distance vectors per query and gathers a 3xk matrix; here nothing is
 // materialised: k, sum(p-q) and sum((p-q)(p-q)^T) are accumulated in registers about the QUERY as origin
 // (|p-q| < r, so the one-pass covariance is as well conditioned as the reference's two-pass one).
@@ -28,18 +32,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
       GridView g, SlabView slab, double r2, int min_k, double *__restrict__ ent_s, unsigned char *__restrict__ valid_s,
       double *__restrict__ part_sum, long long *__restrict__ part_cnt) {
-    const int lane = threadIdx.x & 63;
     // XCD-aware chunking (see k_nn1): gridDim.x is a multiple of 8
     const unsigned int per = gridDim.x / 8;
     const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    const long long i = i_begin + (long long) vb * blockDim.x + threadIdx.x;
-    bool active = i < i_end;
+    // (the index is rebuilt from this 32-bit offset where it is needed: one live register instead of two)
+    const unsigned int loc = vb * blockDim.x + threadIdx.x;
+    bool active = i_begin + (long long) loc < i_end;
     const int shift3 = 3 * g.shift;
     const int cell_lim = 1 << (kMortonBits - g.shift);
 
     double qx = 0, qy = 0, qz = 0;
     unsigned long long mycell = ~0ULL;
     if (active) {
+        const long long i = i_begin + (long long) loc;
         const SPoint q = sp[i];
         qx = q.x;
         qy = q.y;
@@ -55,8 +60,6 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
     double s1x = 0, s1y = 0, s1z = 0;
     double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
     bool done = !active;
-
-    const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
 
     // r2e = r2 for the lanes of the current group, -1 for the others: the group predicate rides on the radius
     // compare, so the loop needs no exec juggling of its own (the scalar side of this kernel is nearly as busy as the
@@ -93,26 +96,20 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
         }
     };
 
-    // wave-shared candidate streams (scalar loads): every group lane tests the union of the group's cells
+    // wave-shared candidate streams (scalar loads): every group lane tests the union of the group's cells.  The run
+    // table of a round lives in LDS (not in registers: the kernel is tuned to 64 VGPRs = 8 waves per SIMD)
+    __shared__ int2 s_tab[4][kGroupTab + 1];
+    int2 *tab = s_tab[threadIdx.x >> 6];
     while (__ballot(!done)) {
-        int rs0, rc0, rs1, rc1;
-        const bool in = wave_group_runs(!done, cx, cy, cz, g, cell_lim, lane, rs0, rc0, rs1, rc1);
+        GroupBox bx;
+        int nk = 0;
+        const int lane = threadIdx.x & 63;
+        const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
+        const bool in = wave_group_table<1>(!done, cx, cy, cz, g, cell_lim, lane, tab, bx, &nk);
         const double r2e = in ? r2 : -1.0;
-        unsigned long long m = __ballot(rc0 > 0);
-        while (m) {
-            const int n = __ffsll((long long) m) - 1;
-            m &= m - 1;
-            const int cs = readlane_i(rs0, n);
-            stream_run(cs, cs + readlane_i(rc0, n), r2e);
-        }
-        m = __ballot(rc1 > 0);
-        while (m) {
-            const int n = __ffsll((long long) m) - 1;
-            m &= m - 1;
-            const int cs = readlane_i(rs1, n);
-            stream_run(cs, cs + readlane_i(rc1, n), r2e);
-        }
+        wave_for_each_run(tab, nk, lane, [&](int cs, int ce) { stream_run(cs, ce, r2e); });
         if (in) done = true;
+        __builtin_amdgcn_wave_barrier();
     }
 
     double H = 0.0;
@@ -135,6 +132,7 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
                 ok = true;
             }
         }
+        const long long i = i_begin + (long long) loc;
         ent_s[i] = H;                       // 0.0 where invalid (:1614)
         valid_s[i] = ok ? 1 : 0;
     }
