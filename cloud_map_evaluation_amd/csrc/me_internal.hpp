@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <map>
 #include <string>
@@ -16,6 +17,7 @@ namespace me {
 constexpr int kFan = 8;        // children per octree node
 constexpr int kMaxLevels = 17; // octree levels above the leaf cells (taken-masks: 2 x 64 bits)
 constexpr int kMortonBits = 21;
+constexpr unsigned int kXcdChunk = 128;  // virtual blocks per XCD chunk (see xcd_virtual_block)
 
 struct DevBuf {
     void *p = nullptr;
@@ -227,6 +229,16 @@ struct TimerScope {
     ~TimerScope() { c->timer_end(); }
 };
 
+// chunk size of the XCD-aware block order (ME_XCD_CHUNK overrides; a huge value = one contiguous piece per XCD)
+inline unsigned int xcd_chunk_setting() {
+    static const unsigned int v = [] {
+        const char *e = std::getenv("ME_XCD_CHUNK");
+        const long x = e ? std::atol(e) : (long) kXcdChunk;
+        return (unsigned int) (x > 0 ? x : kXcdChunk);
+    }();
+    return v;
+}
+
 // ---- me_prims.hip (rocPRIM-backed primitives) ----
 int sort_pairs_u64_u32(me_ctx *ctx, const unsigned long long *k_in, unsigned long long *k_out,
                        const unsigned int *v_in, unsigned int *v_out, long long n, int begin_bit, int end_bit);
@@ -272,6 +284,19 @@ int scs_table(me_ctx *ctx, const int32_t *keys, const double *w, long long n, in
 
 // ---- shared device helpers ----
 #ifdef __HIPCC__
+// XCD-aware block order.  The hardware deals consecutive block ids round-robin to the 8 XCDs (each with its own L2).
+// XCD x gets the chunks x, x+8, x+16, ... of `chunk` consecutive virtual blocks: neighbouring blocks (which stream
+// largely the same candidates) share an L2, and every XCD sees a sample of the whole cloud.  One contiguous eighth per
+// XCD (the first version) left XCDs with dense regions running long after the others had drained.
+// nblocks must be a multiple of 8; the map is a bijection of [0, nblocks).
+__device__ __forceinline__ unsigned int xcd_virtual_block(unsigned int bid, unsigned int nblocks, unsigned int chunk) {
+    const unsigned int per = nblocks >> 3, x = bid & 7u, s = bid >> 3;
+    const unsigned int full = (per / chunk) * chunk;  // slots per XCD covered by whole chunks
+    if (s < full) return ((s / chunk) * 8u + x) * chunk + (s % chunk);
+    const unsigned int rem = per - full;              // leftover slots: one contiguous piece per XCD
+    return full * 8u + x * rem + (s - full);
+}
+
 __device__ __forceinline__ double dist2_exact(double ax, double ay, double az, double bx, double by, double bz) {
     // ((dx*dx + dy*dy) + dz*dz) without FMA contraction (file compiled with -ffp-contract=off):
     // this expression must be bit-identical to the CPU path (nanoflann L2 adaptor order).

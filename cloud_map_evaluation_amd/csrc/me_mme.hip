@@ -31,10 +31,9 @@ namespace me {
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
       GridView g, SlabView slab, double r2, int min_k, double *__restrict__ ent_s, unsigned char *__restrict__ valid_s,
-      double *__restrict__ part_sum, long long *__restrict__ part_cnt) {
+      double *__restrict__ part_sum, long long *__restrict__ part_cnt, unsigned int xcd_chunk) {
     // XCD-aware chunking (see k_nn1): gridDim.x is a multiple of 8
-    const unsigned int per = gridDim.x / 8;
-    const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const unsigned int vb = xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);
     // (the index is rebuilt from this 32-bit offset where it is needed: one live register instead of two)
     const unsigned int loc = vb * blockDim.x + threadIdx.x;
     bool active = i_begin + (long long) loc < i_end;
@@ -219,7 +218,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     {
         TimerScope ts(ctx, "mme");
         hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
-                           c.grid, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc);
+                           c.grid, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting());
     }
     const long long chunk = ((long long) nb + kStage - 1) / kStage;
     hipLaunchKernelGGL(k_mme_final, dim3(kStage), dim3(256), 0, ctx->stream, ps, pc, (long long) nb, chunk, ps2, pc2);

@@ -60,10 +60,9 @@ __global__ void __launch_bounds__(256)
 k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
           GridView g,
           FrameView fr, SlabView slab, double *__restrict__ d2_out, int *__restrict__ idx_out,
-          unsigned int *__restrict__ list, unsigned int *__restrict__ list_count) {
+          unsigned int *__restrict__ list, unsigned int *__restrict__ list_count, unsigned int xcd_chunk) {
     const int lane = threadIdx.x & 63;
-    const unsigned int per = gridDim.x / 8;  // XCD-aware chunking, gridDim.x is a multiple of 8
-    const unsigned int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const unsigned int vb = xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);  // gridDim.x is a multiple of 8
     const long long i = q_begin + (long long) vb * blockDim.x + threadIdx.x;
     bool active = i < q_end;
     const int cell_bits = kMortonBits - g.shift;
@@ -576,7 +575,8 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         {
             TimerScope ts(ctx, "nn_grid");
             hipLaunchKernelGGL(k_nn_grid, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
-                               r.n, r.nn_grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt);
+                               r.n, r.nn_grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt,
+                               xcd_chunk_setting());
         }
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)
