@@ -56,7 +56,7 @@ __device__ __forceinline__ double box_upper_bound(const float *__restrict__ b, d
 // tests 4x fewer candidates but is bound by vector-L1 tag lookups (~11 distinct lines per load instruction) and
 // loses; Chebyshev-1 groups serialise a wave into ~5 rounds on a fine grid and lose as well.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
           GridView g,
           FrameView fr, SlabView slab, double *__restrict__ d2_out, int *__restrict__ idx_out,
