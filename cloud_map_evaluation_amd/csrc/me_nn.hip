@@ -46,7 +46,7 @@ __device__ __forceinline__ double box_upper_bound(const float *__restrict__ b, d
 // Fast path: uniform-grid 1-NN.  A wavefront owns 64 consecutive (Morton-ordered) queries.  The lanes whose
 // reference-grid cell lies within Chebyshev distance 2 of the leader's form a group (normally the whole wave); the
 // group's cell box grown by one is resolved with one hash probe per (lane, slot) into a wave-private LDS table, and
-// every non-empty run is streamed ONCE with wave-uniform addresses (scalar loads: the candidate sits in SGPRs), every
+// every non-empty run is streamed ONCE through a wave-private LDS tile (one coalesced load per run, broadcast reads), every
 // lane keeping its own running minimum in fp64.  The grid level is the finest whose occupied cells hold >= 6 points.
 // A lane is RESOLVED when its best distance is below its distance to the faces of its own 3x3x3 block: every
 // reference point outside the block is farther, so the minimum is the exact global minimum.  Unresolved lanes
@@ -117,20 +117,42 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         best = vmin_f64(best, m);
         best_j = lt ? j : best_j;
     };
+    // Candidate delivery.  A run (the points of one cell) is copied into a wave-private LDS tile with ONE coalesced vector
+    // load per 64 points and read back with wave-uniform (broadcast) ds_reads, four candidates per group.  The first
+    // version fetched the candidates with scalar loads (s_load, candidate in SGPRs): the scalar cache misses on this
+    // stream (rocprofv3 SQC counters: 75 % of the requests), so every group of four paid an L2 round trip that 8 waves
+    // per SIMD could not hide (68 % VALU issue); one round trip per run and LDS latency in between is 9 % faster.
     // Every candidate is a real reference point, so lanes outside the current group (or already done) may test it as
-    // well: an extra candidate can only lower their bound.  No per-lane predicate means no exec juggling in the loop;
-    // the kernel issues about as many scalar as vector instructions, so the scalar side is kept lean: one pointer
-    // walk, four wave-uniform fetches in flight.
+    // well: an extra candidate can only lower their bound, hence no per-lane predicate in the loop.
+    __shared__ double s_tile[4][3][64];
+    double *tx = s_tile[threadIdx.x >> 6][0], *ty = s_tile[threadIdx.x >> 6][1], *tz = s_tile[threadIdx.x >> 6][2];
     auto stream_run = [&](int cs, int ce) {
-        const SPoint *p = rsp + cs;
-        int j = cs;
-        for (; j + 4 <= ce; j += 4, p += 4) {
-            const SPoint p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
-            test4(p0, p1, p2, p3, j);
-        }
-        for (; j < ce; ++j, ++p) {
-            const SPoint p0 = p[0];
-            test1(p0, j);
+        for (int base = cs; base < ce; base += 64) {
+            const int n = min(64, ce - base);
+            if (lane < n) {
+                const SPoint p = rsp[base + lane];
+                tx[lane] = p.x;
+                ty[lane] = p.y;
+                tz[lane] = p.z;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int j = 0;
+            for (; j + 4 <= n; j += 4) {
+                SPoint a, b, c, e;
+                a.x = tx[j], a.y = ty[j], a.z = tz[j];
+                b.x = tx[j + 1], b.y = ty[j + 1], b.z = tz[j + 1];
+                c.x = tx[j + 2], c.y = ty[j + 2], c.z = tz[j + 2];
+                e.x = tx[j + 3], e.y = ty[j + 3], e.z = tz[j + 3];
+                test4(a, b, c, e, base + j);
+            }
+            for (; j < n; ++j) {
+                SPoint a;
+                a.x = tx[j], a.y = ty[j], a.z = tz[j];
+                test1(a, base + j);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
         }
     };
     // (the candidate set of a round is a superset of the lane's own 3x3x3 block; extra candidates only help)
