@@ -26,6 +26,12 @@ __device__ __forceinline__ double vmin_f64(double a, double b) {
     return r;
 }
 
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ double box_lower_bound(const float *__restrict__ b, double qx, double qy, double qz) {
     const double dx = fmax(fmax((double) b[0] - qx, qx - (double) b[3]), 0.0);
     const double dy = fmax(fmax((double) b[1] - qy, qy - (double) b[4]), 0.0);
@@ -94,36 +100,42 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             mcz = (int) ((unsigned int) fz >> g.shift);
         }
     }
-    double best = INFINITY;
-    int best_j = -1;  // position in the sorted reference array (wave-uniform per candidate: no per-candidate idx load)
+    double best = INFINITY;    // smallest FAST distance seen (see below)
+    double second = INFINITY;  // second smallest among the group minima
+    int best_j = -1;  // position in the sorted reference array of the group that produced `best`
     bool done = !active || !in_grid;
 
-    // The hot loop keeps only (best, position of the GROUP of <= 4 stream-consecutive candidates that produced it):
-    // 8 fp64 ops per candidate for the distance plus 7 per group, instead of a compare and three selects per candidate.
-    // The epilogue re-tests that one group per lane to name the winner.  Strict <: the first group in stream order
-    // wins ties, and inside it the first position, so coincident reference points (one stable-sorted run) still
-    // resolve to the smallest original index.
-    auto test1 = [&](const SPoint &p, int j) {
-        const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
-        const bool lt = d < best;
-        best = lt ? d : best;
-        best_j = lt ? j : best_j;
+    // The hot loop ranks candidates by a FAST squared distance, fma(dz, dz, fma(dy, dy, dx*dx)): 6 fp64 ops instead of the
+    // 8 of the exact, unfused expression, and keeps only (best, runner-up, position of the GROUP of <= 4 stream-
+    // consecutive candidates that produced the best): 9 more ops per group.  The epilogue re-evaluates that one group
+    // EXACTLY ((dx*dx + dy*dy) + dz*dz, the CPU path's value) and names the winner (strict <: the first group in stream
+    // order keeps a tie, inside it the first position, so coincident reference points — one stable-sorted run — resolve
+    // to the smallest original index).  Fast and exact values differ by a few ulp, so the ranking can only be wrong when
+    // the runner-up lies within 1e-14 (relative) of the winner: those lanes (exact duplicates split over two groups,
+    // essentially) are handed to the octree kernel, which is exact.
+    // qx_eff = qx for the lanes of the current round's group, a huge value for the others: their distances come out
+    // infinite, so a lane never sees the same candidate twice when a later round streams an overlapping cell box (it
+    // would look like an exact tie), and the loop needs no exec juggling for the predicate.
+    double qx_eff = qx;
+    auto dist2_fast = [&](const SPoint &p) {
+        const double dx = qx_eff - p.x, dy = qy - p.y, dz = qz - p.z;
+        return fma(dz, dz, fma(dy, dy, dx * dx));
     };
-    auto test4 = [&](const SPoint &a, const SPoint &b, const SPoint &c, const SPoint &e, int j) {
-        const double d0 = dist2_exact(qx, qy, qz, a.x, a.y, a.z), d1 = dist2_exact(qx, qy, qz, b.x, b.y, b.z);
-        const double d2 = dist2_exact(qx, qy, qz, c.x, c.y, c.z), d3 = dist2_exact(qx, qy, qz, e.x, e.y, e.z);
-        const double m = vmin_f64(vmin_f64(d0, d1), vmin_f64(d2, d3));
+    auto note = [&](double m, int j) {
         const bool lt = m < best;
+        second = vmin_f64(second, vmax_f64(m, best));
         best = vmin_f64(best, m);
         best_j = lt ? j : best_j;
+    };
+    auto test1 = [&](const SPoint &p, int j) { note(dist2_fast(p), j); };
+    auto test4 = [&](const SPoint &a, const SPoint &b, const SPoint &c, const SPoint &e, int j) {
+        note(vmin_f64(vmin_f64(dist2_fast(a), dist2_fast(b)), vmin_f64(dist2_fast(c), dist2_fast(e))), j);
     };
     // Candidate delivery.  A run (the points of one cell) is copied into a wave-private LDS tile with ONE coalesced vector
     // load per 64 points and read back with wave-uniform (broadcast) ds_reads, four candidates per group.  The first
     // version fetched the candidates with scalar loads (s_load, candidate in SGPRs): the scalar cache misses on this
     // stream (rocprofv3 SQC counters: 75 % of the requests), so every group of four paid an L2 round trip that 8 waves
     // per SIMD could not hide (68 % VALU issue); one round trip per run and LDS latency in between is 9 % faster.
-    // Every candidate is a real reference point, so lanes outside the current group (or already done) may test it as
-    // well: an extra candidate can only lower their bound, hence no per-lane predicate in the loop.
     __shared__ double s_tile[4][3][64];
     double *tx = s_tile[threadIdx.x >> 6][0], *ty = s_tile[threadIdx.x >> 6][1], *tz = s_tile[threadIdx.x >> 6][2];
     auto stream_run = [&](int cs, int ce) {
@@ -162,6 +174,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         GroupBox bx;
         int nk = 0;
         const bool in = wave_group_table<1>(!done, mcx, mcy, mcz, g, cell_lim, lane, tab, bx, &nk);
+        qx_eff = in ? qx : 1e200;
         wave_for_each_run(tab, nk, lane, [&](int cs, int ce) { stream_run(cs, ce); });
         if (in) done = true;
         __builtin_amdgcn_wave_barrier();
@@ -170,7 +183,26 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     bool unresolved = false;
     if (active) {
         unresolved = true;
-        if (in_grid && best < INFINITY) {
+        // exact distances of the winning group (positions past the group's run belong to cells outside the candidate
+        // set: real reference points all the same, so a closer one among them is a better answer, not an error)
+        double best_x = INFINITY;
+        int best_i = -1;
+        if (best_j >= 0) {
+#pragma unroll
+            for (int t = 3; t >= 0; --t) {
+                const long long pos = (long long) best_j + t;
+                if (pos < nr) {
+                    const SPoint p = rsp[pos];
+                    const double e = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
+                    if (e <= best_x) {  // descending t: the first position keeps a tie
+                        best_x = e;
+                        best_i = (int) p.idx;
+                    }
+                }
+            }
+        }
+        const bool ranking_safe = second > best_x * (1.0 + 1e-14);
+        if (in_grid && best_j >= 0 && ranking_safe) {
             // distance from q to the faces of the 3x3x3 cell block around its cell (>= one cell edge... minus where
             // q sits in its cell); anything outside the block is at least that far away
             const double lox = fr.ox + (double) (mcx - 1) * cell_h, hix = fr.ox + (double) (mcx + 2) * cell_h;
@@ -178,22 +210,9 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             const double loz = fr.oz + (double) (mcz - 1) * cell_h, hiz = fr.oz + (double) (mcz + 2) * cell_h;
             double gmin = fmin(fmin(qx - lox, hix - qx), fmin(fmin(qy - loy, hiy - qy), fmin(qz - loz, hiz - qz)));
             gmin *= (1.0 - 1e-9);  // rounding slack of the cell assignment
-            unresolved = !(gmin > 0.0 && best < gmin * gmin);
+            unresolved = !(gmin > 0.0 && best_x < gmin * gmin);
         }
-        d2_out[i] = best;  // final if resolved, initial bound otherwise
-        int best_i = -1;
-        if (best_j >= 0) {  // name the winner inside its group: the first position whose distance IS the minimum
-            // (positions past the group's run belong to cells outside the candidate set; for a resolved lane they are
-            //  strictly farther than `best`, for an unresolved one any exact match is an equally valid bound)
-#pragma unroll
-            for (int t = 3; t >= 0; --t) {
-                const long long pos = (long long) best_j + t;
-                if (pos < nr) {
-                    const SPoint p = rsp[pos];
-                    if (dist2_exact(qx, qy, qz, p.x, p.y, p.z) == best) best_i = (int) p.idx;
-                }
-            }
-        }
+        d2_out[i] = best_x;  // final if resolved, initial bound otherwise
         idx_out[i] = best_i;
     }
     // wave-aggregated append of the unresolved lanes
