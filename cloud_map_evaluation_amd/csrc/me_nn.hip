@@ -100,69 +100,58 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             mcz = (int) ((unsigned int) fz >> g.shift);
         }
     }
-    double best = INFINITY;    // smallest FAST distance seen (see below)
+    double best = INFINITY;    // smallest RANK value seen (see below)
     double second = INFINITY;  // second smallest among the group minima
     int best_j = -1;  // position in the sorted reference array of the group that produced `best`
     bool done = !active || !in_grid;
 
-    // The hot loop ranks candidates by a FAST squared distance, fma(dz, dz, fma(dy, dy, dx*dx)): 6 fp64 ops instead of the
-    // 8 of the exact, unfused expression, and keeps only (best, runner-up, position of the GROUP of <= 4 stream-
-    // consecutive candidates that produced the best): 9 more ops per group.  The epilogue re-evaluates that one group
-    // EXACTLY ((dx*dx + dy*dy) + dz*dz, the CPU path's value) and names the winner (strict <: the first group in stream
-    // order keeps a tie, inside it the first position, so coincident reference points — one stable-sorted run — resolve
-    // to the smallest original index).  Fast and exact values differ by a few ulp, so the ranking can only be wrong when
-    // the runner-up lies within 1e-14 (relative) of the winner: those lanes (exact duplicates split over two groups,
-    // essentially) are handed to the octree kernel, which is exact.
-    // qx_eff = qx for the lanes of the current round's group, a huge value for the others: their distances come out
-    // infinite, so a lane never sees the same candidate twice when a later round streams an overlapping cell box (it
-    // would look like an exact tie), and the loop needs no exec juggling for the predicate.
-    double qx_eff = qx;
-    auto dist2_fast = [&](const SPoint &p) {
-        const double dx = qx_eff - p.x, dy = qy - p.y, dz = qz - p.z;
-        return fma(dz, dz, fma(dy, dy, dx * dx));
-    };
+    // Ranking.  argmin_p |p - q|^2 = argmin_p (|p|^2 - 2 p.q): with the candidates shifted to a wave-local origin o (the
+    // corner of the round's cell box; p' = p - o and |p'|^2 are computed ONCE per candidate when its run is staged) the
+    // hot loop ranks by  r = fma(p'x, ax, fma(p'y, ay, fma(p'z, az, |p'|^2))),  a = -2 (q - o):  3 fp64 ops per candidate
+    // instead of the 8 of the exact distance, plus 10 per group of four (min tree, runner-up, position of the group).
+    // |p'|, |q - o| < 8 cells, so r carries an absolute error of a few 1e-16 * (8 h)^2 — far below any real difference
+    // of squared distances — but it is not the CPU path's value: the epilogue re-evaluates the winning group EXACTLY
+    // ((dx*dx + dy*dy) + dz*dz) and names the winner (the first group in stream order keeps a tie, inside it the first
+    // position, so coincident reference points — one stable-sorted run — resolve to the smallest original index), and a
+    // lane whose runner-up group lies within `rank_tol` of the winner (exact duplicates split over two groups,
+    // essentially) is handed to the octree kernel, which is exact.
+    // bias = 0 for the lanes of the current round's group, +inf for the others: a lane ranks candidates in exactly one
+    // round (one origin), never sees a candidate twice, and the loop needs no exec juggling for the predicate.
+    double ax = 0, ay = 0, az = 0, bias = INFINITY;
+    const double rank_tol = 1e-11 * (3.0 * 64.0 * cell_h * cell_h);
     auto note = [&](double m, int j) {
+        m += bias;
         const bool lt = m < best;
         second = vmin_f64(second, vmax_f64(m, best));
         best = vmin_f64(best, m);
         best_j = lt ? j : best_j;
-    };
-    auto test1 = [&](const SPoint &p, int j) { note(dist2_fast(p), j); };
-    auto test4 = [&](const SPoint &a, const SPoint &b, const SPoint &c, const SPoint &e, int j) {
-        note(vmin_f64(vmin_f64(dist2_fast(a), dist2_fast(b)), vmin_f64(dist2_fast(c), dist2_fast(e))), j);
     };
     // Candidate delivery.  A run (the points of one cell) is copied into a wave-private LDS tile with ONE coalesced vector
     // load per 64 points and read back with wave-uniform (broadcast) ds_reads, four candidates per group.  The first
     // version fetched the candidates with scalar loads (s_load, candidate in SGPRs): the scalar cache misses on this
     // stream (rocprofv3 SQC counters: 75 % of the requests), so every group of four paid an L2 round trip that 8 waves
     // per SIMD could not hide (68 % VALU issue); one round trip per run and LDS latency in between is 9 % faster.
-    __shared__ double s_tile[4][3][64];
-    double *tx = s_tile[threadIdx.x >> 6][0], *ty = s_tile[threadIdx.x >> 6][1], *tz = s_tile[threadIdx.x >> 6][2];
+    __shared__ double s_tile[4][4][64];
+    double *tx = s_tile[threadIdx.x >> 6][0], *ty = s_tile[threadIdx.x >> 6][1], *tz = s_tile[threadIdx.x >> 6][2],
+           *tp = s_tile[threadIdx.x >> 6][3];
+    double ox = 0, oy = 0, oz = 0;  // the round's local origin (wave-uniform)
+    auto rank = [&](int j) { return fma(tx[j], ax, fma(ty[j], ay, fma(tz[j], az, tp[j]))); };
     auto stream_run = [&](int cs, int ce) {
         for (int base = cs; base < ce; base += 64) {
             const int n = min(64, ce - base);
             if (lane < n) {
                 const SPoint p = rsp[base + lane];
-                tx[lane] = p.x;
-                ty[lane] = p.y;
-                tz[lane] = p.z;
+                const double px = p.x - ox, py = p.y - oy, pz = p.z - oz;
+                tx[lane] = px;
+                ty[lane] = py;
+                tz[lane] = pz;
+                tp[lane] = fma(pz, pz, fma(py, py, px * px));
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             int j = 0;
-            for (; j + 4 <= n; j += 4) {
-                SPoint a, b, c, e;
-                a.x = tx[j], a.y = ty[j], a.z = tz[j];
-                b.x = tx[j + 1], b.y = ty[j + 1], b.z = tz[j + 1];
-                c.x = tx[j + 2], c.y = ty[j + 2], c.z = tz[j + 2];
-                e.x = tx[j + 3], e.y = ty[j + 3], e.z = tz[j + 3];
-                test4(a, b, c, e, base + j);
-            }
-            for (; j < n; ++j) {
-                SPoint a;
-                a.x = tx[j], a.y = ty[j], a.z = tz[j];
-                test1(a, base + j);
-            }
+            for (; j + 4 <= n; j += 4) note(vmin_f64(vmin_f64(rank(j), rank(j + 1)), vmin_f64(rank(j + 2), rank(j + 3))), base + j);
+            for (; j < n; ++j) note(rank(j), base + j);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
         }
@@ -174,7 +163,15 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         GroupBox bx;
         int nk = 0;
         const bool in = wave_group_table<1>(!done, mcx, mcy, mcz, g, cell_lim, lane, tab, bx, &nk);
-        qx_eff = in ? qx : 1e200;
+        ox = fr.ox + (double) bx.x0 * cell_h;
+        oy = fr.oy + (double) bx.y0 * cell_h;
+        oz = fr.oz + (double) bx.z0 * cell_h;
+        if (in) {
+            ax = -2.0 * (qx - ox);
+            ay = -2.0 * (qy - oy);
+            az = -2.0 * (qz - oz);
+        }
+        bias = in ? 0.0 : INFINITY;
         wave_for_each_run(tab, nk, lane, [&](int cs, int ce) { stream_run(cs, ce); });
         if (in) done = true;
         __builtin_amdgcn_wave_barrier();
@@ -201,7 +198,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
                 }
             }
         }
-        const bool ranking_safe = second > best_x * (1.0 + 1e-14);
+        const bool ranking_safe = second - best > rank_tol;
         if (in_grid && best_j >= 0 && ranking_safe) {
             // distance from q to the faces of the 3x3x3 cell block around its cell (>= one cell edge... minus where
             // q sits in its cell); anything outside the block is at least that far away
