@@ -100,57 +100,59 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             mcz = (int) ((unsigned int) fz >> g.shift);
         }
     }
-    double best = INFINITY;    // smallest RANK value seen (see below)
-    double second = INFINITY;  // second smallest among the group minima
-    int best_j = -1;  // position in the sorted reference array of the group that produced `best`
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;  // the three smallest group ranks seen (see below)
+    int j1 = -1, j2 = -1;  // positions (in the sorted reference array) of the groups that produced b1 and b2
     bool done = !active || !in_grid;
 
-    // Ranking.  argmin_p |p - q|^2 = argmin_p (|p|^2 - 2 p.q): with the candidates shifted to a wave-local origin o (the
-    // corner of the round's cell box; p' = p - o and |p'|^2 are computed ONCE per candidate when its run is staged) the
-    // hot loop ranks by  r = fma(p'x, ax, fma(p'y, ay, fma(p'z, az, |p'|^2))),  a = -2 (q - o):  3 fp64 ops per candidate
-    // instead of the 8 of the exact distance, plus 10 per group of four (min tree, runner-up, position of the group).
-    // |p'|, |q - o| < 8 cells, so r carries an absolute error of a few 1e-16 * (8 h)^2 — far below any real difference
-    // of squared distances — but it is not the CPU path's value: the epilogue re-evaluates the winning group EXACTLY
-    // ((dx*dx + dy*dy) + dz*dz) and names the winner (the first group in stream order keeps a tie, inside it the first
-    // position, so coincident reference points — one stable-sorted run — resolve to the smallest original index), and a
-    // lane whose runner-up group lies within `rank_tol` of the winner (exact duplicates split over two groups,
-    // essentially) is handed to the octree kernel, which is exact.
+    // Ranking.  argmin_p |p - q|^2 = argmin_p (|p|^2 - 2 p.q).  With the candidates shifted to a wave-local origin o (the
+    // corner of the round's cell box, |p - o| and |q - o| < 8 cells) the rank
+    //     r = fma(p'x, ax, fma(p'y, ay, fma(p'z, az, |p'|^2))),   p' = p - o,  a = -2 (q - o)
+    // is accurate enough in FP32 to ORDER candidates down to ~1e-6 (cell edge 0.1 m) of squared distance: p' and |p'|^2
+    // are computed in fp64 ONCE per candidate when its run is staged and stored as one float4, so a candidate costs one
+    // 16-byte broadcast LDS read and 3 fp32 FMAs per lane (the fp64 variant of this loop was bound by LDS bandwidth:
+    // 32 bytes per candidate broadcast to 64 lanes).  The loop keeps the two best GROUPS of <= 4 stream-consecutive
+    // candidates (rank + position) and the third-best rank.  The epilogue evaluates both groups EXACTLY in fp64
+    // ((dx*dx + dy*dy) + dz*dz, the CPU path's value; ties -> smallest original index, as the CPU path) — every
+    // candidate outside them ranks at least b3, so the exact minimum over the two groups is the answer whenever
+    // b3 - b1 exceeds twice the rank error (rank_tol).  The few lanes where it does not (about 0.05 %: three near-equal
+    // neighbours, or duplicates spread over three groups) go to the octree kernel, which is exact.
     // bias = 0 for the lanes of the current round's group, +inf for the others: a lane ranks candidates in exactly one
     // round (one origin), never sees a candidate twice, and the loop needs no exec juggling for the predicate.
-    double ax = 0, ay = 0, az = 0, bias = INFINITY;
-    const double rank_tol = 1e-11 * (3.0 * 64.0 * cell_h * cell_h);
-    auto note = [&](double m, int j) {
+    float ax = 0, ay = 0, az = 0, bias = INFINITY;
+    const float rank_tol = (float) (4e-4 * cell_h * cell_h);
+    auto note = [&](float m, int j) {
         m += bias;
-        const bool lt = m < best;
-        second = vmin_f64(second, vmax_f64(m, best));
-        best = vmin_f64(best, m);
-        best_j = lt ? j : best_j;
+        const bool lt1 = m < b1, lt2 = m < b2;
+        b3 = fminf(b3, fmaxf(m, b2));
+        b2 = fminf(b2, fmaxf(m, b1));
+        j2 = lt1 ? j1 : (lt2 ? j : j2);
+        b1 = fminf(b1, m);
+        j1 = lt1 ? j : j1;
     };
     // Candidate delivery.  A run (the points of one cell) is copied into a wave-private LDS tile with ONE coalesced vector
     // load per 64 points and read back with wave-uniform (broadcast) ds_reads, four candidates per group.  The first
     // version fetched the candidates with scalar loads (s_load, candidate in SGPRs): the scalar cache misses on this
     // stream (rocprofv3 SQC counters: 75 % of the requests), so every group of four paid an L2 round trip that 8 waves
-    // per SIMD could not hide (68 % VALU issue); one round trip per run and LDS latency in between is 9 % faster.
-    __shared__ double s_tile[4][4][64];
-    double *tx = s_tile[threadIdx.x >> 6][0], *ty = s_tile[threadIdx.x >> 6][1], *tz = s_tile[threadIdx.x >> 6][2],
-           *tp = s_tile[threadIdx.x >> 6][3];
+    // per SIMD could not hide (68 % VALU issue).
+    __shared__ float4 s_tile[4][64];
+    float4 *tile = s_tile[threadIdx.x >> 6];
     double ox = 0, oy = 0, oz = 0;  // the round's local origin (wave-uniform)
-    auto rank = [&](int j) { return fma(tx[j], ax, fma(ty[j], ay, fma(tz[j], az, tp[j]))); };
+    auto rank = [&](int j) {
+        const float4 c = tile[j];
+        return fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
+    };
     auto stream_run = [&](int cs, int ce) {
         for (int base = cs; base < ce; base += 64) {
             const int n = min(64, ce - base);
             if (lane < n) {
                 const SPoint p = rsp[base + lane];
                 const double px = p.x - ox, py = p.y - oy, pz = p.z - oz;
-                tx[lane] = px;
-                ty[lane] = py;
-                tz[lane] = pz;
-                tp[lane] = fma(pz, pz, fma(py, py, px * px));
+                tile[lane] = make_float4((float) px, (float) py, (float) pz, (float) fma(pz, pz, fma(py, py, px * px)));
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             int j = 0;
-            for (; j + 4 <= n; j += 4) note(vmin_f64(vmin_f64(rank(j), rank(j + 1)), vmin_f64(rank(j + 2), rank(j + 3))), base + j);
+            for (; j + 4 <= n; j += 4) note(fminf(fminf(rank(j), rank(j + 1)), fminf(rank(j + 2), rank(j + 3))), base + j);
             for (; j < n; ++j) note(rank(j), base + j);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
@@ -167,11 +169,11 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         oy = fr.oy + (double) bx.y0 * cell_h;
         oz = fr.oz + (double) bx.z0 * cell_h;
         if (in) {
-            ax = -2.0 * (qx - ox);
-            ay = -2.0 * (qy - oy);
-            az = -2.0 * (qz - oz);
+            ax = (float) (-2.0 * (qx - ox));
+            ay = (float) (-2.0 * (qy - oy));
+            az = (float) (-2.0 * (qz - oz));
         }
-        bias = in ? 0.0 : INFINITY;
+        bias = in ? 0.0f : INFINITY;
         wave_for_each_run(tab, nk, lane, [&](int cs, int ce) { stream_run(cs, ce); });
         if (in) done = true;
         __builtin_amdgcn_wave_barrier();
@@ -180,26 +182,29 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     bool unresolved = false;
     if (active) {
         unresolved = true;
-        // exact distances of the winning group (positions past the group's run belong to cells outside the candidate
-        // set: real reference points all the same, so a closer one among them is a better answer, not an error)
+        // exact distances of the two best groups (positions past a group's run belong to cells outside the candidate set:
+        // real reference points all the same, so a closer one among them is a better answer, not an error)
         double best_x = INFINITY;
-        int best_i = -1;
-        if (best_j >= 0) {
+        long long best_i = 0x7fffffffffffffffLL;
+        auto exact_group = [&](int jg) {
+            if (jg < 0) return;
 #pragma unroll
-            for (int t = 3; t >= 0; --t) {
-                const long long pos = (long long) best_j + t;
+            for (int t = 0; t < 4; ++t) {
+                const long long pos = (long long) jg + t;
                 if (pos < nr) {
                     const SPoint p = rsp[pos];
                     const double e = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
-                    if (e <= best_x) {  // descending t: the first position keeps a tie
+                    if (e < best_x || (e == best_x && p.idx < best_i)) {
                         best_x = e;
-                        best_i = (int) p.idx;
+                        best_i = p.idx;
                     }
                 }
             }
-        }
-        const bool ranking_safe = second - best > rank_tol;
-        if (in_grid && best_j >= 0 && ranking_safe) {
+        };
+        exact_group(j1);
+        exact_group(j2);
+        const bool ranking_safe = b3 - b1 > rank_tol;
+        if (in_grid && j1 >= 0 && ranking_safe) {
             // distance from q to the faces of the 3x3x3 cell block around its cell (>= one cell edge... minus where
             // q sits in its cell); anything outside the block is at least that far away
             const double lox = fr.ox + (double) (mcx - 1) * cell_h, hix = fr.ox + (double) (mcx + 2) * cell_h;
@@ -210,7 +215,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             unresolved = !(gmin > 0.0 && best_x < gmin * gmin);
         }
         d2_out[i] = best_x;  // final if resolved, initial bound otherwise
-        idx_out[i] = best_i;
+        idx_out[i] = (j1 >= 0) ? (int) best_i : -1;
     }
     // wave-aggregated append of the unresolved lanes
     const unsigned long long um = __ballot(unresolved);
