@@ -53,7 +53,8 @@ __device__ __forceinline__ double box_upper_bound(const float *__restrict__ b, d
 // reference-grid cell lies within Chebyshev distance 2 of the leader's form a group (normally the whole wave); the
 // group's cell box grown by one is resolved with one hash probe per (lane, slot) into a wave-private LDS table, and
 // every non-empty run is streamed ONCE through a wave-private LDS tile (one coalesced load per run, broadcast reads), every
-// lane keeping its own running minimum in fp64.  The grid level is the finest whose occupied cells hold >= 6 points.
+// lane ranking the candidates in FP32 and settling the winner exactly in fp64 afterwards (see "Ranking" below).  The grid
+// level is the finest whose occupied cells hold >= 6 points.
 // A lane is RESOLVED when its best distance is below its distance to the faces of its own 3x3x3 block: every
 // reference point outside the block is farther, so the minimum is the exact global minimum.  Unresolved lanes
 // (no neighbour within about one cell edge: outliers, non-overlapping map regions, queries outside the reference
