@@ -120,7 +120,9 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     // bias = 0 for the lanes of the current round's group, +inf for the others: a lane ranks candidates in exactly one
     // round (one origin), never sees a candidate twice, and the loop needs no exec juggling for the predicate.
     float ax = 0, ay = 0, az = 0, bias = INFINITY;
-    const float rank_tol = (float) (4e-4 * cell_h * cell_h);
+    // rank error: the cell box spans <= 7 cells per axis, so |p'| <= 12 h, |a| <= 24 h, every term of r is below ~150 h^2
+    // and carries a few 2^-24 relative: E < 1.2e-4 h^2 in the worst case (typically 10x less); the check uses 2E with margin
+    const float rank_tol = (float) (1e-3 * cell_h * cell_h);
     auto note = [&](float m, int j) {
         m += bias;
         const bool lt1 = m < b1, lt2 = m < b2;
