@@ -19,6 +19,7 @@ SYMBOLS = [
     "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_patch", "me_voxel_partials",
     "me_upload_cloud", "me_upload_cloud_device", "me_cloud_size", "me_download_cloud", "me_voxel_downsample",
     "me_transform_cloud",
+    "me_set_normals", "me_get_normals", "me_estimate_normals", "me_gicp_covariances", "me_get_covariances", "me_icp_lsq_sums",
     "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats", "me_nn_partial_sums", "me_nn_sigma_sums", "me_nn_finalize", "me_chamfer",
     "me_mme", "me_voxel_gaussians", "me_awd_scs", "me_w2_batch", "me_scs_table", "me_run_suite",
     "me_timers_enable", "me_timers_reset", "me_timer_get",
@@ -44,6 +45,17 @@ class IcpSums(C.Structure):
         ("sum_p", C.c_double * 3),
         ("sum_q", C.c_double * 3),
         ("sum_pq", C.c_double * 9),
+        ("sum_d2", C.c_double),
+    ]
+
+
+class IcpLsq(C.Structure):
+    _fields_ = [
+        ("n_corr", C.c_int64),
+        ("n_source", C.c_int64),
+        ("JTJ", C.c_double * 36),
+        ("JTr", C.c_double * 6),
+        ("r2", C.c_double),
         ("sum_d2", C.c_double),
     ]
 
@@ -132,6 +144,15 @@ def load():
     L.me_nn1.argtypes = [vp, C.c_int, C.c_int, ip, dp]
     L.me_icp_p2p_sums.argtypes = [vp, C.c_int, C.c_double, C.POINTER(IcpSums)]
     L.me_icp_p2p_sums.restype = C.c_int
+    L.me_set_normals.argtypes = [vp, C.c_int, dp]
+    L.me_get_normals.argtypes = [vp, C.c_int, dp]
+    L.me_estimate_normals.argtypes = [vp, C.c_int, C.c_int, dp, ip, dp]
+    L.me_gicp_covariances.argtypes = [vp, C.c_int, C.c_double, dp]
+    L.me_get_covariances.argtypes = [vp, C.c_int, dp]
+    L.me_get_covariances.restype = C.c_int
+    L.me_icp_lsq_sums.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.POINTER(IcpLsq)]
+    for f in ("me_set_normals", "me_get_normals", "me_estimate_normals", "me_gicp_covariances", "me_icp_lsq_sums"):
+        getattr(L, f).restype = C.c_int
     L.me_render_distance.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp]
     L.me_render_distance.restype = C.c_int
     L.me_render_entropy.argtypes = [vp, C.c_int, vp, vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double),

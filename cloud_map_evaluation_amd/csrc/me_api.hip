@@ -196,6 +196,36 @@ int me_icp_p2p_sums(me_ctx *ctx, int query_slot, double max_distance, me_icp_sum
     return me::icp_p2p_sums(ctx, query_slot, max_distance, out);
 }
 
+int me_set_normals(me_ctx *ctx, int slot, const double *normals) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::set_normals(ctx, slot, normals);
+}
+
+int me_get_normals(me_ctx *ctx, int slot, double *normals) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::get_normals(ctx, slot, normals);
+}
+
+int me_estimate_normals(me_ctx *ctx, int slot, int knn, double *normals, int32_t *knn_idx, double *knn_d2) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::estimate_normals(ctx, slot, knn, normals, knn_idx, knn_d2);
+}
+
+int me_gicp_covariances(me_ctx *ctx, int slot, double epsilon, double *cov) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::gicp_covariances(ctx, slot, epsilon, cov);
+}
+
+int me_get_covariances(me_ctx *ctx, int slot, double *cov) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::get_covariances(ctx, slot, cov);
+}
+
+int me_icp_lsq_sums(me_ctx *ctx, int query_slot, int mode, double max_distance, me_icp_lsq *out) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::icp_lsq_sums(ctx, query_slot, mode, max_distance, out);
+}
+
 int me_render_distance(me_ctx *ctx, int query_slot, double dis, double gate, int gate_mode, double *rgb, uint8_t *inlier) {
     if (!ctx) return ME_ERR_ARG;
     return me::render_distance(ctx, query_slot, dis, gate, gate_mode, rgb, inlier);

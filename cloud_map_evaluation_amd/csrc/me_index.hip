@@ -304,6 +304,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
     ctx->cloud[1 - slot].nn_ref_slot = -1;
     c.n = n;
     c.n_total = n;
+    c.have_normals = c.have_cov = false;
     c.slab = ctx->slab;
     c.n_unres = 0;
     if (ctx->slab.axis < 0) {
@@ -396,6 +397,7 @@ int cloud_transform(me_ctx *ctx, int slot, const double *T) {
     Mat4 m;
     std::memcpy(m.m, T, sizeof(m.m));
     hipLaunchKernelGGL(k_transform, dim3(grid_for(c.n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), c.n, m);
+    ME_TRY(rotate_attributes(ctx, slot, T));  // normals / covariances follow the points (Open3D PointCloud::Transform)
     return cloud_finish(ctx, slot);
 }
 

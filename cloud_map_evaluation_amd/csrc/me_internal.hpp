@@ -149,6 +149,10 @@ struct Cloud {
     DevBuf vox_mu;     // double[V][3]
     DevBuf vox_sigma;  // double[V][9] as stored by the reference
     DevBuf vox_entropy;
+    // per-point attributes of the registration path, ORIGINAL point order (me_reg.hip)
+    DevBuf normals;  // double[n][3]
+    DevBuf cov;      // double[n][9] generalized-ICP covariances
+    bool have_normals = false, have_cov = false;
 };
 
 struct TimerRec {
@@ -262,6 +266,15 @@ int nn_patch(me_ctx *ctx, int qslot, const double *d2_device, long long count);
 int icp_p2p_sums(me_ctx *ctx, int qslot, double max_distance, me_icp_sums *out);
 int nn_partial(me_ctx *ctx, int qslot, double gate, int gate_mode, const double trunc[5], me_nn_partial *out);
 int nn_sigma(me_ctx *ctx, int qslot, double gate, int gate_mode, const double mean[5], double sigma_num[5]);
+
+// ---- me_reg.hip (registration_methods 1 / 2) ----
+int set_normals(me_ctx *ctx, int slot, const double *normals_host);
+int get_normals(me_ctx *ctx, int slot, double *normals_host);
+int estimate_normals(me_ctx *ctx, int slot, int knn, double *normals_host, int32_t *knn_idx_host, double *knn_d2_host);
+int gicp_covariances(me_ctx *ctx, int slot, double epsilon, double *cov_host);
+int get_covariances(me_ctx *ctx, int slot, double *cov_host);
+int rotate_attributes(me_ctx *ctx, int slot, const double *T);
+int icp_lsq_sums(me_ctx *ctx, int qslot, int mode, double max_distance, me_icp_lsq *out);
 
 // ---- me_mme.hip ----
 int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, uint8_t *valid, double *sum_H,

@@ -920,6 +920,12 @@ int voxel_downsample(me_ctx *ctx, int slot, double voxel_size, long long *n_out)
     hipLaunchKernelGGL(k_vds_mean, dim3(grid_for(V)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), perm.as<unsigned int>(),
                        seg_start.as<unsigned int>(), V, out.as<double>());
     ME_CHECK(ctx, hipMemcpyAsync(c.xyz.p, out.p, (size_t) V * 24, hipMemcpyDeviceToDevice, ctx->stream));
+    if (c.have_normals) {  // Open3D averages the normals of a voxel as well (sum / count, not re-normalised)
+        hipLaunchKernelGGL(k_vds_mean, dim3(grid_for(V)), dim3(256), 0, ctx->stream, c.normals.as<double>(), perm.as<unsigned int>(),
+                           seg_start.as<unsigned int>(), V, out.as<double>());
+        ME_CHECK(ctx, hipMemcpyAsync(c.normals.p, out.p, (size_t) V * 24, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    c.have_cov = false;
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
     c.n = V;

@@ -211,10 +211,55 @@ class Engine:
             self._ck(self._L.me_render_entropy(self._ctx, slot, _addr(xyz), _addr(rgb), m.value, C.byref(m), C.byref(mn), C.byref(mx)))
         return xyz, rgb, mn.value, mx.value
 
-    def performICPRegistration(self, max_distance: float, **criteria):
-        """map_eval.cpp:1369-1371, registration_methods 0 (point-to-point); see icp.icp_point_to_point."""
-        from .icp import icp_point_to_point
-        return icp_point_to_point(self, max_distance, **criteria)
+    def set_normals(self, slot: int, normals) -> None:
+        """Normals that came with the cloud (N,3), caller's point order."""
+        nrm = np.ascontiguousarray(normals, dtype=np.float64)
+        if nrm.shape != (self.size(slot), 3):
+            raise ValueError("normals must be (N,3) for the N points of the slot")
+        self._ck(self._L.me_set_normals(self._ctx, slot, _addr(nrm)))
+
+    def get_normals(self, slot: int) -> np.ndarray:
+        out = np.empty((self.size(slot), 3), np.float64)
+        self._ck(self._L.me_get_normals(self._ctx, slot, _addr(out)))
+        return out
+
+    def estimate_normals(self, slot: int, knn: int = 20, fetch: bool = True, with_neighbours: bool = False):
+        """open3d EstimateNormals(KDTreeSearchParamKNN(knn)) -> normals (N,3) [, knn_idx (N,knn), knn_d2 (N,knn)]."""
+        n = self.size(slot)
+        nrm = np.empty((n, 3), np.float64) if fetch else None
+        idx = np.empty((n, knn), np.int32) if with_neighbours else None
+        d2 = np.empty((n, knn), np.float64) if with_neighbours else None
+        self._ck(self._L.me_estimate_normals(self._ctx, slot, int(knn), _addr(nrm) if fetch else 0,
+                                             _addr(idx) if with_neighbours else 0, _addr(d2) if with_neighbours else 0))
+        return (nrm, idx, d2) if with_neighbours else nrm
+
+    def gicp_covariances(self, slot: int, epsilon: float = 1e-3, fetch: bool = False):
+        """open3d InitializePointCloudForGeneralizedICP -> (N,3,3) when fetch."""
+        out = np.empty((self.size(slot), 9), np.float64) if fetch else None
+        self._ck(self._L.me_gicp_covariances(self._ctx, slot, float(epsilon), _addr(out) if fetch else 0))
+        return out.reshape(-1, 3, 3) if fetch else None
+
+    def get_covariances(self, slot: int) -> np.ndarray:
+        out = np.empty((self.size(slot), 9), np.float64)
+        self._ck(self._L.me_get_covariances(self._ctx, slot, _addr(out)))
+        return out.reshape(-1, 3, 3)
+
+    def icp_lsq_sums(self, query_slot: int, mode: int, max_distance: float) -> _lib.IcpLsq:
+        """J^T J, J^T r of one point-to-plane (mode 1) / generalized (mode 2) step over the last nn1(query_slot, ...)."""
+        out = _lib.IcpLsq()
+        self._ck(self._L.me_icp_lsq_sums(self._ctx, query_slot, int(mode), float(max_distance), C.byref(out)))
+        return out
+
+    def performICPRegistration(self, max_distance: float, method: int = 0, **criteria):
+        """map_eval.cpp:1366-1394: registration_methods 0 point-to-point, 1 point-to-plane, 2 generalized ICP (see icp.py)."""
+        from . import icp
+        if method == 0:
+            return icp.icp_point_to_point(self, max_distance, **criteria)
+        if method == 1:
+            return icp.icp_point_to_plane(self, max_distance, **criteria)
+        if method == 2:
+            return icp.icp_generalized(self, max_distance, **criteria)
+        raise MapEvalError("Invalid registration type specified")  # (:1385-1387)
 
     def computeChamferDistance(self) -> float:
         """map_eval.cpp:1398-1431 on the uploaded pair."""

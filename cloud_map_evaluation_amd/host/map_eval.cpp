@@ -174,7 +174,8 @@ int MapEval::process() {
     // ground truth: .pcd or .ply by extension (map_eval.cpp:9-17)
     const std::string ext = param_.map_gt_path_.substr(param_.map_gt_path_.find_last_of(".") + 1);
     bool ok_gt;
-    if (ext == "pcd") ok_gt = pcio::read_pcd(param_.map_gt_path_, gt_3d_->points_, &err);
+    std::vector<double> gt_normals;  // normal_x/y/z of the ground truth, if the file has them (point-to-plane ICP needs them)
+    if (ext == "pcd") ok_gt = pcio::read_pcd(param_.map_gt_path_, gt_3d_->points_, &err, &gt_normals);
     else if (ext == "ply") ok_gt = pcio::read_ply(param_.map_gt_path_, gt_3d_->points_, &err);
     else return fail("Unsupported ground truth file format: " + param_.map_gt_path_);
     if (!ok_gt) std::cerr << "WARNING: " << err << std::endl;
@@ -195,7 +196,10 @@ int MapEval::process() {
     if (me_upload_cloud(ctx_, ME_SLOT_GT, gt_3d_->points_.data(), (int64_t) gt_3d_->size(), nullptr, param_.nn_radius_) != ME_OK ||
         me_upload_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data(), (int64_t) map_3d_->size(), nullptr, param_.nn_radius_) != ME_OK)
         return fail(me_last_error(ctx_));
-    // map_3d_ = map_3d_->VoxelDownSample(downsample_size) (:38-39), on the device
+    if (gt_normals.size() == gt_3d_->points_.size() && !gt_normals.empty() &&
+        me_set_normals(ctx_, ME_SLOT_GT, gt_normals.data()) != ME_OK)
+        return fail(me_last_error(ctx_));
+    // map_3d_ = map_3d_->VoxelDownSample(downsample_size) (:38-39), on the device (normals are averaged with the points)
     if (param_.downsample_size > 0) {
         int64_t ne = 0, ng = 0;
         if (me_voxel_downsample(ctx_, ME_SLOT_EST, param_.downsample_size, &ne) != ME_OK ||
@@ -238,11 +242,10 @@ int MapEval::process() {
         calculateMetricsWithInitialMatrix();
         if (!last_error.empty()) return -1;
     } else {
-        // performRegistration (map_eval.cpp:191-237).  Point-to-point ICP (registration_methods: 0) runs on the device-side
-        // correspondence + reduction step; point-to-plane (1) and GICP (2) are Open3D optimisers this build does not provide.
-        if (param_.evaluation_method_ != 0)
-            return fail("registration_methods 1 (point-to-plane) / 2 (GICP) are not provided: use 0 (point-to-point ICP), or pass "
-                        "the alignment as initial_matrix and set evaluate_using_initial: true");
+        // performRegistration (map_eval.cpp:191-237): point-to-point (0), point-to-plane (1) and generalized ICP (2) all run
+        // on the device-side correspondence + reduction step; the small solve per iteration is done here.
+        if (param_.evaluation_method_ < 0 || param_.evaluation_method_ > 2)
+            return fail("Invalid registration type specified");  // (:1385-1387)
         if (performRegistration() != 0) return -1;
     }
     if (param_.evaluate_using_initial_) t5 = t4 = t3 = tic_toc.toc();
@@ -329,6 +332,52 @@ void kabsch_from_sums(const me_icp_sums &s, double T[16]) {
     }
 }
 
+// utility::SolveJacobianSystemAndObtainExtrinsicMatrix [Open3D, upstream]: x = solve(JTJ, -JTr) (LDLT there, Gaussian
+// elimination with partial pivoting here), then TransformVector6dToMatrix4d: R = Rz(x2) Ry(x1) Rx(x0), t = x[3..5].
+// A singular system leaves the identity (ComputeTransformation's failure value).
+void lsq_update(const me_icp_lsq &q, double T[16]) {
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    double A[6][7];
+    for (int r = 0; r < 6; ++r) {
+        for (int c = 0; c < 6; ++c) A[r][c] = q.JTJ[6 * r + c];
+        A[r][6] = -q.JTr[r];
+    }
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        for (int r = k + 1; r < 6; ++r)
+            if (std::fabs(A[r][k]) > std::fabs(A[piv][k])) piv = r;
+        if (A[piv][k] == 0.0 || !std::isfinite(A[piv][k])) return;
+        if (piv != k)
+            for (int c = 0; c < 7; ++c) std::swap(A[piv][c], A[k][c]);
+        for (int r = k + 1; r < 6; ++r) {
+            const double f = A[r][k] / A[k][k];
+            for (int c = k; c < 7; ++c) A[r][c] -= f * A[k][c];
+        }
+    }
+    double x[6];
+    for (int k = 5; k >= 0; --k) {
+        double acc = A[k][6];
+        for (int c = k + 1; c < 6; ++c) acc -= A[k][c] * x[c];
+        x[k] = acc / A[k][k];
+        if (!std::isfinite(x[k])) return;
+    }
+    const double ca = std::cos(x[0]), sa = std::sin(x[0]), cb = std::cos(x[1]), sb = std::sin(x[1]), cg = std::cos(x[2]),
+                 sg = std::sin(x[2]);
+    // Rz(g) * Ry(b) * Rx(a)
+    T[0] = cg * cb;
+    T[1] = cg * sb * sa - sg * ca;
+    T[2] = cg * sb * ca + sg * sa;
+    T[4] = sg * cb;
+    T[5] = sg * sb * sa + cg * ca;
+    T[6] = sg * sb * ca - cg * sa;
+    T[8] = -sb;
+    T[9] = cb * sa;
+    T[10] = cb * ca;
+    T[3] = x[3];
+    T[7] = x[4];
+    T[11] = x[5];
+}
+
 void matmul4(const double A[16], const double B[16], double C[16]) {
     double out[16];
     for (int r = 0; r < 4; ++r)
@@ -349,12 +398,28 @@ int MapEval::performRegistration() {
     for (int i = 0; i < 16; ++i) trans[i] = param_.initial_matrix_[i];
     bool identity = true;
     for (int i = 0; i < 16; ++i) identity = identity && (trans[i] == ((i % 5 == 0) ? 1.0 : 0.0));
+    const int method = param_.evaluation_method_;
+    if (method == 2) {
+        // RegistrationGeneralizedICP (:1378-1384): InitializePointCloudForGeneralizedICP(epsilon = 1e-3) on both clouds as
+        // loaded (normals from the 20 nearest neighbours where a cloud has none); they rotate with the map from here on
+        if (me_gicp_covariances(ctx_, ME_SLOT_EST, 1e-3, nullptr) != ME_OK || me_gicp_covariances(ctx_, ME_SLOT_GT, 1e-3, nullptr) != ME_OK)
+            return fail(me_last_error(ctx_));
+    }
     if (!identity && me_transform_cloud(ctx_, ME_SLOT_EST, trans.data()) != ME_OK) return fail(me_last_error(ctx_));
     me_icp_sums s;
+    me_icp_lsq q;
     auto evaluate = [&](double &fit, double &rmse) -> bool {
-        if (me_nn1(ctx_, ME_SLOT_EST, ME_SLOT_GT, nullptr, nullptr) != ME_OK ||
-            me_icp_p2p_sums(ctx_, ME_SLOT_EST, param_.icp_max_distance_, &s) != ME_OK)
-            return false;
+        if (me_nn1(ctx_, ME_SLOT_EST, ME_SLOT_GT, nullptr, nullptr) != ME_OK) return false;
+        if (method == 0) {
+            if (me_icp_p2p_sums(ctx_, ME_SLOT_EST, param_.icp_max_distance_, &s) != ME_OK) return false;
+        } else {
+            // TransformationEstimationPointToPlane (:1373-1377) needs normals on the target, as in Open3D
+            if (me_icp_lsq_sums(ctx_, ME_SLOT_EST, method == 1 ? ME_ICP_POINT_TO_PLANE : ME_ICP_GENERALIZED, param_.icp_max_distance_, &q) != ME_OK)
+                return false;
+            s.n_corr = q.n_corr;
+            s.n_source = q.n_source;
+            s.sum_d2 = q.sum_d2;
+        }
         fit = s.n_source ? (double) s.n_corr / (double) s.n_source : 0.0;
         rmse = s.n_corr ? std::sqrt(s.sum_d2 / (double) s.n_corr) : 0.0;
         return true;
@@ -363,9 +428,10 @@ int MapEval::performRegistration() {
     if (!evaluate(fit, rmse)) return fail(me_last_error(ctx_));
     int it = 0;
     for (it = 1; it <= 30; ++it) {
-        if (s.n_corr < 3) break;
+        if (method == 0 ? s.n_corr < 3 : s.n_corr == 0) break;
         double upd[16];
-        kabsch_from_sums(s, upd);
+        if (method == 0) kabsch_from_sums(s, upd);
+        else lsq_update(q, upd);
         matmul4(upd, trans.data(), trans.data());
         if (me_transform_cloud(ctx_, ME_SLOT_EST, upd) != ME_OK) return fail(me_last_error(ctx_));
         const double pf = fit, pr = rmse;

@@ -72,15 +72,20 @@ inline size_t lzf_decompress(const unsigned char *in, size_t in_len, unsigned ch
     return (size_t) (op - out);
 }
 
-inline void push_if_finite(std::vector<double> &xyz, double x, double y, double z) {
+inline bool push_if_finite(std::vector<double> &xyz, double x, double y, double z) {
     if (std::isfinite(x) && std::isfinite(y) && std::isfinite(z)) {
         xyz.push_back(x);
         xyz.push_back(y);
         xyz.push_back(z);
+        return true;
     }
+    return false;
 }
 
-inline bool read_pcd(const std::string &path, std::vector<double> &xyz, std::string *err = nullptr) {
+// normals (optional): filled with normal_x / normal_y / normal_z of the kept points when the file has those fields
+// (Open3D's reader does the same: PointCloud::HasNormals() is what point-to-plane ICP asks for), left empty otherwise.
+inline bool read_pcd(const std::string &path, std::vector<double> &xyz, std::string *err = nullptr,
+                     std::vector<double> *normals = nullptr) {
     auto fail = [&](const std::string &m) {
         if (err) *err = m;
         return false;
@@ -114,7 +119,7 @@ inline bool read_pcd(const std::string &path, std::vector<double> &xyz, std::str
     if (sizes.size() != names.size() || types.size() != names.size() || counts.size() != names.size())
         return fail("inconsistent PCD header in " + path);
     size_t rec = 0;
-    int ix = -1, iy = -1, iz = -1;
+    int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1;
     for (size_t i = 0; i < names.size(); ++i) {
         Field fd;
         fd.name = names[i];
@@ -126,11 +131,22 @@ inline bool read_pcd(const std::string &path, std::vector<double> &xyz, std::str
         if (fd.name == "x") ix = (int) i;
         if (fd.name == "y") iy = (int) i;
         if (fd.name == "z") iz = (int) i;
+        if (fd.name == "normal_x") inx = (int) i;
+        if (fd.name == "normal_y") iny = (int) i;
+        if (fd.name == "normal_z") inz = (int) i;
         fields.push_back(fd);
     }
     if (ix < 0 || iy < 0 || iz < 0) return fail("PCD has no x/y/z fields: " + path);
     xyz.clear();
     xyz.reserve(n_points * 3);
+    const bool want_n = normals && inx >= 0 && iny >= 0 && inz >= 0;
+    if (normals) normals->clear();
+    if (want_n) normals->reserve(n_points * 3);
+    auto push_n = [&](double a, double b, double c) {
+        normals->push_back(a);
+        normals->push_back(b);
+        normals->push_back(c);
+    };
     if (data_kind == "ascii") {
         size_t total_cols = 0;
         std::vector<size_t> col0(fields.size());
@@ -144,7 +160,8 @@ inline bool read_pcd(const std::string &path, std::vector<double> &xyz, std::str
                 if (!(ss >> tok)) { ok = false; break; }
                 row[c] = (tok == "nan" || tok == "NaN") ? NAN : std::strtod(tok.c_str(), nullptr);
             }
-            if (ok) push_if_finite(xyz, row[col0[ix]], row[col0[iy]], row[col0[iz]]);
+            if (ok && push_if_finite(xyz, row[col0[ix]], row[col0[iy]], row[col0[iz]]) && want_n)
+                push_n(row[col0[inx]], row[col0[iny]], row[col0[inz]]);
         }
     } else if (data_kind == "binary") {
         std::vector<unsigned char> buf(rec * n_points);
@@ -152,9 +169,8 @@ inline bool read_pcd(const std::string &path, std::vector<double> &xyz, std::str
         if ((size_t) f.gcount() != buf.size()) return fail("truncated binary PCD: " + path);
         for (size_t p = 0; p < n_points; ++p) {
             const unsigned char *r = buf.data() + p * rec;
-            push_if_finite(xyz, read_scalar(r + fields[ix].offset, fields[ix].type, fields[ix].size),
-                           read_scalar(r + fields[iy].offset, fields[iy].type, fields[iy].size),
-                           read_scalar(r + fields[iz].offset, fields[iz].type, fields[iz].size));
+            auto at = [&](int fi) { return read_scalar(r + fields[fi].offset, fields[fi].type, fields[fi].size); };
+            if (push_if_finite(xyz, at(ix), at(iy), at(iz)) && want_n) push_n(at(inx), at(iny), at(inz));
         }
     } else if (data_kind == "binary_compressed") {
         uint32_t csize = 0, usize = 0;
@@ -172,7 +188,8 @@ inline bool read_pcd(const std::string &path, std::vector<double> &xyz, std::str
         auto at = [&](int fi, size_t p) {
             return read_scalar(ubuf.data() + base[fi] + p * (size_t) fields[fi].size * fields[fi].count, fields[fi].type, fields[fi].size);
         };
-        for (size_t p = 0; p < n_points; ++p) push_if_finite(xyz, at(ix, p), at(iy, p), at(iz, p));
+        for (size_t p = 0; p < n_points; ++p)
+            if (push_if_finite(xyz, at(ix, p), at(iy, p), at(iz, p)) && want_n) push_n(at(inx, p), at(iny, p), at(inz, p));
     } else {
         return fail("unsupported PCD DATA kind '" + data_kind + "'");
     }

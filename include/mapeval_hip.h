@@ -175,6 +175,40 @@ typedef struct me_icp_sums {
 } me_icp_sums;
 int me_icp_p2p_sums(me_ctx *ctx, int query_slot, double max_distance, me_icp_sums *out);
 
+/* registration_methods 1 (point-to-plane) and 2 (generalized ICP, the shipped config's default; map_eval.cpp:1373-1384):
+ * Open3D RegistrationICP(.., TransformationEstimationPointToPlane) / RegistrationGeneralizedICP [upstream].  Per-point
+ * attributes live on the device in the caller's point order and follow the cloud through me_transform_cloud
+ * (n <- R n, C <- R C R^T, as PointCloud::Transform) and me_voxel_downsample (normals averaged per voxel).
+ *   me_set_normals       normals that came with the cloud (PCD normal_x/y/z), N x 3.
+ *   me_get_normals       the current normals, N x 3.
+ *   me_estimate_normals  PointCloud::EstimateNormals(KDTreeSearchParamKNN(knn)) of a cloud WITHOUT normals: exact k-NN of
+ *                        every point (itself included), utility::ComputeCovariance, FastEigen3x3; (0,0,1) where
+ *                        undefined.  1 <= knn <= 40.  Optional outputs: normals N x 3, and the neighbours themselves,
+ *                        knn_idx / knn_d2 N x knn ascending by (d2, index), -1 / +inf where the cloud has fewer points.
+ *   me_gicp_covariances  InitializePointCloudForGeneralizedICP(epsilon): C = Rx diag(epsilon,1,1) Rx^T from the normals
+ *                        (estimated with knn = 20 when the slot has none); optional output N x 9 row-major.
+ *   me_icp_lsq_sums      one correspondence + reduction step over the pairs of the last me_nn1(query_slot, ref) with
+ *                        d2 < max_distance^2: J^T J (6x6 row-major), J^T r, sum r^2 of utility::ComputeJTJandJTr and
+ *                        sum d2 (fitness = n_corr / n_source, inlier_rmse = sqrt(sum_d2 / n_corr)).  The host solves
+ *                        JTJ x = -JTr, converts x with TransformVector6dToMatrix4d and calls me_transform_cloud.
+ *                        ME_ICP_POINT_TO_PLANE needs normals on the ref cloud, ME_ICP_GENERALIZED covariances on both. */
+#define ME_ICP_POINT_TO_PLANE 1
+#define ME_ICP_GENERALIZED 2
+typedef struct me_icp_lsq {
+    int64_t n_corr;
+    int64_t n_source;
+    double JTJ[36];
+    double JTr[6];
+    double r2;
+    double sum_d2;
+} me_icp_lsq;
+int me_set_normals(me_ctx *ctx, int slot, const double *normals);
+int me_get_normals(me_ctx *ctx, int slot, double *normals);
+int me_estimate_normals(me_ctx *ctx, int slot, int knn, double *normals, int32_t *knn_idx, double *knn_d2);
+int me_gicp_covariances(me_ctx *ctx, int slot, double epsilon, double *cov);
+int me_get_covariances(me_ctx *ctx, int slot, double *cov); /* the current N x 9 covariances (after any transform) */
+int me_icp_lsq_sums(me_ctx *ctx, int query_slot, int mode, double max_distance, me_icp_lsq *out);
+
 /* renderDistanceOnPointCloud (map_eval.cpp:586-607; raw_rendered_dis_map.pcd / inlier_rendered_dis_map.pcd, :485-495) for
  * the queries of the last me_nn1(query_slot, ...): rgb[N][3] in the caller's cloud order = ColorMapJet(min(d2, dis) / dis)
  * (the SQUARED distance against the unsquared `dis`, as the reference does; it repeats a serial KD-tree pass for it,

@@ -45,6 +45,11 @@ class _RegStats(C.Structure):
     ]
 
 
+class _LsqSums(C.Structure):
+    _fields_ = [("n_corr", C.c_int64), ("n_src", C.c_int64), ("JTJ", C.c_double * 36), ("JTr", C.c_double * 6),
+                ("r2", C.c_double), ("sum_d2", C.c_double)]
+
+
 @dataclass
 class RegStats:
     n_src: int
@@ -99,6 +104,12 @@ def lib():
         L.orc_render_entropy.argtypes = [dp, dp, C.POINTER(C.c_uint8), C.c_int64, dp, dp, C.c_int64, dp, dp]
         L.orc_scs.restype = C.c_double
         L.orc_scs.argtypes = [ip, dp, C.c_int64, C.c_int]
+        L.orc_kdtree_knn.argtypes = [C.c_void_p, dp, C.c_int64, C.c_int, ip, dp, C.c_int]
+        L.orc_estimate_normals_knn.argtypes = [dp, C.c_int64, C.c_int, dp, C.c_int]
+        L.orc_gicp_covariances.argtypes = [dp, C.c_int64, C.c_double, dp]
+        L.orc_rotate_attributes.argtypes = [dp, dp, C.c_int64, dp]
+        L.orc_icp_lsq_sums.argtypes = [C.c_int, dp, dp, C.c_int64, dp, dp, C.c_int64, C.c_double,
+                                       C.POINTER(_LsqSums), C.c_int]
         _lib = L
     return _lib
 
@@ -263,3 +274,101 @@ def render_entropy(xyz, entropies, valid):
     xo, co = np.empty((m, 3), np.float64), np.empty((m, 3), np.float64)
     lib().orc_render_entropy(_dp(xyz), _dp(ent), vp, xyz.shape[0], _dp(xo), _dp(co), m, C.byref(mn), C.byref(mx))
     return xo, co, mn.value, mx.value
+
+
+# ---- registration_methods 1 / 2 (performICPRegistration, map_eval.cpp:1366-1394): Open3D pieces restated ----
+def knn(ref, query, k: int, threads: int = 0):
+    """k nearest neighbours, ascending by (d2, index) -> (idx int32[M,k], d2 float64[M,k])."""
+    ref, query = _pts(ref), _pts(query)
+    t = lib().orc_kdtree_build(_dp(ref), ref.shape[0])
+    idx = np.empty((query.shape[0], k), np.int32)
+    d2 = np.empty((query.shape[0], k), np.float64)
+    lib().orc_kdtree_knn(t, _dp(query), query.shape[0], int(k), _ip(idx), _dp(d2), threads)
+    lib().orc_kdtree_free(t)
+    return idx, d2
+
+
+def estimate_normals_knn(xyz, k: int = 20, threads: int = 0) -> np.ndarray:
+    """open3d EstimateNormals(KDTreeSearchParamKNN(k)) on a cloud without normals."""
+    xyz = _pts(xyz)
+    out = np.empty_like(xyz)
+    lib().orc_estimate_normals_knn(_dp(xyz), xyz.shape[0], int(k), _dp(out), threads)
+    return out
+
+
+def gicp_covariances(normals, epsilon: float = 1e-3) -> np.ndarray:
+    """InitializePointCloudForGeneralizedICP -> (N,3,3)."""
+    normals = _pts(normals)
+    out = np.empty((normals.shape[0], 9), np.float64)
+    lib().orc_gicp_covariances(_dp(normals), normals.shape[0], float(epsilon), _dp(out))
+    return out.reshape(-1, 3, 3)
+
+
+def rotate_attributes(T, normals=None, cov=None):
+    """PointCloud::Transform on normals (N,3) / covariances (N,3,3); returns rotated copies."""
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    nn = None if normals is None else _pts(normals).copy()
+    cc = None if cov is None else np.ascontiguousarray(cov, dtype=np.float64).reshape(-1, 9).copy()
+    n = nn.shape[0] if nn is not None else cc.shape[0]
+    lib().orc_rotate_attributes(None if nn is None else _dp(nn), None if cc is None else _dp(cc), n, _dp(T))
+    return nn, (None if cc is None else cc.reshape(-1, 3, 3))
+
+
+def icp_lsq_sums(mode: int, src, src_attr, tgt, tgt_attr, max_distance: float, threads: int = 0):
+    """One linearised step: mode 1 point-to-plane (tgt_attr = normals), mode 2 generalized ICP (attrs = covariances).
+    -> dict(n_corr, n_src, JTJ (6,6), JTr (6,), r2, sum_d2)."""
+    src, tgt = _pts(src), _pts(tgt)
+    width = 3 if mode == 1 else 9
+    ta = np.ascontiguousarray(tgt_attr, dtype=np.float64).reshape(tgt.shape[0], width)
+    sa = None if mode == 1 else np.ascontiguousarray(src_attr, dtype=np.float64).reshape(src.shape[0], 9)
+    out = _LsqSums()
+    lib().orc_icp_lsq_sums(int(mode), _dp(src), None if sa is None else _dp(sa), src.shape[0], _dp(tgt), _dp(ta),
+                           tgt.shape[0], float(max_distance), C.byref(out), threads)
+    return dict(n_corr=out.n_corr, n_src=out.n_src, JTJ=np.array(list(out.JTJ)).reshape(6, 6),
+                JTr=np.array(list(out.JTr)), r2=out.r2, sum_d2=out.sum_d2)
+
+
+def vector6_to_matrix(x) -> np.ndarray:
+    """open3d utility::TransformVector6dToMatrix4d: R = Rz(x2) Ry(x1) Rx(x0), t = x[3:6]."""
+    a, b, g = float(x[0]), float(x[1]), float(x[2])
+    Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    Rz = np.array([[np.cos(g), -np.sin(g), 0], [np.sin(g), np.cos(g), 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = np.asarray(x[3:6], float)
+    return T
+
+
+def registration_icp(mode: int, src, tgt, max_distance: float, tgt_normals=None, knn_k: int = 20, epsilon: float = 1e-3,
+                     max_iteration: int = 30, relative_fitness: float = 1e-6, relative_rmse: float = 1e-6):
+    """RegistrationICP (mode 1, point-to-plane; needs tgt_normals) / RegistrationGeneralizedICP (mode 2) with the default
+    ICPConvergenceCriteria, init = identity.  -> dict(transformation, fitness, inlier_rmse, n_corr, iterations, cloud)."""
+    src, tgt = _pts(src).copy(), _pts(tgt)
+    if mode == 2:
+        cs = gicp_covariances(estimate_normals_knn(src, knn_k), epsilon)
+        ct = gicp_covariances(estimate_normals_knn(tgt, knn_k), epsilon)
+    else:
+        cs, ct = None, _pts(tgt_normals)
+
+    def evaluate():
+        s = icp_lsq_sums(mode, src, cs, tgt, ct, max_distance)
+        n = s["n_corr"]
+        return s, (n / len(src) if len(src) else 0.0), (float(np.sqrt(s["sum_d2"] / n)) if n else 0.0)
+
+    total = np.eye(4)
+    s, fit, rmse = evaluate()
+    it = 0
+    for it in range(1, max_iteration + 1):
+        if s["n_corr"] == 0:
+            break
+        upd = vector6_to_matrix(np.linalg.solve(s["JTJ"], -s["JTr"]))
+        total = upd @ total
+        src = transform(src, upd)
+        if cs is not None:
+            _, cs = rotate_attributes(upd, cov=cs)
+        pf, pr = fit, rmse
+        s, fit, rmse = evaluate()
+        if abs(pf - fit) < relative_fitness and abs(pr - rmse) < relative_rmse:
+            break
+    return dict(transformation=total, fitness=fit, inlier_rmse=rmse, n_corr=int(s["n_corr"]), iterations=it, cloud=src)

@@ -243,6 +243,52 @@ struct orc_kdtree {
         const double md = init_dists(q, dists);
         radius_rec(root, q, r2, md, dists, emit);
     }
+
+    // k nearest neighbours, ascending by (d2, index): nanoflann KNNResultSet keeps its k best sorted by distance
+    // [upstream]; equal distances are ordered by point index here (the traversal order decides upstream).
+    using Hit = std::pair<double, int32_t>;
+    void knn_rec(int32_t id, const double *q, double mindist, double dists[3], size_t k, std::vector<Hit> &res) const {
+        const Node &nd = nodes[id];
+        if (nd.child1 < 0) {
+            for (int32_t kk = nd.left; kk < nd.right; ++kk) {
+                const int32_t pi = vind[kk];
+                const Hit h(dist2(q, pts + 3 * (int64_t) pi), pi);
+                if (res.size() < k || h < res.back()) {
+                    res.insert(std::upper_bound(res.begin(), res.end(), h), h);
+                    if (res.size() > k) res.pop_back();
+                }
+            }
+            return;
+        }
+        const int f = nd.divfeat;
+        const double val = q[f];
+        const double diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+        int32_t first, other;
+        double cut;
+        if (diff1 + diff2 < 0) {
+            first = nd.child1;
+            other = nd.child2;
+            cut = diff2 * diff2;
+        } else {
+            first = nd.child2;
+            other = nd.child1;
+            cut = diff1 * diff1;
+        }
+        knn_rec(first, q, mindist, dists, k, res);
+        const double saved = dists[f];
+        const double md = mindist + cut - saved;
+        dists[f] = cut;
+        const double worst = res.size() < k ? std::numeric_limits<double>::infinity() : res.back().first;
+        if (md <= worst * kSlack) knn_rec(other, q, md, dists, k, res);
+        dists[f] = saved;
+    }
+    void knn(const double *q, size_t k, std::vector<Hit> &res) const {
+        res.clear();
+        if (n == 0 || k == 0) return;
+        double dists[3];
+        const double md = init_dists(q, dists);
+        knn_rec(root, q, md, dists, k, res);
+    }
 };
 
 namespace {
@@ -931,5 +977,354 @@ int64_t orc_render_entropy(const double *xyz, const double *entropies, const uin
     return m;
 }
 
+
+}  // extern "C"
+
+// =============================================================================================================
+// Registration (performICPRegistration, map_eval.cpp:1366-1394): the Open3D pieces behind registration_methods 1 / 2.
+// None of Open3D is in the reference tree; what follows restates its published algorithms [upstream, stated 0.15.1]:
+//   PointCloud::EstimateNormals(KDTreeSearchParamKNN(k))  -> EstimatePerPointCovariances + ComputeNormal(fast = true)
+//   utility::ComputeCovariance (one-pass raw moments), FastEigen3x3 (Eberly, "A Robust Eigensolver for 3x3 Symmetric
+//   Matrices"), InitializePointCloudForGeneralizedICP(epsilon = 1e-3), GetRotationFromE1ToX,
+//   TransformationEstimationForGeneralizedICP / PointToPlane ::ComputeTransformation (the J^T J, J^T r sums).
+// 3x3 products are accumulated as (a_i0 b_0j + a_i1 b_1j) + a_i2 b_2j.
+// =============================================================================================================
+namespace {
+
+using Hit = orc_kdtree::Hit;
+
+inline void mat3_mul(const double a[9], const double b[9], double out[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) out[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+inline void mat3_mul_bt(const double a[9], const double b[9], double out[9]) {  // a * b^T
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) out[3 * i + j] = (a[3 * i] * b[3 * j] + a[3 * i + 1] * b[3 * j + 1]) + a[3 * i + 2] * b[3 * j + 2];
+}
+inline void cross3(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline double dot3(const double a[3], const double b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+// Eigen Matrix3d::inverse(): cofactors, determinant expanded along column 0
+inline void inv3(const double m[9], double out[9]) {
+    auto cof = [&](int i, int j) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return m[3 * i1 + j1] * m[3 * i2 + j2] - m[3 * i1 + j2] * m[3 * i2 + j1];
+    };
+    const double c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+    const double det = (c00 * m[0] + c10 * m[3]) + c20 * m[6];
+    const double invdet = 1.0 / det;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) out[3 * i + j] = cof(j, i) * invdet;
+}
+
+// utility::ComputeCovariance(points, indices): raw first and second moments, divided by the count
+void o3d_covariance(const double *pts, const Hit *nb, size_t m, double cov[9]) {
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t j = 0; j < m; ++j) {
+        const double *p = pts + 3 * (int64_t) nb[j].second;
+        c[0] += p[0];
+        c[1] += p[1];
+        c[2] += p[2];
+        c[3] += p[0] * p[0];
+        c[4] += p[0] * p[1];
+        c[5] += p[0] * p[2];
+        c[6] += p[1] * p[1];
+        c[7] += p[1] * p[2];
+        c[8] += p[2] * p[2];
+    }
+    for (int e = 0; e < 9; ++e) c[e] /= (double) m;
+    cov[0] = c[3] - c[0] * c[0];
+    cov[4] = c[6] - c[1] * c[1];
+    cov[8] = c[8] - c[2] * c[2];
+    cov[1] = cov[3] = c[4] - c[0] * c[1];
+    cov[2] = cov[6] = c[5] - c[0] * c[2];
+    cov[5] = cov[7] = c[7] - c[1] * c[2];
+}
+
+void o3d_eigvec0(const double A[9], double eval0, double out[3]) {
+    const double row0[3] = {A[0] - eval0, A[1], A[2]};
+    const double row1[3] = {A[1], A[4] - eval0, A[5]};
+    const double row2[3] = {A[2], A[5], A[8] - eval0};
+    double r0xr1[3], r0xr2[3], r1xr2[3];
+    cross3(row0, row1, r0xr1);
+    cross3(row0, row2, r0xr2);
+    cross3(row1, row2, r1xr2);
+    const double d0 = dot3(r0xr1, r0xr1), d1 = dot3(r0xr2, r0xr2), d2 = dot3(r1xr2, r1xr2);
+    double dmax = d0;
+    int imax = 0;
+    if (d1 > dmax) {
+        dmax = d1;
+        imax = 1;
+    }
+    if (d2 > dmax) imax = 2;
+    const double *v = imax == 0 ? r0xr1 : (imax == 1 ? r0xr2 : r1xr2);
+    const double len = std::sqrt(imax == 0 ? d0 : (imax == 1 ? d1 : d2));
+    for (int k = 0; k < 3; ++k) out[k] = v[k] / len;
+}
+
+void o3d_eigvec1(const double A[9], const double e0[3], double eval1, double out[3]) {
+    double U[3], V[3];
+    if (std::fabs(e0[0]) > std::fabs(e0[1])) {
+        const double inv_length = 1.0 / std::sqrt(e0[0] * e0[0] + e0[2] * e0[2]);
+        U[0] = -e0[2] * inv_length;
+        U[1] = 0;
+        U[2] = e0[0] * inv_length;
+    } else {
+        const double inv_length = 1.0 / std::sqrt(e0[1] * e0[1] + e0[2] * e0[2]);
+        U[0] = 0;
+        U[1] = e0[2] * inv_length;
+        U[2] = -e0[1] * inv_length;
+    }
+    cross3(e0, U, V);
+    const double AU[3] = {(A[0] * U[0] + A[1] * U[1]) + A[2] * U[2], (A[1] * U[0] + A[4] * U[1]) + A[5] * U[2],
+                          (A[2] * U[0] + A[5] * U[1]) + A[8] * U[2]};
+    const double AV[3] = {(A[0] * V[0] + A[1] * V[1]) + A[2] * V[2], (A[1] * V[0] + A[4] * V[1]) + A[5] * V[2],
+                          (A[2] * V[0] + A[5] * V[1]) + A[8] * V[2]};
+    double m00 = dot3(U, AU) - eval1, m01 = dot3(U, AV), m11 = dot3(V, AV) - eval1;
+    const double a00 = std::fabs(m00), a01 = std::fabs(m01), a11 = std::fabs(m11);
+    if (a00 >= a11) {
+        if (std::max(a00, a01) > 0) {
+            if (a00 >= a01) {
+                m01 /= m00;
+                m00 = 1 / std::sqrt(1 + m01 * m01);
+                m01 *= m00;
+            } else {
+                m00 /= m01;
+                m01 = 1 / std::sqrt(1 + m00 * m00);
+                m00 *= m01;
+            }
+            for (int k = 0; k < 3; ++k) out[k] = m01 * U[k] - m00 * V[k];
+        } else {
+            for (int k = 0; k < 3; ++k) out[k] = U[k];
+        }
+    } else {
+        if (std::max(a11, a01) > 0) {
+            if (a11 >= a01) {
+                m01 /= m11;
+                m11 = 1 / std::sqrt(1 + m01 * m01);
+                m01 *= m11;
+            } else {
+                m11 /= m01;
+                m01 = 1 / std::sqrt(1 + m11 * m11);
+                m11 *= m01;
+            }
+            for (int k = 0; k < 3; ++k) out[k] = m11 * U[k] - m01 * V[k];
+        } else {
+            for (int k = 0; k < 3; ++k) out[k] = U[k];
+        }
+    }
+}
+
+// FastEigen3x3: the eigenvector of the smallest eigenvalue of a symmetric 3x3 (closed form, matrix pre-scaled by its
+// largest coefficient)
+void o3d_fast_eigen3x3(const double cov[9], double out[3]) {
+    double A[9];
+    double max_coeff = cov[0];
+    for (int e = 1; e < 9; ++e) max_coeff = std::max(max_coeff, cov[e]);
+    if (max_coeff == 0) {
+        out[0] = out[1] = out[2] = 0;
+        return;
+    }
+    for (int e = 0; e < 9; ++e) A[e] = cov[e] / max_coeff;
+    const double norm = (A[1] * A[1] + A[2] * A[2]) + A[5] * A[5];
+    if (norm > 0) {
+        const double q = ((A[0] + A[4]) + A[8]) / 3;
+        const double b00 = A[0] - q, b11 = A[4] - q, b22 = A[8] - q;
+        const double p = std::sqrt((((b00 * b00 + b11 * b11) + b22 * b22) + norm * 2) / 6);
+        const double c00 = b11 * b22 - A[5] * A[5];
+        const double c01 = A[1] * b22 - A[5] * A[2];
+        const double c02 = A[1] * A[5] - b11 * A[2];
+        const double det = ((b00 * c00 - A[1] * c01) + A[2] * c02) / ((p * p) * p);
+        double half_det = det * 0.5;
+        half_det = std::min(std::max(half_det, -1.0), 1.0);
+        const double angle = std::acos(half_det) / 3.0;
+        const double two_thirds_pi = 2.09439510239319549;
+        const double beta2 = std::cos(angle) * 2;
+        const double beta0 = std::cos(angle + two_thirds_pi) * 2;
+        const double beta1 = -(beta0 + beta2);
+        const double ev0 = q + p * beta0, ev1 = q + p * beta1, ev2 = q + p * beta2;
+        double e0[3], e1[3], e2[3];
+        if (half_det >= 0) {
+            o3d_eigvec0(A, ev2, e2);
+            if (ev2 < ev0 && ev2 < ev1) {
+                for (int k = 0; k < 3; ++k) out[k] = e2[k];
+                return;
+            }
+            o3d_eigvec1(A, e2, ev1, e1);
+            if (ev1 < ev0 && ev1 < ev2) {
+                for (int k = 0; k < 3; ++k) out[k] = e1[k];
+                return;
+            }
+            cross3(e1, e2, out);
+        } else {
+            o3d_eigvec0(A, ev0, e0);
+            if (ev0 < ev1 && ev0 < ev2) {
+                for (int k = 0; k < 3; ++k) out[k] = e0[k];
+                return;
+            }
+            o3d_eigvec1(A, e0, ev1, e1);
+            if (ev1 < ev0 && ev1 < ev2) {
+                for (int k = 0; k < 3; ++k) out[k] = e1[k];
+                return;
+            }
+            cross3(e0, e1, out);
+        }
+    } else {  // diagonal matrix (the scaling is undone upstream before this test; the comparisons are scale-free)
+        out[0] = out[1] = out[2] = 0;
+        if (cov[0] < cov[4] && cov[0] < cov[8]) out[0] = 1;
+        else if (cov[4] < cov[0] && cov[4] < cov[8]) out[1] = 1;
+        else out[2] = 1;
+    }
+}
+
+// GetRotationFromE1ToX (GeneralizedICP.cpp): Rodrigues rotation taking e1 = (1,0,0) onto the unit vector x
+void o3d_rotation_e1_to_x(const double x[3], double R[9]) {
+    const double v[3] = {0.0, -x[2], x[1]};  // e1.cross(x)
+    const double c = x[0];                   // e1.dot(x)
+    for (int e = 0; e < 9; ++e) R[e] = (e % 4 == 0) ? 1.0 : 0.0;
+    if (c < -0.99) return;                   // (sic) near-opposite: identity
+    const double sv[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    double sv2[9];
+    mat3_mul(sv, sv, sv2);
+    const double factor = 1 / (1 + c);
+    for (int e = 0; e < 9; ++e) R[e] = (R[e] + sv[e]) + sv2[e] * factor;
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_kdtree_knn(const orc_kdtree *t, const double *q, int64_t m, int k, int32_t *idx, double *d2, int threads) {
+    const int nt = resolve_threads(threads);
+#pragma omp parallel num_threads(nt) if (nt > 1)
+    {
+        std::vector<Hit> res;
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t i = 0; i < m; ++i) {
+            t->knn(q + 3 * i, (size_t) k, res);
+            for (int j = 0; j < k; ++j) {
+                const bool have = j < (int) res.size();
+                if (idx) idx[i * k + j] = have ? res[(size_t) j].second : -1;
+                if (d2) d2[i * k + j] = have ? res[(size_t) j].first : std::numeric_limits<double>::infinity();
+            }
+        }
+    }
+}
+
+// PointCloud::EstimateNormals(KDTreeSearchParamKNN(knn)) on a cloud WITHOUT normals: SearchKNN(point, knn) (the point
+// itself is its first neighbour); >= 3 neighbours -> ComputeCovariance, else identity; normal = FastEigen3x3, a zero
+// vector becomes (0,0,1); no orientation step (there is no previous normal to agree with).
+void orc_estimate_normals_knn(const double *xyz, int64_t n, int knn, double *normals, int threads) {
+    orc_kdtree *t = orc_kdtree_build(xyz, n);
+    const int nt = resolve_threads(threads);
+#pragma omp parallel num_threads(nt) if (nt > 1)
+    {
+        std::vector<Hit> res;
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t i = 0; i < n; ++i) {
+            t->knn(xyz + 3 * i, (size_t) knn, res);
+            double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (res.size() >= 3) o3d_covariance(xyz, res.data(), res.size(), cov);
+            double nv[3];
+            o3d_fast_eigen3x3(cov, nv);
+            if (std::sqrt(dot3(nv, nv)) == 0.0) {
+                nv[0] = nv[1] = 0;
+                nv[2] = 1;
+            }
+            for (int d = 0; d < 3; ++d) normals[3 * i + d] = nv[d];
+        }
+    }
+    orc_kdtree_free(t);
+}
+
+// InitializePointCloudForGeneralizedICP: covariance = Rx * diag(epsilon, 1, 1) * Rx^T with Rx = rotation e1 -> normal
+void orc_gicp_covariances(const double *normals, int64_t n, double epsilon, double *cov) {
+    const double Cd[9] = {epsilon, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int64_t i = 0; i < n; ++i) {
+        double R[9], RC[9];
+        o3d_rotation_e1_to_x(normals + 3 * i, R);
+        mat3_mul(R, Cd, RC);
+        mat3_mul_bt(RC, R, cov + 9 * i);
+    }
+}
+
+// PointCloud::Transform on per-point attributes: normals n <- R n, covariances C <- R C R^T (R = T.block<3,3>(0,0))
+void orc_rotate_attributes(double *normals, double *cov, int64_t n, const double T[16]) {
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    for (int64_t i = 0; i < n; ++i) {
+        if (normals) {
+            const double v[3] = {normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]};
+            for (int r = 0; r < 3; ++r) normals[3 * i + r] = (R[3 * r] * v[0] + R[3 * r + 1] * v[1]) + R[3 * r + 2] * v[2];
+        }
+        if (cov) {
+            double RC[9], out[9];
+            mat3_mul(R, cov + 9 * i, RC);
+            mat3_mul_bt(RC, R, out);
+            std::memcpy(cov + 9 * i, out, sizeof(out));
+        }
+    }
+}
+
+// One linearised least-squares step of RegistrationICP / RegistrationGeneralizedICP: correspondences = 1-NN of every
+// source point in the target with d2 < max^2 (GetRegistrationResultAndCorrespondences), then the sums of
+// utility::ComputeJTJandJTr over them.
+//   mode 1, point-to-plane: J = [vs x nt, nt] (1 x 6), r = (vs - vt) . nt          (tgt_attr = target normals, n x 3)
+//   mode 2, generalized   : M = Ct + Cs, W = M^(-1/2); rows of W [-skew(vs) | I], r = W (vs - vt);
+//           sum_rows J^T J = [-skew(vs) | I]^T M^-1 [-skew(vs) | I] (W symmetric, W W = M^-1): the matrix square
+//           root is not formed.                                                     (attrs = covariances, n x 9)
+void orc_icp_lsq_sums(int mode, const double *src, const double *src_attr, int64_t ns, const double *tgt,
+                      const double *tgt_attr, int64_t nt_, double max_distance, orc_lsq_sums *out, int threads) {
+    std::vector<int32_t> idx((size_t) ns);
+    std::vector<double> d2((size_t) ns);
+    orc_kdtree *t = orc_kdtree_build(tgt, nt_);
+    orc_kdtree_nn1(t, src, ns, idx.data(), d2.data(), threads);
+    orc_kdtree_free(t);
+    std::memset(out, 0, sizeof(*out));
+    out->n_src = ns;
+    const double gate2 = max_distance * max_distance;
+    for (int64_t i = 0; i < ns; ++i) {
+        if (idx[(size_t) i] < 0 || !(d2[(size_t) i] < gate2)) continue;
+        const int64_t j = idx[(size_t) i];
+        const double *vs = src + 3 * i, *vt = tgt + 3 * j;
+        const double d[3] = {vs[0] - vt[0], vs[1] - vt[1], vs[2] - vt[2]};
+        ++out->n_corr;
+        out->sum_d2 += d2[(size_t) i];
+        if (mode == 1) {
+            const double *nt = tgt_attr + 3 * j;
+            double J[6];
+            cross3(vs, nt, J);
+            J[3] = nt[0];
+            J[4] = nt[1];
+            J[5] = nt[2];
+            const double r = dot3(d, nt);
+            for (int a = 0; a < 6; ++a) {
+                for (int b = 0; b < 6; ++b) out->JTJ[6 * a + b] += J[a] * J[b];
+                out->JTr[a] += J[a] * r;
+            }
+            out->r2 += r * r;
+        } else {
+            double M[9], B[9];
+            for (int e = 0; e < 9; ++e) M[e] = tgt_attr[9 * j + e] + src_attr[9 * i + e];
+            inv3(M, B);
+            const double x = vs[0], y = vs[1], z = vs[2];
+            const double J[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};  // [-skew(vs) | I], 3 x 6
+            double BJ[18];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 6; ++c) BJ[6 * r + c] = (B[3 * r] * J[c] + B[3 * r + 1] * J[6 + c]) + B[3 * r + 2] * J[12 + c];
+            const double Bd[3] = {(B[0] * d[0] + B[1] * d[1]) + B[2] * d[2], (B[3] * d[0] + B[4] * d[1]) + B[5] * d[2],
+                                  (B[6] * d[0] + B[7] * d[1]) + B[8] * d[2]};
+            for (int a = 0; a < 6; ++a) {
+                for (int b = 0; b < 6; ++b)
+                    out->JTJ[6 * a + b] += (J[a] * BJ[b] + J[6 + a] * BJ[6 + b]) + J[12 + a] * BJ[12 + b];
+                out->JTr[a] += (J[a] * Bd[0] + J[6 + a] * Bd[1]) + J[12 + a] * Bd[2];
+            }
+            out->r2 += dot3(d, Bd);
+        }
+    }
+}
 
 }  // extern "C"

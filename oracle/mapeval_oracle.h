@@ -105,6 +105,27 @@ void orc_render_distance(const double *d2, int64_t n, double dis, double *rgb);
 int64_t orc_render_entropy(const double *xyz, const double *entropies, const uint8_t *valid, int64_t n, double *xyz_out,
                            double *rgb_out, int64_t capacity, double *min_abs_out, double *max_abs_out);
 
+/* ---- registration_methods 1 / 2 (performICPRegistration, map_eval.cpp:1366-1394): Open3D pieces [upstream] ----
+ * k nearest neighbours, ascending by (d2, index); missing neighbours (n < k): idx -1, d2 +inf. */
+void orc_kdtree_knn(const orc_kdtree *t, const double *q, int64_t m, int k, int32_t *idx, double *d2, int threads);
+/* PointCloud::EstimateNormals(KDTreeSearchParamKNN(knn)) for a cloud without normals -> normals[n][3] */
+void orc_estimate_normals_knn(const double *xyz, int64_t n, int knn, double *normals, int threads);
+/* InitializePointCloudForGeneralizedICP(epsilon): normals[n][3] -> cov[n][9] (row-major 3x3) */
+void orc_gicp_covariances(const double *normals, int64_t n, double epsilon, double *cov);
+/* PointCloud::Transform on the attributes: n <- R n, C <- R C R^T (either pointer may be NULL) */
+void orc_rotate_attributes(double *normals, double *cov, int64_t n, const double T_rowmajor[16]);
+/* sums of one linearised step (ComputeJTJandJTr) over the correspondences with d2 < max_distance^2 */
+typedef struct orc_lsq_sums {
+    int64_t n_corr, n_src;
+    double JTJ[36]; /* row-major 6x6 */
+    double JTr[6];
+    double r2;      /* sum of squared (weighted) residuals */
+    double sum_d2;  /* sum of squared Euclidean correspondence distances (-> inlier_rmse) */
+} orc_lsq_sums;
+/* mode 1: point-to-plane (tgt_attr = target normals n x 3, src_attr unused); mode 2: generalized ICP (attrs = n x 9) */
+void orc_icp_lsq_sums(int mode, const double *src, const double *src_attr, int64_t ns, const double *tgt,
+                      const double *tgt_attr, int64_t nt, double max_distance, orc_lsq_sums *out, int threads);
+
 #ifdef __cplusplus
 }
 #endif

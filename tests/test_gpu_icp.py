@@ -213,15 +213,19 @@ enable_debug: true
     np.testing.assert_allclose(vals["FULL CD"][0], oracle.chamfer(ref["cloud"], gt), atol=6e-6)
 
 
-def test_host_refuses_gicp(tmp_path):
-    est_dir = tmp_path / "est"
-    est_dir.mkdir()
-    pts = np.random.default_rng(1).uniform(0, 1, (500, 3))
-    _write_pcd(est_dir / "map.pcd", pts)
-    _write_pcd(tmp_path / "gt.pcd", pts)
+def _write_pcd_normals(path, pts, nrm):
+    n = len(pts)
+    hdr = (f"# .PCD v0.7\nVERSION 0.7\nFIELDS x y z normal_x normal_y normal_z\nSIZE 8 8 8 8 8 8\nTYPE F F F F F F\n"
+           f"COUNT 1 1 1 1 1 1\nWIDTH {n}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA binary\n")
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        f.write(np.ascontiguousarray(np.hstack([pts, nrm]), dtype="<f8").tobytes())
+
+
+def _host_cfg(tmp_path, est_dir, method, max_d=0.3):
     cfg = tmp_path / "config.yaml"
-    cfg.write_text(f"""registration_methods: 2
-icp_max_distance: 0.3
+    cfg.write_text(f"""registration_methods: {method}
+icp_max_distance: {max_d}
 accuracy_level: [0.2, 0.1, 0.08, 0.05, 0.01]
 initial_matrix:
   - [1.0, 0.0, 0.0, 0.0]
@@ -242,5 +246,52 @@ downsample_size: 0.0
 use_visualization: false
 enable_debug: false
 """)
-    r = subprocess.run([EXE, str(cfg)], capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and "point-to-point" in (r.stdout + r.stderr)
+    return cfg
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_host_point_to_plane_and_generalized_icp(tmp_path, method):
+    """registration_methods 1 / 2 through the host executable (map_eval.cpp:1373-1384): the shipped configs use 2.
+    Checked against the oracle's restatement of Open3D's loops (same normals for point-to-plane: they travel in the PCD)."""
+    import oracle
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.campus_pair(40_000, seed=12)
+    est, gt = est.numpy(), gt.numpy()
+    est = oracle.transform(est, _rigid(0.002, -0.001, 0.003, [0.02, -0.015, 0.01]))
+    est_dir = tmp_path / "est"
+    est_dir.mkdir()
+    _write_pcd(est_dir / "map.pcd", est)
+    n_gt = oracle.estimate_normals_knn(gt, 20)
+    if method == 1:
+        _write_pcd_normals(tmp_path / "gt.pcd", gt, n_gt)
+    else:
+        _write_pcd(tmp_path / "gt.pcd", gt)
+    r = subprocess.run([EXE, str(_host_cfg(tmp_path, est_dir, method, 0.5))], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    txt = open(est_dir / "map_results" / "map_results.txt").read()
+    ref = oracle.registration_icp(method, est, gt, 0.5, tgt_normals=n_gt)
+    m = re.search(r"Aligned cloud: ((?:[-\d.e+]+\s+){16})", txt)
+    Th = np.array([float(v) for v in m.group(1).split()]).reshape(4, 4)
+    np.testing.assert_allclose(Th, ref["transformation"], atol=2e-5)  # 5 decimals in the file
+    m = re.search(r"Aligned results: ([\d.]+) (\d+)", txt)
+    assert int(m.group(2)) == ref["n_corr"]
+    o_eg = oracle.reg_stats(ref["cloud"], gt, 0.5, 1, TRUNC)
+    vals = {k: [float(v) for v in re.search(rf"^{re.escape(k)}: (.*)$", txt, flags=re.M).group(1).split()]
+            for k in ("RMSE/AC", "Comp", "FULL CD")}
+    np.testing.assert_allclose(vals["RMSE/AC"], o_eg.rmse, rtol=1e-6)
+    np.testing.assert_allclose(vals["Comp"], o_eg.fitness, rtol=0, atol=2e-15)
+    np.testing.assert_allclose(vals["FULL CD"][0], oracle.chamfer(ref["cloud"], gt), atol=6e-6)
+
+
+def test_host_point_to_plane_needs_target_normals(tmp_path):
+    """Open3D refuses point-to-plane ICP on a target without normals; so does the host (no silent estimate)."""
+    est_dir = tmp_path / "est"
+    est_dir.mkdir()
+    pts = np.random.default_rng(1).uniform(0, 1, (500, 3))
+    _write_pcd(est_dir / "map.pcd", pts)
+    _write_pcd(tmp_path / "gt.pcd", pts)
+    r = subprocess.run([EXE, str(_host_cfg(tmp_path, est_dir, 1))], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "normals" in (r.stdout + r.stderr)
+    r = subprocess.run([EXE, str(_host_cfg(tmp_path, est_dir, 3))], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "Invalid registration type" in (r.stdout + r.stderr)
