@@ -89,3 +89,60 @@ def test_full_size_self_distance_is_zero(big):
     assert st.n_corr == gt.shape[0] and st.mean_nn_dist == 0.0
     assert np.all(st.rmse == 0.0) and np.all(st.fitness == 1.0) and np.all(st.number == gt.shape[0])
     assert eng.computeChamferDistance() == 0.0
+
+
+def test_full_size_generalized_icp_properties(big):
+    """registration_methods 2 at the full size: normals are unit vectors, the correspondence count of the least-squares
+    step is the d2 < max^2 count of the statistics pass (bit-exact), the normal matrix is symmetric positive definite, and
+    registering an exactly moved copy of the 50 M cloud recovers the motion."""
+    import torch
+
+    from cloud_map_evaluation_amd.engine import ME_GATE_LT_SQUARED
+    from cloud_map_evaluation_amd.icp import vector6_to_matrix
+
+    eng, est, gt = big
+    eng.upload(0, est, cell_size=0.1)
+    eng.upload(1, gt, cell_size=0.1)
+    nrm = eng.estimate_normals(1, 20)
+    ln = np.linalg.norm(nrm, axis=1)
+    assert np.all(np.isfinite(nrm)) and np.abs(ln - 1.0).max() < 1e-9
+    del nrm, ln
+    eng.gicp_covariances(0, 1e-3)
+    eng.gicp_covariances(1, 1e-3)
+    eng.nn1(0, 1, fetch=False)
+    s = eng.icp_lsq_sums(0, 2, 0.5)
+    st = eng.nn_stats(0, 0.5, ME_GATE_LT_SQUARED, TRUNC)
+    assert s.n_corr == st.n_corr and s.n_source == est.shape[0]
+    JTJ = np.array(list(s.JTJ)).reshape(6, 6)
+    assert np.array_equal(JTJ, JTJ.T) and np.linalg.eigvalsh(JTJ).min() > 0
+    assert 0 < s.r2 < 1e3 * s.sum_d2  # weighted residuals: eigenvalues of (Ct + Cs)^-1 lie in [1/2, 1/(2 eps)]
+    # an exact copy of the ground truth, moved by a known rigid motion
+    T0 = vector6_to_matrix([0.0004, -0.0003, 0.0005, 0.03, -0.02, 0.04])
+    moved = gt @ torch.as_tensor(T0[:3, :3].T.copy(), device=gt.device) + torch.as_tensor(T0[:3, 3].copy(), device=gt.device)
+    eng.upload(0, moved, cell_size=0.1)
+    del moved
+    res = eng.performICPRegistration(1.0, method=2)
+    assert res["fitness"] == 1.0 and res["n_corr"] == gt.shape[0]
+    assert res["inlier_rmse"] < 1e-6
+    assert np.abs(res["transformation"] @ T0 - np.eye(4)).max() < 1e-7
+
+
+def test_knn_rows_against_the_oracle_at_5m():
+    """5 M points: sampled rows of the device k-NN equal the oracle's KD-tree rows bit for bit; every row is sorted and
+    starts with the point itself."""
+    import torch
+
+    import oracle
+    from cloud_map_evaluation_amd import synth
+    from cloud_map_evaluation_amd.engine import Engine
+
+    _, gt = synth.campus_pair(5_000_000, density=2500.0, seed=21, device=torch.device("cuda", 0))
+    with Engine(0) as eng:
+        eng.upload(1, gt, cell_size=0.1)
+        _, idx, d2 = eng.estimate_normals(1, 20, with_neighbours=True)
+    g = gt.cpu().numpy()
+    assert np.array_equal(idx[:, 0], np.arange(len(g), dtype=np.int32)) and np.all(d2[:, 0] == 0.0)
+    assert np.all(np.diff(d2, axis=1) >= 0)
+    sel = np.random.default_rng(0).choice(len(g), 3000, replace=False)
+    oidx, od2 = oracle.knn(g, g[sel], 20)
+    assert np.array_equal(idx[sel], oidx) and np.array_equal(d2[sel], od2)
