@@ -529,11 +529,12 @@ int estimate_normals(me_ctx *ctx, int slot, int knn, double *normals_host, int32
     ME_CHECK(ctx, c.normals.ensure((size_t) n * 24));
     int *d_idx = nullptr;
     double *d_d2 = nullptr;
+    DevBuf buf_idx, buf_d2;  // released on return: n * knn * 12 bytes would otherwise stay with the context's scratch
     if (knn_idx_host) {
-        ME_CHECK(ctx, ctx->tmp[0].ensure((size_t) n * knn * 4));
-        ME_CHECK(ctx, ctx->tmp[1].ensure((size_t) n * knn * 8));
-        d_idx = ctx->tmp[0].as<int>();
-        d_d2 = ctx->tmp[1].as<double>();
+        ME_CHECK(ctx, buf_idx.ensure((size_t) n * knn * 4));
+        ME_CHECK(ctx, buf_d2.ensure((size_t) n * knn * 8));
+        d_idx = buf_idx.as<int>();
+        d_d2 = buf_d2.as<double>();
     }
     {
         TimerScope ts(ctx, "normals");
