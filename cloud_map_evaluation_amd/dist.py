@@ -36,9 +36,19 @@ def pack_partials(parts, mme_est, mme_gt) -> np.ndarray:
     return np.asarray(vec, dtype=np.float64)
 
 
+def _single(dist) -> bool:
+    """True when a collective would be a no-op (no process group, or one rank).  ME_FORCE_COLLECTIVES=1 sends one-rank
+    jobs through the collectives anyway: the way to exercise the RCCL calls on a single GPU (tests/test_gpu_slab.py)."""
+    import os
+
+    if dist is None or not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("ME_FORCE_COLLECTIVES", "0") != "1"
+
+
 def all_reduce_sum(vec: np.ndarray, dist, device) -> np.ndarray:
     """Sum over ranks (no-op without a process group)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(dist):
         return vec
     import torch
 
@@ -68,7 +78,7 @@ def direction_stats(vec: np.ndarray, i: int, sigma_num: np.ndarray, n_src: int) 
 # ---------------------------------------------------------------------------------------------------------------
 def _all_reduce(t, dist, comm_device, op=None):
     """all_reduce of a torch tensor living anywhere, through `comm_device` (cuda for nccl/RCCL, cpu for gloo)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(dist):
         return t
     src_device = t.device
     c = t.to(comm_device).contiguous()
@@ -224,7 +234,7 @@ def _slab_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     for q, r in ((ME_SLOT_EST, ME_SLOT_GT), (ME_SLOT_GT, ME_SLOT_EST)):
         eng.nn1(q, r, fetch=False)
         cnt = eng.nn_unresolved_count(q)
-        if dist is not None and world > 1:
+        if not _single(dist):
             # everybody learns everybody's count (one tiny all-reduce of a one-hot vector)
             onehot = torch.zeros(world, dtype=torch.int64)
             onehot[rank] = cnt
@@ -266,7 +276,7 @@ def _slab_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         local = [lane.rows[ME_SLOT_EST], lane.rows[ME_SLOT_GT]]
     else:
         local = [_partial_rows(eng, slot, P.vmd_voxel_size_) for slot in (ME_SLOT_EST, ME_SLOT_GT)]
-    if dist is not None and world > 1:
+    if not _single(dist):
         vmax = _all_reduce(torch.tensor([len(local[0]), len(local[1])], dtype=torch.int64), dist, comm_device, dist.ReduceOp.MAX)
         for rows, m in zip(local, vmax.tolist()):
             g = _all_gather_rows(torch.from_numpy(rows), max(int(m), 1), dist, comm_device, pad_value=0.0)

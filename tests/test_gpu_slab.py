@@ -84,7 +84,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, est, gt, T, q, overlap):
+def _worker(rank, world, port, est, gt, T, q, overlap, backend="gloo"):
     import torch
     import torch.distributed as dist
 
@@ -93,11 +93,15 @@ def _worker(rank, world, port, est, gt, T, q, overlap):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        os.environ["ME_FORCE_COLLECTIVES"] = "1"  # one rank, but every collective of the step goes through RCCL
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=1.0, initial_matrix_=T)
+        comm = torch.device("cuda", 0) if backend == "nccl" else torch.device("cpu")
         with Engine(0) as eng:
-            res = medist.suite_step_slab(eng, dist, torch.device("cpu"), est, gt, P, rank, world, halo=0.5, overlap=overlap)
+            res = medist.suite_step_slab(eng, dist, comm, est, gt, P, rank, world, halo=0.5, overlap=overlap)
         q.put((rank, {k: (v if not isinstance(v, dict) else {kk: np.asarray(vv) for kk, vv in v.items()}) for k, v in res.items()}))
     finally:
         dist.destroy_process_group()
@@ -145,3 +149,36 @@ def test_two_process_slab_suite_matches_oracle(overlap):
         assert r["n_w"] == len(o_v["rows"])
         np.testing.assert_allclose(r["awd"], o_v["awd"], rtol=1e-9)
         np.testing.assert_allclose(r["scs"], o_v["scs"], rtol=1e-9)
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_step_through_rccl_matches_the_plain_step():
+    """There is one GPU here, so the RCCL calls of the slab step cannot be exercised across ranks; a one-rank `nccl`
+    process group with ME_FORCE_COLLECTIVES=1 still sends every all-reduce / all-gather of the step through RCCL on
+    device tensors (int64 MAX, float64 SUM, padded float64 gathers): the result must equal the same step without a
+    process group."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Engine, Param
+
+    est, gt = _scene(60_000)
+    T = np.eye(4)
+    T[:3, 3] = [0.003, -0.002, 0.001]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), est, gt, T, q, True, "nccl"))
+    p.start()
+    rank, r = q.get(timeout=500)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and rank == 0
+    P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=1.0, initial_matrix_=T)
+    with Engine(0) as eng:
+        ref = medist.suite_step_slab(eng, None, torch.device("cpu"), est, gt, P, 0, 1, halo=0.5, overlap=True)
+    for k in ("cd", "mme_est", "mme_gt", "awd", "scs"):
+        assert r[k] == ref[k], k
+    for d in ("est_gt", "gt_est"):
+        for k in ("mean", "rmse", "sigma", "number", "fitness"):
+            assert np.array_equal(np.asarray(r[d][k]), np.asarray(ref[d][k])), (d, k)
+    assert r["n_w"] == ref["n_w"] and r["mme_valid"] == ref["mme_valid"]
