@@ -294,11 +294,20 @@ class _Lane:
     HBM-bound work (index of the ground truth, both voxel tables) while the main lane runs the VALU-bound MME / 1-NN
     kernels; ctypes calls release the GIL, the two HIP streams overlap on the device."""
 
-    def __init__(self, eng, gt, P, upload_gt, partials=False):
+    def __init__(self, eng, gt, P, upload_gt, partials=False, after_est=False, nn_back=False):
         import threading
 
         self.err = None
         self.partials = partials  # slab mode: raw per-rank partial tables instead of the finished voxel tables
+        # after_est: index the ground truth only once the map's index is built.  Both builds are HBM-bound, side by
+        # side each takes twice as long and the map's MME (which only needs the map) starts late; one after the other,
+        # the ground truth is indexed UNDER that MME kernel.  (Not in slab mode: a rank's MME is too short to hide it.)
+        self.after_est = after_est
+        # nn_back: this lane also runs the ground-truth -> map search and its partial sums, so that the latency-bound
+        # octree fallback of one direction overlaps the grid kernel of the other (single-GPU step only: the slab step
+        # has collectives inside the search)
+        self.nn_back = nn_back
+        self.parts_back = None
         self.rows = {}
         self.gt_ready = threading.Event()
         self.est_ready = threading.Event()
@@ -307,6 +316,10 @@ class _Lane:
 
     def _run(self, lane, gt, P, upload_gt):
         try:
+            if self.after_est:
+                self.est_ready.wait()
+                if self.err is not None:
+                    return
             if upload_gt:
                 lane.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
             self.gt_ready.set()
@@ -314,6 +327,9 @@ class _Lane:
             self.est_ready.wait()
             if self.err is None:
                 self._voxel(lane, ME_SLOT_EST, P)
+            if self.err is None and self.nn_back:
+                lane.nn1(ME_SLOT_GT, ME_SLOT_EST, fetch=False)
+                self.parts_back = lane.nn_partial_sums(ME_SLOT_GT, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_)
         except BaseException as e:  # re-raised by join()
             self.err = e
             self.gt_ready.set()
@@ -350,7 +366,10 @@ def suite_step(eng, dist, device, est, gt, P, evaluate_gt_mme: bool = True, uplo
     """
     lane = None
     if overlap and upload and hasattr(eng, "twin"):
-        lane = _Lane(eng, gt, P, True)
+        import os
+
+        lane = _Lane(eng, gt, P, True, after_est=os.environ.get("ME_LANE_AFTER_EST", "0") == "1",
+                     nn_back=os.environ.get("ME_LANE_NN_BACK", "1") == "1")
     try:
         if upload:
             eng.upload(ME_SLOT_EST, est, T=np.asarray(P.initial_matrix_, dtype=np.float64), cell_size=P.nn_radius_)
@@ -385,7 +404,12 @@ def _suite_after_upload(eng, dist, device, P, evaluate_gt_mme, lane):
     n_e, n_g = eng.size(ME_SLOT_EST), eng.size(ME_SLOT_GT)
     # --- AC / COM / CD (map_eval.cpp:76, :1194): both directions, partial sums over the rank's slab ---
     parts = []
+    back_on_lane = lane is not None and getattr(lane, "nn_back", False)
     for q, r in ((ME_SLOT_EST, ME_SLOT_GT), (ME_SLOT_GT, ME_SLOT_EST)):
+        if back_on_lane and q == ME_SLOT_GT:
+            lane.join()  # the second lane has searched this direction meanwhile (and built both voxel tables)
+            parts.append(lane.parts_back)
+            continue
         eng.nn1(q, r, fetch=False)
         parts.append(eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_))
     vec = all_reduce_sum(pack_partials(parts, m_e, m_g), dist, device)  # collective #1
@@ -402,7 +426,7 @@ def _suite_after_upload(eng, dist, device, P, evaluate_gt_mme, lane):
     mme_est = vec[o] / vec[o + 1] if vec[o + 1] > 0 else 0.0      # (:1720-1724)
     mme_gt = vec[o + 2] / vec[o + 3] if vec[o + 3] > 0 else 0.0
     # --- AWD / SCS (map_eval.cpp:85): O(V) voxel tables, replicated on every rank ---
-    if lane is not None:
+    if lane is not None and not back_on_lane:
         lane.join()  # both voxel tables are built (and cached on the clouds) by now
     v = eng.calculateVMD(P.vmd_voxel_size_, rows=False)
     return dict(est_gt=s_eg, gt_est=s_ge, ac=s_eg["rmse"], com=s_eg["fitness"], cd=s_eg["mean_nn"] + s_ge["mean_nn"],
