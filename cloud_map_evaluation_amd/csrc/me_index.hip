@@ -102,6 +102,42 @@ __global__ void k_slab_compact(const double *__restrict__ xyz, long long n, int 
     out[3 * o + 2] = p[2];
 }
 
+// upload from a device buffer: copy + optional transform + bounding-box partials in ONE pass over the cloud (three
+// passes otherwise: the copy, k_transform, k_bbox).  Same arithmetic as k_transform / k_bbox; part = [blocks][6].
+__global__ void __launch_bounds__(256)
+k_ingest(const double *__restrict__ in, long long n, int has_T, Mat4 T, double *__restrict__ out, double *__restrict__ part) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        double p[3] = {in[3 * i], in[3 * i + 1], in[3 * i + 2]};
+        if (has_T) transform_point(T, p[0], p[1], p[2], p);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            out[3 * i + d] = p[d];
+            lo[d] = fmin(lo[d], p[d]);
+            hi[d] = fmax(hi[d], p[d]);
+        }
+    }
+    __shared__ double sm[4][6];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[d] = fmin(lo[d], __shfl_down(lo[d], o, 64));
+            hi[d] = fmax(hi[d], __shfl_down(hi[d], o, 64));
+        }
+        if (lane == 0) {
+            sm[w][d] = lo[d];
+            sm[w][3 + d] = hi[d];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        part[6 * blockIdx.x + d] = fmin(fmin(sm[0][d], sm[1][d]), fmin(sm[2][d], sm[3][d]));
+        part[6 * blockIdx.x + 3 + d] = fmax(fmax(sm[0][3 + d], sm[1][3 + d]), fmax(sm[2][3 + d], sm[3][3 + d]));
+    }
+}
+
 __global__ void k_morton(const double *__restrict__ xyz, long long n, double ox, double oy, double oz, double fine_h,
                          unsigned long long *__restrict__ codes, unsigned int *__restrict__ iota) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,10 +343,20 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
     c.have_normals = c.have_cov = false;
     c.slab = ctx->slab;
     c.n_unres = 0;
-    if (ctx->slab.axis < 0) {
+    bool bbox_ready = false;
+    if (ctx->slab.axis < 0 && src_on_device) {
+        // one pass: copy + transform + bounding-box partials
         ME_CHECK(ctx, c.xyz.ensure((size_t) n * 3 * sizeof(double)));
-        ME_CHECK(ctx, hipMemcpyAsync(c.xyz.p, src, (size_t) n * 3 * sizeof(double),
-                                     src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        const unsigned int nb = (unsigned int) std::min<long long>(1024, (n + 255) / 256);
+        ME_CHECK(ctx, ctx->red.ensure((size_t) nb * 6 * sizeof(double)));
+        Mat4 m{};
+        if (T) std::memcpy(m.m, T, sizeof(m.m));
+        hipLaunchKernelGGL(k_ingest, dim3(nb), dim3(256), 0, ctx->stream, src, n, T ? 1 : 0, m, c.xyz.as<double>(),
+                           ctx->red.as<double>());
+        bbox_ready = true;
+    } else if (ctx->slab.axis < 0) {
+        ME_CHECK(ctx, c.xyz.ensure((size_t) n * 3 * sizeof(double)));
+        ME_CHECK(ctx, hipMemcpyAsync(c.xyz.p, src, (size_t) n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         if (T) {
             Mat4 m;
             std::memcpy(m.m, T, sizeof(m.m));
@@ -351,11 +397,11 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
         }
     }
     c.cell_size_req = cell_size;
-    return cloud_finish(ctx, slot);
+    return cloud_finish(ctx, slot, bbox_ready);
 }
 
 // bbox of the points now in c.xyz, then the index (shared by upload, in-place down-sampling and in-place transform)
-int cloud_finish(me_ctx *ctx, int slot) {
+int cloud_finish(me_ctx *ctx, int slot, bool bbox_ready) {
     Cloud &c = ctx->cloud[slot];
     const long long n = c.n;
     c.uploaded = false;
@@ -367,7 +413,8 @@ int cloud_finish(me_ctx *ctx, int slot) {
     // bbox
     const unsigned int nb = (unsigned int) std::min<long long>(1024, (n + 255) / 256);
     ME_CHECK(ctx, ctx->red.ensure((size_t) nb * 6 * sizeof(double)));
-    hipLaunchKernelGGL(k_bbox, dim3(nb), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, ctx->red.as<double>());
+    if (!bbox_ready)  // (an upload from a device buffer has produced the partials in its single pass, k_ingest)
+        hipLaunchKernelGGL(k_bbox, dim3(nb), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, ctx->red.as<double>());
     std::vector<double> part((size_t) nb * 6);
     ME_CHECK(ctx, hipMemcpyAsync(part.data(), ctx->red.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));

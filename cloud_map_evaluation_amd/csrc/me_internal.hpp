@@ -253,7 +253,7 @@ int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n);
 int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, long long n, const double *T,
                  double cell_size);
 int cloud_build_index(me_ctx *ctx, int slot, double cell_size);
-int cloud_finish(me_ctx *ctx, int slot);
+int cloud_finish(me_ctx *ctx, int slot, bool bbox_ready = false);
 int cloud_transform(me_ctx *ctx, int slot, const double *T);
 int voxel_downsample(me_ctx *ctx, int slot, double voxel_size, long long *n_out);
 
