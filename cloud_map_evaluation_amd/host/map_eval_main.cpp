@@ -23,18 +23,22 @@ int main(int argc, char **argv) {
         }
     }
     if (argc > 2 && std::string(argv[1]) == "--cloud-info") {
-        std::vector<double> xyz;
+        std::vector<double> xyz, nrm;
         std::string err, path = argv[2];
-        const bool ok = path.size() > 4 && path.substr(path.size() - 4) == ".ply" ? pcio::read_ply(path, xyz, &err) : pcio::read_pcd(path, xyz, &err);
+        const bool ok = path.size() > 4 && path.substr(path.size() - 4) == ".ply" ? pcio::read_ply(path, xyz, &err)
+                                                                                     : pcio::read_pcd(path, xyz, &err, &nrm);
         if (!ok) {
             std::cerr << "ERROR: " << err << std::endl;
             return EXIT_FAILURE;
         }
-        double s[3] = {0, 0, 0};
+        double s[3] = {0, 0, 0}, sn[3] = {0, 0, 0};
         for (size_t i = 0; i < xyz.size() / 3; ++i)
             for (int d = 0; d < 3; ++d) s[d] += xyz[3 * i + d];
+        for (size_t i = 0; i < nrm.size() / 3; ++i)
+            for (int d = 0; d < 3; ++d) sn[d] += nrm[3 * i + d];
         std::cout << std::setprecision(17) << "{\"points\": " << xyz.size() / 3 << ", \"sum\": [" << s[0] << ", " << s[1] << ", " << s[2]
-                  << "]}" << std::endl;
+                  << "], \"normals\": " << nrm.size() / 3 << ", \"normal_sum\": [" << sn[0] << ", " << sn[1] << ", " << sn[2] << "]}"
+                  << std::endl;
         return EXIT_SUCCESS;
     }
     if (argc > 1) config_file = argv[1];

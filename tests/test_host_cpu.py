@@ -204,3 +204,36 @@ def test_full_run_without_gpu_fails_loudly(exe, tmp_path):
     # the header of map_results.txt is still written (append mode, map_eval.h:168-185)
     txt = (est_dir / "map_results" / "map_results.txt").read_text()
     assert "unit_test =====================" in txt and "Estimated-Ground Truth point count: 200 / 200" in txt
+
+
+@pytest.mark.parametrize("kind", ["ascii", "binary", "binary_compressed"])
+def test_pcd_reader_keeps_normals_with_their_points(exe, tmp_path, kind):
+    """normal_x / normal_y / normal_z travel with the points (point-to-plane ICP needs them on the target): a row whose
+    coordinates are not finite is dropped together with its normal; a file without the fields yields no normals."""
+    rng = np.random.default_rng(3)
+    n = 500
+    pts = rng.uniform(-50, 50, (n, 3)).astype("f4").astype(np.float64)
+    nrm = rng.normal(size=(n, 3)).astype("f4").astype(np.float64)
+    pts[7, 2] = np.nan
+    hdr = (f"# .PCD v0.7\nVERSION 0.7\nFIELDS x y z normal_x normal_y normal_z curvature\nSIZE 4 4 4 4 4 4 4\n"
+           f"TYPE F F F F F F F\nCOUNT 1 1 1 1 1 1 1\nWIDTH {n}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA {kind}\n")
+    cols = np.hstack([pts, nrm, np.zeros((n, 1))]).astype("f4")
+    path = tmp_path / f"n_{kind}.pcd"
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        if kind == "ascii":
+            for row in cols:
+                f.write((" ".join("nan" if not np.isfinite(v) else repr(float(v)) for v in row) + "\n").encode())
+        elif kind == "binary":
+            f.write(cols.tobytes())
+        else:
+            raw = b"".join(cols[:, c].tobytes() for c in range(7))
+            comp = _lzf_literal(raw)
+            f.write(struct.pack("<II", len(comp), len(raw)) + comp)
+    info = json.loads(run(exe, "--cloud-info", str(path)).stdout)
+    keep = np.isfinite(pts).all(1)
+    assert info["points"] == info["normals"] == keep.sum() == n - 1
+    np.testing.assert_allclose(info["normal_sum"], nrm[keep].sum(0), rtol=1e-9, atol=1e-6)
+    plain = tmp_path / "plain.pcd"
+    _write_pcd(plain, pts[keep], "binary")
+    assert json.loads(run(exe, "--cloud-info", str(plain)).stdout)["normals"] == 0
