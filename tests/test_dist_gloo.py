@@ -398,3 +398,70 @@ def test_merge_voxel_partials_is_chan_exact():
     big = n2 > 10
     exp[big] = exp[big] / (n2[big] - 1.0)[:, None, None] / (n2[big] - 1.0)[:, None, None]
     np.testing.assert_allclose(sig, exp, rtol=1e-10, atol=1e-18)
+
+
+class _TwoLaneEngine(OracleShardEngine):
+    """The stand-in with a twin(): the second lane of an overlapped step then runs on a real second thread."""
+
+    def __init__(self, fail_in=None):
+        super().__init__()
+        self.fail_in = fail_in
+        self.calls = []
+
+    def twin(self):
+        return self
+
+    def voxel_build(self, slot, vs):
+        self.calls.append(("voxel_build", slot))
+        if self.fail_in == "voxel_build":
+            raise RuntimeError("lane failure")
+
+    def nn1(self, q, r, fetch=False):
+        import threading
+
+        self.calls.append(("nn1", q, threading.current_thread() is threading.main_thread()))
+        return super().nn1(q, r, fetch)
+
+
+def _small_pair():
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.cube_pair(6000, seed=4)
+    return est.numpy(), gt.numpy()
+
+
+def test_overlapped_driver_equals_sequential_driver_on_cpu():
+    """dist._Lane on CPU: same scalars with and without the second lane; the ground-truth -> map search runs on the lane's
+    thread, the map -> ground-truth one on the caller's."""
+    import torch
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Param
+
+    est, gt = _small_pair()
+    P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=2.0)
+    seq = medist.suite_step(_TwoLaneEngine(), None, torch.device("cpu"), est, gt, P, overlap=False)
+    eng = _TwoLaneEngine()
+    ovl = medist.suite_step(eng, None, torch.device("cpu"), est, gt, P, overlap=True)
+    assert seq["n_w"] > 0 and np.isfinite(seq["awd"])
+    for k in ("cd", "mme_est", "mme_gt", "awd", "scs", "mme_valid", "n_w"):
+        assert seq[k] == ovl[k], k
+    for d in ("est_gt", "gt_est"):
+        for k in ("mean", "rmse", "sigma", "number", "fitness"):
+            assert np.array_equal(np.asarray(seq[d][k]), np.asarray(ovl[d][k])), (d, k)
+    on_main = {c[1]: c[2] for c in eng.calls if c[0] == "nn1"}
+    assert on_main == {0: True, 1: False}
+    assert [c for c in eng.calls if c[0] == "voxel_build"] == [("voxel_build", 1), ("voxel_build", 0)]
+
+
+@pytest.mark.timeout(120)
+def test_a_failure_on_the_second_lane_surfaces_and_does_not_hang():
+    import torch
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Param
+
+    est, gt = _small_pair()
+    P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=0.5)
+    with pytest.raises(RuntimeError, match="lane failure"):
+        medist.suite_step(_TwoLaneEngine(fail_in="voxel_build"), None, torch.device("cpu"), est, gt, P, overlap=True)
