@@ -18,7 +18,12 @@
  *     SearchKNN(k=1) returns the SQUARED distance ((dx*dx + dy*dy) + dz*dz) in fp64,
  *     SearchRadius(q, r) returns all points with d2 < r*r sorted ascending.
  *   Eigen 3.3.7: Matrix3d::determinant (cofactor expansion along row 0),
- *     SelfAdjointEigenSolver<Matrix3d> (restated as cyclic Jacobi), LLT (Cholesky, no pivoting).
+ *     SelfAdjointEigenSolver<Matrix3d> (restated as cyclic Jacobi), LLT (Cholesky, no pivoting),
+ *     Matrix3d::inverse (cofactors).
+ *   Open3D registration (performICPRegistration, map_eval.cpp:1366-1394) — PARITY UNPINNED, cross-checked against
+ *     numpy / scipy in tests/test_oracle_registration.py: EstimateNormals(KDTreeSearchParamKNN) = k-NN +
+ *     utility::ComputeCovariance + FastEigen3x3; InitializePointCloudForGeneralizedICP; the J^T J / J^T r sums of
+ *     TransformationEstimationPointToPlane and TransformationEstimationForGeneralizedICP; RegistrationICP's loop.
  */
 #ifndef MAPEVAL_ORACLE_H
 #define MAPEVAL_ORACLE_H
