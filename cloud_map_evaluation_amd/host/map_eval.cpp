@@ -176,7 +176,7 @@ int MapEval::process() {
     bool ok_gt;
     std::vector<double> gt_normals;  // normal_x/y/z of the ground truth, if the file has them (point-to-plane ICP needs them)
     if (ext == "pcd") ok_gt = pcio::read_pcd(param_.map_gt_path_, gt_3d_->points_, &err, &gt_normals);
-    else if (ext == "ply") ok_gt = pcio::read_ply(param_.map_gt_path_, gt_3d_->points_, &err);
+    else if (ext == "ply") ok_gt = pcio::read_ply(param_.map_gt_path_, gt_3d_->points_, &err, &gt_normals);
     else return fail("Unsupported ground truth file format: " + param_.map_gt_path_);
     if (!ok_gt) std::cerr << "WARNING: " << err << std::endl;
     const bool success = pcio::read_pcd(param_.evaluation_map_pcd_path_ + param_.pcd_file_name_, map_3d_->points_, &err);

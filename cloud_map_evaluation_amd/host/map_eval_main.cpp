@@ -25,7 +25,7 @@ int main(int argc, char **argv) {
     if (argc > 2 && std::string(argv[1]) == "--cloud-info") {
         std::vector<double> xyz, nrm;
         std::string err, path = argv[2];
-        const bool ok = path.size() > 4 && path.substr(path.size() - 4) == ".ply" ? pcio::read_ply(path, xyz, &err)
+        const bool ok = path.size() > 4 && path.substr(path.size() - 4) == ".ply" ? pcio::read_ply(path, xyz, &err, &nrm)
                                                                                      : pcio::read_pcd(path, xyz, &err, &nrm);
         if (!ok) {
             std::cerr << "ERROR: " << err << std::endl;

@@ -204,7 +204,9 @@ inline int ply_type_size(const std::string &t) {
     return -1;
 }
 
-inline bool read_ply(const std::string &path, std::vector<double> &xyz, std::string *err = nullptr) {
+// normals (optional): the vertex properties nx / ny / nz of the kept points, when the file has them
+inline bool read_ply(const std::string &path, std::vector<double> &xyz, std::string *err = nullptr,
+                     std::vector<double> *normals = nullptr) {
     auto fail = [&](const std::string &m) {
         if (err) *err = m;
         return false;
@@ -240,7 +242,7 @@ inline bool read_ply(const std::string &path, std::vector<double> &xyz, std::str
         } else if (key == "end_header") break;
     }
     if (!vertex_first) return fail("PLY: vertex element must come first");
-    int ix = -1, iy = -1, iz = -1;
+    int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1;
     std::vector<size_t> off(props.size());
     size_t rec = 0;
     for (size_t i = 0; i < props.size(); ++i) {
@@ -251,16 +253,31 @@ inline bool read_ply(const std::string &path, std::vector<double> &xyz, std::str
         if (props[i].name == "x") ix = (int) i;
         if (props[i].name == "y") iy = (int) i;
         if (props[i].name == "z") iz = (int) i;
+        if (props[i].name == "nx") inx = (int) i;
+        if (props[i].name == "ny") iny = (int) i;
+        if (props[i].name == "nz") inz = (int) i;
     }
     if (ix < 0 || iy < 0 || iz < 0) return fail("PLY has no x/y/z vertex properties");
     xyz.clear();
     xyz.reserve(n_vertex * 3);
+    const bool want_n = normals && inx >= 0 && iny >= 0 && inz >= 0;
+    if (normals) normals->clear();
+    if (want_n) normals->reserve(n_vertex * 3);
+    auto push_n = [&](double a, double b, double c) {
+        normals->push_back(a);
+        normals->push_back(b);
+        normals->push_back(c);
+    };
     if (format == "ascii") {
         std::vector<double> row(props.size());
         for (size_t p = 0; p < n_vertex && std::getline(f, line); ++p) {
             std::stringstream ss(line);
-            for (auto &v : row) ss >> v;
-            push_if_finite(xyz, row[ix], row[iy], row[iz]);
+            std::string tok;
+            for (auto &v : row) {  // strtod: "nan" / "inf" tokens parse as such (operator>> would fail on them)
+                v = NAN;
+                if (ss >> tok) v = std::strtod(tok.c_str(), nullptr);
+            }
+            if (push_if_finite(xyz, row[ix], row[iy], row[iz]) && want_n) push_n(row[inx], row[iny], row[inz]);
         }
     } else if (format == "binary_little_endian") {
         std::vector<unsigned char> buf(rec * n_vertex);
@@ -274,7 +291,7 @@ inline bool read_ply(const std::string &path, std::vector<double> &xyz, std::str
         };
         for (size_t p = 0; p < n_vertex; ++p) {
             const unsigned char *r = buf.data() + p * rec;
-            push_if_finite(xyz, get(r, ix), get(r, iy), get(r, iz));
+            if (push_if_finite(xyz, get(r, ix), get(r, iy), get(r, iz)) && want_n) push_n(get(r, inx), get(r, iny), get(r, inz));
         }
     } else {
         return fail("unsupported PLY format '" + format + "'");

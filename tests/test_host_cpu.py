@@ -237,3 +237,28 @@ def test_pcd_reader_keeps_normals_with_their_points(exe, tmp_path, kind):
     plain = tmp_path / "plain.pcd"
     _write_pcd(plain, pts[keep], "binary")
     assert json.loads(run(exe, "--cloud-info", str(plain)).stdout)["normals"] == 0
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian"])
+def test_ply_reader_keeps_normals_with_their_points(exe, tmp_path, fmt):
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-5, 5, (300, 3))
+    nrm = rng.normal(size=(300, 3)).astype("f4").astype(np.float64)
+    pts[11, 0] = np.nan
+    path = tmp_path / f"n_{fmt}.ply"
+    hdr = (f"ply\nformat {fmt} 1.0\nelement vertex {len(pts)}\nproperty double x\nproperty double y\nproperty double z\n"
+           "property float nx\nproperty float ny\nproperty float nz\nend_header\n")
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        if fmt == "ascii":
+            for p, q in zip(pts, nrm):
+                f.write((" ".join("nan" if not np.isfinite(v) else repr(float(v)) for v in list(p) + list(q)) + "\n").encode())
+        else:
+            rec = np.zeros(len(pts), dtype=[("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4")])
+            rec["x"], rec["y"], rec["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+            rec["nx"], rec["ny"], rec["nz"] = nrm[:, 0], nrm[:, 1], nrm[:, 2]
+            f.write(rec.tobytes())
+    info = json.loads(run(exe, "--cloud-info", str(path)).stdout)
+    keep = np.isfinite(pts).all(1)
+    assert info["points"] == info["normals"] == 299
+    np.testing.assert_allclose(info["normal_sum"], nrm[keep].sum(0), rtol=1e-9, atol=1e-6)
