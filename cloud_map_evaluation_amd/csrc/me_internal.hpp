@@ -483,10 +483,18 @@ constexpr int kGroupR = 2;
 constexpr int kGroupTab = 343;                               // (2R+1+2H)^3 for halo H = 1
 constexpr int kGroupTab2 = (2 * kGroupR + 5) * (2 * kGroupR + 5) * (2 * kGroupR + 5);  // halo H = 2: 9^3 = 729
 
-// H = halo in cells: 1 when the cell edge covers the search radius, 2 for half-radius cells (5x5x5 stencil)
-template <int H = 1>
+// H = halo in cells: 1 when the cell edge covers the search radius, 2 for half-radius cells (5x5x5 stencil).
+// CULL: a cell of the box is kept only when it lies within Chebyshev distance H of the cell of SOME group lane (the box is
+// the bounding box of the group's cells grown by H: when the cells of 64 Morton-consecutive queries do not fill their
+// bounding box — an L, a diagonal, the two sides of a Z-curve jump — whole runs of it are adjacent to nobody, and every
+// candidate of such a run would be tested by 64 lanes for nothing).  Per (y,z) row of the box the group lanes OR their x
+// position into a bit mask (LDS atomics), a row's mask is then dilated over the 3x3 neighbouring rows and by one bit in x:
+// a few dozen LDS operations per round against 64 x (9..19) VALU operations per candidate saved.  `rows` = 2 x 49 ints.
+// `tcell` (optional) receives the box-relative cell coordinates of every table slot, packed x | y << 3 | z << 6.
+template <int H = 1, bool CULL = false>
 __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, int cz, const GridView &g, int cell_lim,
-                                                 int lane, int2 *tab, GroupBox &box, int *n_keys_out = nullptr) {
+                                                 int lane, int2 *tab, GroupBox &box, int *n_keys_out = nullptr,
+                                                 unsigned int *rows = nullptr, unsigned short *tcell = nullptr) {
     const unsigned long long pm = __ballot(pending);  // caller guarantees pm != 0
     const int leader = __ffsll((long long) pm) - 1;
     const int lx = readlane_i(cx, leader), ly = readlane_i(cy, leader), lz = readlane_i(cz, leader);
@@ -503,10 +511,37 @@ __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, i
     box.z0 = z0;
     box.nx = nx;
     box.ny = ny;
+    if (CULL) {
+        const int n_rows = ny * nz;  // <= 49 (H = 1)
+        if (lane < n_rows) rows[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (in) atomicOr(&rows[(cy - y0) + ny * (cz - z0)], 1u << (cx - x0));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n_rows) {
+            const int ry = lane % ny, rz = lane / ny;
+            unsigned int m = 0;
+            for (int dz = -H; dz <= H; ++dz)
+                for (int dy = -H; dy <= H; ++dy) {
+                    const int yy = ry + dy, zz = rz + dz;
+                    if (yy >= 0 && yy < ny && zz >= 0 && zz < nz) m |= rows[yy + ny * zz];
+                }
+            unsigned int d = m;
+#pragma unroll
+            for (int s = 1; s <= H; ++s) d |= (m << s) | (m >> s);
+            rows[64 + lane] = d;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     for (int t = lane; t < n_keys; t += 64) {
-        const int ix = x0 + t % nx, iy = y0 + (t / nx) % ny, iz = z0 + t / (nx * ny);
+        const int tx = t % nx, ty = (t / nx) % ny, tz = t / (nx * ny);
+        const int ix = x0 + tx, iy = y0 + ty, iz = z0 + tz;
         int2 run = make_int2(0, 0);
-        if (ix >= 0 && iy >= 0 && iz >= 0 && ix < cell_lim && iy < cell_lim && iz < cell_lim) {
+        bool want = ix >= 0 && iy >= 0 && iz >= 0 && ix < cell_lim && iy < cell_lim && iz < cell_lim;
+        if (CULL) want = want && ((rows[64 + ty + ny * tz] >> tx) & 1u);
+        if (want) {
             const unsigned long long key = spread21((unsigned long long) ix) | (spread21((unsigned long long) iy) << 1) |
                                            (spread21((unsigned long long) iz) << 2);
             const int ci = hash_lookup(g.hkeys, g.hvals, g.hmask, key);
@@ -516,13 +551,16 @@ __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, i
             }
         }
         tab[t] = run;
+        if (tcell) tcell[t] = (unsigned short) (tx | (ty << 3) | (tz << 6));
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return in;
 }
+constexpr int kGroupRows = 128;  // LDS ints per wave for the CULL row masks (64 raw + 64 dilated)
 
-// Calls f(begin, end) once per non-empty run of the wave's table, with WAVE-UNIFORM arguments (so that a loop over
-// [begin, end) fetches candidates with scalar loads and all lanes test the same candidate).
+// Calls f(begin, end, slot) once per non-empty run of the wave's table, with WAVE-UNIFORM arguments (so that a loop over
+// [begin, end) fetches candidates with scalar loads and all lanes test the same candidate); slot = its table index.
 template <class F>
 __device__ __forceinline__ void wave_for_each_run(const int2 *tab, int n_keys, int lane, F &&f) {
     for (int base = 0; base < n_keys; base += 64) {
@@ -534,7 +572,7 @@ __device__ __forceinline__ void wave_for_each_run(const int2 *tab, int n_keys, i
             m &= m - 1;
             const int2 run = tab[base + n];
             const int cs = __builtin_amdgcn_readfirstlane(run.x), cc = __builtin_amdgcn_readfirstlane(run.y);
-            f(cs, cs + cc);
+            f(cs, cs + cc, base + n);
         }
     }
 }

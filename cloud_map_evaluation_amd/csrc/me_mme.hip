@@ -106,7 +106,7 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
         const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
         const bool in = wave_group_table<1>(!done, cx, cy, cz, g, cell_lim, lane, tab, bx, &nk);
         const double r2e = in ? r2 : -1.0;
-        wave_for_each_run(tab, nk, lane, [&](int cs, int ce) { stream_run(cs, ce, r2e); });
+        wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) { stream_run(cs, ce, r2e); });
         if (in) done = true;
         __builtin_amdgcn_wave_barrier();
     }
@@ -127,6 +127,194 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
             const double det = cxx * (cyy * czz - cyz * cyz) - cxy * (cxy * czz - cyz * cxz) + cxz * (cxy * cyz - cyy * cxz);
             const double h = 0.5 * log(2.0 * M_PI * M_E * det);  // ComputeEntropy (:1656)
             if (!isnan(h) && !isinf(h)) {                         // (:1692)
+                H = h;
+                ok = true;
+            }
+        }
+        const long long i = i_begin + (long long) loc;
+        ent_s[i] = H;                       // 0.0 where invalid (:1614)
+        valid_s[i] = ok ? 1 : 0;
+    }
+    __shared__ double smd[4];
+    __shared__ long long smi[4];
+    const double bs = block_sum_256(H, smd);
+    const long long bc = block_sum_256_ll(ok ? 1LL : 0LL, smi);
+    if (threadIdx.x == 0) {
+        part_sum[blockIdx.x] = bs;
+        part_cnt[blockIdx.x] = bc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_mme3 — the wave-shared candidate streams of k_mme with (a) an FP32 pre-test, (b) the per-run adjacency cull and
+// (c) candidates delivered through a wave-private LDS tile instead of scalar fetches.
+//
+// (a) fp64 VALU instructions issue at half the rate of 32-bit ones on gfx950 and the exact test costs 9 of them per
+// candidate (3 subtractions, 5 for ((dx*dx + dy*dy) + dz*dz), the compare) — for a lane that accepts ~12 % of what its
+// wave streams.  When a run is staged, the lane that loads candidate p also writes p' = p - o (o = corner of the round's
+// cell box) as (p'x, p'y, p'z, |p'|^2) in FP32.  With a = -2 (q - o) and T = r^2 - |q - o|^2 per lane and round, a
+// candidate costs
+//        u = fma(p'x, ax, fma(p'y, ay, fma(p'z, az, |p'|^2)))          (u - T ~ d^2 - r^2)
+// and two compares, u < T - E ("inside for sure") and u < T + E ("perhaps"), E = 2^-12 h^2 bounding everything FP32 does
+// to u - T (below).  Only when some lane sits in the band in between is that lane's exact fp64 test evaluated (a few
+// candidates in a thousand), so `k` and the accepted set are exactly those of the fp64 test, and the moments are
+// accumulated from the fp64 coordinates exactly as in k_mme: the results are bit-identical to its.
+// Error bound (h = cell edge; the box spans <= 7 cells per axis, so |p'|, |q - o| <= 7h per axis, |a| <= 14h):
+//   rounding of p' and a moves d^2 by <= 3 * 2 * (8h) * (14h 2^-24) = 672 * 2^-24 h^2;   |p'|^2 <= 147 h^2: 147;
+//   the three FMAs (partial sums <= 441 h^2): 1323;   s = |a|^2 <= 588 h^2, three roundings, a quarter of it: 441;
+//   T's own rounding: 147;   r^2 in FP32: 1.        Sum 2731 * 2^-24 h^2 < 4096 * 2^-24 h^2 = E.
+// (b) wave_group_table<1, true>: runs whose cell is adjacent to no lane of the group are not streamed at all.
+// (c) The first pre-test version fetched (FP32 record, fp64 point) per candidate with scalar loads: 48 bytes per candidate
+// through the scalar data cache instead of 32, for a third less VALU work per candidate — it ran SLOWER than k_mme
+// (29.8 vs 27.2 ms per step, more so with fewer waves per SIMD: the scalar path, not the VALU, was the limit).  Here a
+// run is copied with one coalesced vector load per TILE points; the FP32 record is read back with one broadcast
+// ds_read_b128 per candidate and the fp64 point (three ds_read_b64) only when some lane may accept it.
+// ------------------------------------------------------------------------------------------------------------
+template <int TILE, int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
+       GridView g, FrameView fr, SlabView slab, double r2, int min_k, double *__restrict__ ent_s,
+       unsigned char *__restrict__ valid_s, double *__restrict__ part_sum, long long *__restrict__ part_cnt,
+       unsigned int xcd_chunk) {
+    static_assert(TILE * 16 >= kGroupRows * 4, "the row masks of the cull alias the FP32 tile");
+    const unsigned int vb = xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);
+    const unsigned int loc = vb * blockDim.x + threadIdx.x;
+    bool active = i_begin + (long long) loc < i_end;
+    const int shift3 = 3 * g.shift;
+    const int cell_lim = 1 << (kMortonBits - g.shift);
+    const double cell_h = ldexp(fr.fine_h, g.shift);
+    const float r2f = (float) r2;
+    const float band = (float) (0x1p-12 * cell_h * cell_h);
+
+    double qx = 0, qy = 0, qz = 0;
+    unsigned long long mycell = ~0ULL;
+    if (active) {
+        const long long i = i_begin + (long long) loc;
+        const SPoint q = sp[i];
+        qx = q.x;
+        qy = q.y;
+        qz = q.z;
+        mycell = codes[i] >> shift3;
+        if (!slab_owned(slab, qx, qy, qz)) {
+            ent_s[i] = 0.0;
+            valid_s[i] = 0;
+            active = false;
+        }
+    }
+    bool done = !active;
+
+    __shared__ int2 s_tab[4][kGroupTab + 1];
+    __shared__ float4 s_tf[4][TILE];     // FP32 records of the staged run (the cull's row masks while the table is built)
+    __shared__ double s_td[4][3][TILE];  // its fp64 coordinates, one array per axis
+    const int wv = threadIdx.x >> 6;
+    int2 *tab = s_tab[wv];
+    float4 *tf = s_tf[wv];
+    double *tdx = s_td[wv][0], *tdy = s_td[wv][1], *tdz = s_td[wv][2];
+    const int lane = threadIdx.x & 63;
+
+    double det_keep = 0.0;  // determinant of the neighbourhood covariance (valid when have_det)
+    bool have_det = false;  // the query has at least min_k neighbours
+    // A lane accumulates in exactly ONE round (the one whose group it belongs to), so the moments live inside the round:
+    // nothing of them is alive while the next round's table is built.
+    while (__ballot(!done)) {
+        GroupBox bx;
+        int nk = 0;
+        const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
+        const bool in = wave_group_table<1, true>(!done, cx, cy, cz, g, cell_lim, lane, tab, bx, &nk,
+                                                  reinterpret_cast<unsigned int *>(tf));
+        const double ox = fr.ox + (double) bx.x0 * cell_h, oy = fr.oy + (double) bx.y0 * cell_h,
+                     oz = fr.oz + (double) bx.z0 * cell_h;  // wave-uniform
+        const float ax = (float) (-2.0 * (qx - ox)), ay = (float) (-2.0 * (qy - oy)), az = (float) (-2.0 * (qz - oz));
+        const float s = fmaf(az, az, fmaf(ay, ay, ax * ax));
+        // (the group predicate rides on the thresholds: lanes outside the group accept nothing)
+        const float t_hi = in ? fmaf(-0.25f, s, r2f + band) : -INFINITY;
+        const float t_lo = in ? fmaf(-0.25f, s, r2f - band) : -INFINITY;
+        int k = 0;
+        double s1x = 0, s1y = 0, s1z = 0;
+        double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+        auto test = [&](const float4 &c, int j) {
+            const float u = fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
+            const bool hi = u < t_hi;
+            if (__ballot(hi)) {  // some lane may hold this candidate inside its radius
+                bool acc = u < t_lo;
+                const double dx = tdx[j] - qx, dy = tdy[j] - qy, dz = tdz[j] - qz;
+                if (__builtin_expect(__ballot(hi != acc) != 0, 0)) {  // a lane in the band: its exact test decides
+                    asm volatile("; band: exact test" ::: "memory");     // (keeps the compiler from evaluating it always)
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    acc = acc || (hi && d2 < r2);                        // strict, nanoflann RadiusResultSet [upstream]
+                }
+                if (acc) {
+                    ++k;
+                    s1x += dx;
+                    s1y += dy;
+                    s1z += dz;
+                    sxx = fma(dx, dx, sxx);
+                    sxy = fma(dx, dy, sxy);
+                    sxz = fma(dx, dz, sxz);
+                    syy = fma(dy, dy, syy);
+                    syz = fma(dy, dz, syz);
+                    szz = fma(dz, dz, szz);
+                }
+            }
+        };
+        wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) {
+            for (int base = cs; base < ce; base += TILE) {
+                const int n = min(TILE, ce - base);
+                if (lane < n) {
+                    const SPoint p = sp[base + lane];
+                    const double px = p.x - ox, py = p.y - oy, pz = p.z - oz;
+                    const float fx = (float) px, fy = (float) py, fz = (float) pz;
+                    // |p'|^2 of the ROUNDED coordinates (the error bound is stated for them), rounded once
+                    const double w = ((double) fx * (double) fx + (double) fy * (double) fy) + (double) fz * (double) fz;
+                    tf[lane] = make_float4(fx, fy, fz, (float) w);
+                    tdx[lane] = p.x;
+                    tdy[lane] = p.y;
+                    tdz[lane] = p.z;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                int j = 0;
+                for (; j + 4 <= n; j += 4) {
+                    const float4 c0 = tf[j], c1 = tf[j + 1], c2 = tf[j + 2], c3 = tf[j + 3];
+                    test(c0, j);
+                    test(c1, j + 1);
+                    test(c2, j + 2);
+                    test(c3, j + 3);
+                }
+                for (; j < n; ++j) {
+                    const float4 c0 = tf[j];
+                    test(c0, j);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
+            }
+        });
+        if (in) {
+            done = true;
+            const int kk = k - 1;  // drop the query itself (map_eval.cpp:1672-1673)
+            if (kk >= min_k) {     // (:1675 k >= 10, :1458 k >= 5)
+                const double inv_k = 1.0 / (double) kk, inv_km1 = 1.0 / (double) (kk - 1);
+                const double cxx = (sxx - s1x * s1x * inv_k) * inv_km1;
+                const double cxy = (sxy - s1x * s1y * inv_k) * inv_km1;
+                const double cxz = (sxz - s1x * s1z * inv_k) * inv_km1;
+                const double cyy = (syy - s1y * s1y * inv_k) * inv_km1;
+                const double cyz = (syz - s1y * s1z * inv_k) * inv_km1;
+                const double czz = (szz - s1z * s1z * inv_k) * inv_km1;
+                // Eigen 3x3 determinant (cofactor expansion along row 0)
+                det_keep = cxx * (cyy * czz - cyz * cyz) - cxy * (cxy * czz - cyz * cxz) + cxz * (cxy * cyz - cyy * cxz);
+                have_det = true;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // (the logarithm stays outside the round loop: inside, the compiler hoists its polynomial constants into VGPRs that
+    // live across the candidate loop and spills them)
+    double H = 0.0;
+    bool ok = false;
+    if (active) {
+        if (have_det) {
+            const double h = 0.5 * log(2.0 * M_PI * M_E * det_keep);  // ComputeEntropy (:1656); NaN for det < 0
+            if (!isnan(h) && !isinf(h)) {                              // (:1692)
                 H = h;
                 ok = true;
             }
@@ -216,9 +404,27 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     long long *outc = reinterpret_cast<long long *>(outs + 1);
     const double r2 = radius * radius;  // Open3D SearchRadius -> nanoflann radiusSearch(q, r*r) [upstream]
     {
+        // ME_MME_V=1 runs the first version (exact fp64 test per candidate, no cull) for A/B measurements; ME_MME_WAVES
+        // picks the occupancy the kernel is compiled for (waves per SIMD)
+        static const int variant = std::getenv("ME_MME_V") ? std::atoi(std::getenv("ME_MME_V")) : 2;
+        static const int waves = std::getenv("ME_MME_WAVES") ? std::atoi(std::getenv("ME_MME_WAVES")) : 8;
+        static const int tile = std::getenv("ME_MME_TILE") ? std::atoi(std::getenv("ME_MME_TILE")) : 32;
+        const FrameView fr{c.origin[0], c.origin[1], c.origin[2], c.fine_h};
         TimerScope ts(ctx, "mme");
-        hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
-                           c.grid, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting());
+        if (variant == 1) {
+            hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
+                               c.grid, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting());
+        } else {
+#define ME_LAUNCH_MME3(T, W)                                                                                                  \
+    hipLaunchKernelGGL((k_mme3<T, W>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),                                \
+                       c.codes.as<unsigned long long>(), b, e, c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(),             \
+                       val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting())
+            if (tile == 32 && waves >= 8) ME_LAUNCH_MME3(32, 8);
+            else if (tile == 32) ME_LAUNCH_MME3(32, 7);
+            else if (waves >= 7) ME_LAUNCH_MME3(64, 7);
+            else ME_LAUNCH_MME3(64, 6);
+#undef ME_LAUNCH_MME3
+        }
     }
     const long long chunk = ((long long) nb + kStage - 1) / kStage;
     hipLaunchKernelGGL(k_mme_final, dim3(kStage), dim3(256), 0, ctx->stream, ps, pc, (long long) nb, chunk, ps2, pc2);

@@ -137,7 +137,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     // version fetched the candidates with scalar loads (s_load, candidate in SGPRs): the scalar cache misses on this
     // stream (rocprofv3 SQC counters: 75 % of the requests), so every group of four paid an L2 round trip that 8 waves
     // per SIMD could not hide (68 % VALU issue).
-    __shared__ float4 s_tile[4][64];
+    __shared__ float4 s_tile[4][64];  // (doubles as the row masks of the adjacency cull while a round's table is built)
     float4 *tile = s_tile[threadIdx.x >> 6];
     double ox = 0, oy = 0, oz = 0;  // the round's local origin (wave-uniform)
     auto rank = [&](int j) {
@@ -167,7 +167,9 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     while (__ballot(!done)) {
         GroupBox bx;
         int nk = 0;
-        const bool in = wave_group_table<1>(!done, mcx, mcy, mcz, g, cell_lim, lane, tab, bx, &nk);
+        // (cull: a run adjacent to no lane of the group is in nobody's 3x3x3 block, so nobody's resolution test needs it)
+        const bool in = wave_group_table<1, true>(!done, mcx, mcy, mcz, g, cell_lim, lane, tab, bx, &nk,
+                                                  reinterpret_cast<unsigned int *>(tile));
         ox = fr.ox + (double) bx.x0 * cell_h;
         oy = fr.oy + (double) bx.y0 * cell_h;
         oz = fr.oz + (double) bx.z0 * cell_h;
@@ -177,7 +179,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             az = (float) (-2.0 * (qz - oz));
         }
         bias = in ? 0.0f : INFINITY;
-        wave_for_each_run(tab, nk, lane, [&](int cs, int ce) { stream_run(cs, ce); });
+        wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) { stream_run(cs, ce); });
         if (in) done = true;
         __builtin_amdgcn_wave_barrier();
     }
