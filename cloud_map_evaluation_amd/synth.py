@@ -8,7 +8,9 @@ jittered off-lattice / off-plane so that inlier counts and MME validity do not s
 
 Workloads (restated as surface-density-driven scenes so that nn_radius finds neighbours):
   cube_pair     C1  100 k points on a 4 m cube + noised copy.
-  campus_pair   C2-C4  ground + boxes + poles at a target surface density (points / m^2).
+  campus_pair   C2-C3  ground + boxes + poles at a target surface density (points / m^2); est = perturbed GT points.
+  scan_pair     C2-C4  same scene, est = an INDEPENDENT scan of it, both clouds exactly n points (the bench default).
+  multisession_pair  C4  est = union of three independent scans with their own drifts.
   tunnel_pair   C5  degenerate geometry (tunnel + flat field + staircase) for the AWD eigen-clamp.
 """
 from __future__ import annotations
@@ -76,13 +78,15 @@ def _box_surface(n, g, device, cx, cy, w, d, h, yaw):
     return torch.stack([cx + c * x - sn * y, cy + sn * x + c * y, z], dim=1)
 
 
-def campus_scene(n: int, density: float = 2500.0, seed: int = 100, device="cpu", origin=(0.0, 0.0, 0.0)):
+def campus_scene(n: int, density: float = 2500.0, seed: int = 100, device="cpu", origin=(0.0, 0.0, 0.0), sample_seed=None):
     """Ground + rotated boxes + poles, surface-sampled at ~`density` points/m^2, 2 mm off-surface jitter.
 
     The scene extent follows from n / density (50 % ground, 40 % buildings, 10 % poles), so the local
-    neighbourhood statistics (k in nn_radius) do not change with n.
+    neighbourhood statistics (k in nn_radius) do not change with n.  `seed` fixes the GEOMETRY (buildings, poles);
+    `sample_seed` (default: seed) the points drawn on it: two calls with the same seed and n / density ratio but different
+    sample_seed are two independent scans of the same place.
     """
-    g = _gen(seed, device)
+    g = _gen(seed if sample_seed is None else sample_seed, device)
     n_ground = n // 2
     n_pole = n // 10
     n_box = n - n_ground - n_pole
@@ -133,7 +137,7 @@ def campus_scene(n: int, density: float = 2500.0, seed: int = 100, device="cpu",
 
 def perturb(gt: torch.Tensor, seed: int = 101, noise_std: float = 0.02, drift: float = 0.05,
             outlier_ratio: float = 0.001, outlier_std: float = 5.0, keep_sparse: float = 0.7,
-            region_size: float = 10.0):
+            region_size: float = 10.0, phase: float = 0.0):
     """est = thinned(GT) + smooth drift (<= `drift` m) + N(0, noise_std^2) + sparse outliers."""
     device = gt.device
     g = _gen(seed, device)
@@ -146,9 +150,9 @@ def perturb(gt: torch.Tensor, seed: int = 101, noise_std: float = 0.02, drift: f
     m = p.shape[0]
     # low-frequency drift field
     ph = 0.013
-    dx = drift * torch.sin(p[:, 1] * ph + 0.3) * torch.cos(p[:, 2] * 0.05)
-    dy = drift * torch.sin(p[:, 0] * ph * 1.3 + 1.1)
-    dz = 0.5 * drift * torch.cos(p[:, 0] * ph * 0.7 + p[:, 1] * ph * 0.9)
+    dx = drift * torch.sin(p[:, 1] * ph + 0.3 + phase) * torch.cos(p[:, 2] * 0.05)
+    dy = drift * torch.sin(p[:, 0] * ph * 1.3 + 1.1 + 2.0 * phase)
+    dz = 0.5 * drift * torch.cos(p[:, 0] * ph * 0.7 + p[:, 1] * ph * 0.9 + 0.5 * phase)
     p = p + torch.stack([dx, dy, dz], dim=1)
     p = p + _randn((m, 3), g, device, noise_std)
     out = _rand(m, g, device) < outlier_ratio
@@ -159,6 +163,47 @@ def perturb(gt: torch.Tensor, seed: int = 101, noise_std: float = 0.02, drift: f
 def campus_pair(n: int, density: float = 2500.0, seed: int = 100, device="cpu", origin=(0.0, 0.0, 0.0), **kw):
     gt = campus_scene(n, density, seed, device, origin)
     est = perturb(gt, seed + 1, **kw)
+    return est, gt
+
+
+def _scan(n_out: int, n_ref: int, density: float, seed: int, sample_seed: int, device, origin, oversample: float, **kw):
+    """One independent scan of the `seed` scene (the geometry of campus_scene(n_ref, density, seed)), perturbed, cut to
+    exactly n_out points (the perturbation thins ~15 %, hence the oversampling)."""
+    n_raw = int(n_out * oversample)
+    raw = campus_scene(n_raw, density * n_raw / n_ref, seed, device, origin, sample_seed=sample_seed)
+    est = perturb(raw, sample_seed + 1, **kw)
+    del raw
+    if est.shape[0] < n_out:
+        raise ValueError("oversampling factor too small for the requested point count")
+    return est[:n_out].contiguous()  # (campus_scene shuffles, so a prefix is a uniform subsample)
+
+
+def scan_pair(n: int, density: float = 2500.0, seed: int = 100, device="cpu", origin=(0.0, 0.0, 0.0), n_est=None, **kw):
+    """Map pair with EQUAL sizes (BASELINE.json: "50 M vs 50 M"): the ground truth is campus_scene(n), the estimated map an
+    independent scan of the same scene (its own sample points, not noisy copies of the ground-truth points) with drift,
+    noise, outliers and region-wise thinning, cut to exactly n_est (default n) points."""
+    gt = campus_scene(n, density, seed, device, origin)
+    est = _scan(n if n_est is None else n_est, n, density, seed, seed + 1000, device, origin, 1.5, **kw)
+    return est, gt
+
+
+def multisession_pair(n: int, sessions: int = 3, density: float = 2500.0, seed: int = 100, device="cpu", origin=(0.0, 0.0, 0.0)):
+    """C4 ("MS-Dataset multi-session map vs GT"): the estimated map is the union of `sessions` independent
+    scans of the scene, each with its own drift field (amplitude and phase), noise level and thinning pattern; n points
+    in total, shuffled."""
+    gt = campus_scene(n, density, seed, device, origin)
+    parts = []
+    left = n
+    for k in range(sessions):
+        m = left // (sessions - k)
+        left -= m
+        p = _scan(m, n, density, seed, seed + 2000 + 17 * k, device, origin, 1.5,
+                  noise_std=0.015 + 0.005 * k, drift=0.03 + 0.02 * k, region_size=8.0 + 3.0 * k, phase=0.9 * k)
+        parts.append(p)
+    est = torch.cat(parts, 0)
+    del parts
+    g = _gen(seed + 2999, device)
+    est = est[torch.randperm(est.shape[0], generator=g, device=device)].contiguous()
     return est, gt
 
 

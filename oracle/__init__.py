@@ -74,6 +74,10 @@ def lib():
         ip = C.POINTER(C.c_int32)
         L.orc_kdtree_build.restype = C.c_void_p
         L.orc_kdtree_build.argtypes = [dp, C.c_int64]
+        L.orc_kdtree_build_mt.restype = C.c_void_p
+        L.orc_kdtree_build_mt.argtypes = [dp, C.c_int64, C.c_int]
+        L.orc_mme_points.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_double, C.c_int, dp,
+                                     C.POINTER(C.c_uint8), C.c_int]
         L.orc_kdtree_free.argtypes = [C.c_void_p]
         L.orc_kdtree_nn1.argtypes = [C.c_void_p, dp, C.c_int64, ip, dp, C.c_int]
         L.orc_kdtree_radius_count.argtypes = [C.c_void_p, dp, C.c_int64, C.c_double, ip, C.c_int]
@@ -127,6 +131,45 @@ def _dp(a):
 
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class KDTree:
+    """A KD-tree kept alive across calls (KDTreeFlann::SetGeometry once, many searches): what the full-size parity tests
+    and the CPU baseline use to query a 1 % subsample against the FULL tree.  build_threads = 1 is the reference's serial
+    build; 0 = all cores (same tree, test infrastructure)."""
+
+    def __init__(self, xyz, build_threads: int = 1):
+        self.xyz = _pts(xyz)  # the tree points at this buffer
+        self._t = lib().orc_kdtree_build_mt(_dp(self.xyz), self.xyz.shape[0], int(build_threads))
+
+    def close(self):
+        if getattr(self, "_t", None):
+            lib().orc_kdtree_free(self._t)
+            self._t = None
+
+    __del__ = close
+
+    def nn1(self, query, threads: int = 0):
+        query = _pts(query)
+        idx = np.empty(query.shape[0], np.int32)
+        d2 = np.empty(query.shape[0], np.float64)
+        lib().orc_kdtree_nn1(self._t, _dp(query), query.shape[0], _ip(idx), _dp(d2), threads)
+        return idx, d2
+
+    def radius_count(self, query, r: float, threads: int = 0):
+        query = _pts(query)
+        cnt = np.empty(query.shape[0], np.int32)
+        lib().orc_kdtree_radius_count(self._t, _dp(query), query.shape[0], float(r), _ip(cnt), threads)
+        return cnt
+
+    def mme_points(self, sel, radius: float, min_k: int, threads: int = 0):
+        """MME body (map_eval.cpp:1666-1701) for the tree's own points sel -> (entropies[m], valid[m] uint8)."""
+        sel = np.ascontiguousarray(sel, dtype=np.int64)
+        ent = np.zeros(sel.shape[0], np.float64)
+        val = np.zeros(sel.shape[0], np.uint8)
+        lib().orc_mme_points(self._t, sel.ctypes.data_as(C.POINTER(C.c_int64)), sel.shape[0], float(radius), int(min_k),
+                             _dp(ent), val.ctypes.data_as(C.POINTER(C.c_uint8)), threads)
+        return ent, val
 
 
 def nn1(ref, query, threads: int = 0):

@@ -7,6 +7,8 @@
 #include "mapeval_oracle.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -47,13 +49,20 @@ struct orc_kdtree {
     const double *pts = nullptr;
     int64_t n = 0;
     std::vector<int32_t> vind;
-    std::vector<Node> nodes;
+    // Nodes live in one malloc'ed array of 2n records handed out through an atomic counter (a binary tree over n points has
+    // at most 2n - 1 nodes; untouched pages are never committed), so that sub-trees can be built by concurrent OpenMP tasks.
+    // The tree SHAPE does not depend on the thread count (every split looks at its own point range only); only the
+    // numbering of the nodes does, and no result depends on that.
+    Node *nodes = nullptr;
+    std::atomic<int64_t> n_nodes{0};
     double bb_lo[3], bb_hi[3];
     int32_t root = -1;
+    int64_t task_cutoff = 0;  // sub-trees above this size are split into OpenMP tasks (0 = serial build)
+    ~orc_kdtree() { std::free(nodes); }
 
     int32_t build(int32_t left, int32_t right, double lo[3], double hi[3]) {
-        const int32_t id = (int32_t) nodes.size();
-        nodes.emplace_back();
+        const int32_t id = (int32_t) n_nodes.fetch_add(1, std::memory_order_relaxed);
+        nodes[id] = Node();
         if (right - left <= kLeafMax) {
             nodes[id].left = left;
             nodes[id].right = right;
@@ -129,8 +138,17 @@ struct orc_kdtree {
         double lo2[3] = {lo[0], lo[1], lo[2]}, hi2[3] = {hi[0], hi[1], hi[2]};
         hi1[cut] = cutval;
         lo2[cut] = cutval;
-        const int32_t c1 = build(left, idx, lo1, hi1);
-        const int32_t c2 = build(idx, right, lo2, hi2);
+        int32_t c1, c2;
+        if (task_cutoff > 0 && right - left > task_cutoff) {
+#pragma omp task shared(c1, lo1, hi1) default(shared)
+            c1 = build(left, idx, lo1, hi1);
+#pragma omp task shared(c2, lo2, hi2) default(shared)
+            c2 = build(idx, right, lo2, hi2);
+#pragma omp taskwait
+        } else {
+            c1 = build(left, idx, lo1, hi1);
+            c2 = build(idx, right, lo2, hi2);
+        }
         nodes[id].child1 = c1;
         nodes[id].child2 = c2;
         nodes[id].divfeat = cut;
@@ -533,7 +551,9 @@ struct orc_voxelmap {
 
 extern "C" {
 
-orc_kdtree *orc_kdtree_build(const double *xyz, int64_t n) {
+orc_kdtree *orc_kdtree_build_mt(const double *xyz, int64_t n, int threads) {
+    // threads == 1: the reference's single-threaded SetGeometry (map_eval.cpp:1214 ...); otherwise the same tree built
+    // by OpenMP tasks (test infrastructure for the 20 M / 50 M-point parity checks and the "all-parallel" CPU timing)
     auto *t = new orc_kdtree();
     t->pts = xyz;
     t->n = n;
@@ -549,12 +569,22 @@ orc_kdtree *orc_kdtree_build(const double *xyz, int64_t n) {
             t->bb_lo[d] = mn;
             t->bb_hi[d] = mx;
         }
-        t->nodes.reserve((size_t) (n / 4 + 16));
+        t->nodes = static_cast<Node *>(std::malloc((size_t) (2 * n + 2) * sizeof(Node)));
         double lo[3] = {t->bb_lo[0], t->bb_lo[1], t->bb_lo[2]}, hi[3] = {t->bb_hi[0], t->bb_hi[1], t->bb_hi[2]};
-        t->root = t->build(0, (int32_t) n, lo, hi);
+        const int nt = resolve_threads(threads);
+        if (nt > 1 && n > 100000) {
+            t->task_cutoff = std::max<int64_t>(20000, n / (64 * (int64_t) nt));
+#pragma omp parallel num_threads(nt)
+#pragma omp single
+            t->root = t->build(0, (int32_t) n, lo, hi);
+        } else {
+            t->root = t->build(0, (int32_t) n, lo, hi);
+        }
     }
     return t;
 }
+
+orc_kdtree *orc_kdtree_build(const double *xyz, int64_t n) { return orc_kdtree_build_mt(xyz, n, 1); }
 
 void orc_kdtree_free(orc_kdtree *t) { delete t; }
 
@@ -746,6 +776,26 @@ double orc_mme(const double *xyz, int64_t n, double radius, int min_k, double *e
     if (n_valid) *n_valid = count;
     if (sum_entropy) *sum_entropy = sum;
     return count > 0 ? sum / (double) count : 0.0;  // (:1720-1724)
+}
+
+void orc_mme_points(const orc_kdtree *tree, const int64_t *sel, int64_t m, double radius, int min_k, double *entropies,
+                    uint8_t *valid, int threads) {
+    // the per-point body of ComputeMeanMapEntropy* (map_eval.cpp:1666-1701) for the points sel[0..m) of the tree's own
+    // cloud, against the FULL tree: entropies[j] (0.0 where invalid) and valid[j] for j < m
+    const double r2 = radius * radius;
+    const int nt = resolve_threads(threads);
+#pragma omp parallel num_threads(nt)
+    {
+        std::vector<std::pair<double, int32_t>> nb;
+        nb.reserve(100);
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t j = 0; j < m; ++j) {
+            double H = 0.0;
+            const bool ok = mme_point(*tree, sel[j], r2, min_k, nb, H);
+            entropies[j] = ok ? H : 0.0;
+            valid[j] = ok ? 1 : 0;
+        }
+    }
 }
 
 orc_voxelmap *orc_voxel_build(const double *xyz, int64_t n, double voxel_size) {

@@ -51,6 +51,9 @@ typedef struct orc_reg_stats {
 
 /* ---- KD-tree (map_eval.cpp:1213-1214 SetGeometry; :1218 SearchKNN; :1670 SearchRadius) ---- */
 orc_kdtree *orc_kdtree_build(const double *xyz, int64_t n);
+/* The same tree built by `threads` OpenMP tasks (0 = all cores; 1 = orc_kdtree_build).  The reference builds serially;
+ * this exists so that the parity tests can afford the FULL 20 M / 50 M-point trees, and for the "all-parallel" CPU timing. */
+orc_kdtree *orc_kdtree_build_mt(const double *xyz, int64_t n, int threads);
 void orc_kdtree_free(orc_kdtree *t);
 /* 1-NN for m queries; idx/d2 may be NULL. threads 1 -> serial (as :1215), 0 -> all cores, n -> n (OpenMP, as :1411). */
 void orc_kdtree_nn1(const orc_kdtree *t, const double *q, int64_t m, int32_t *idx, double *d2, int threads);
@@ -79,6 +82,12 @@ double orc_chamfer(const double *a, int64_t na, const double *b, int64_t nb, int
  * entropies[N] (0.0 where invalid) and valid[N] may be NULL. Returns mean entropy (0 if none valid). */
 double orc_mme(const double *xyz, int64_t n, double radius, int min_k, double *entropies, uint8_t *valid,
                int64_t *n_valid, double *sum_entropy, int mode, int threads);
+
+/* The per-point body of the MME loops (map_eval.cpp:1666-1701) for the points sel[0..m) of the tree's OWN cloud against the
+ * full tree: entropies[m] (0.0 where invalid), valid[m].  What the full-size parity tests and the bench's CPU baseline
+ * (1 % query subsample against the full-size tree) call. */
+void orc_mme_points(const orc_kdtree *tree, const int64_t *sel, int64_t m, double radius, int min_k, double *entropies,
+                    uint8_t *valid, int threads);
 
 /* ---- Voxel Gaussians (voxel_calculator.cpp:21-56, :97-113, :241-245) ---- */
 orc_voxelmap *orc_voxel_build(const double *xyz, int64_t n, double voxel_size);
