@@ -1,21 +1,32 @@
 #!/usr/bin/env python
-"""bench.py — BASELINE.json metric: Mpts/s for the full metric suite (AC/COM/CD + MME + AWD/SCS) on a map pair.
+"""bench.py — BASELINE.json metric: Mpts/s for the full metric suite (AC/COM/CD + MME + AWD/SCS) on a 50 M vs 50 M map pair.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run,
 one rank per GPU over RCCL.  One "step" = one pass of the whole hot path over the synthetic pair, starting from the
 two clouds RESIDENT IN HBM (raw, unsorted fp64 AoS) and ending with every scalar on the host: Morton sort + index
 build, both 1-NN passes + AC/COM/CD statistics, est-MME (+ GT-MME), voxel Gaussians, AWD, CDF sort, SCS.
-Strong scaling (N > 1): every rank sees the pair but keeps, sorts, indexes and searches only its spatial slab (+ halo) of
-both clouds (cloud_map_evaluation_amd/dist.py::suite_step_slab); queries whose nearest neighbour may live on another
-rank are resolved with one all-gather + min-reduce, partial sums are all-reduced, voxel partials all-gathered (RCCL);
-value = (N_est + N_gt) / max-over-ranks step time.
+`value` = (N_est + N_gt) / step time of that span.  SURVEY.md 8(d) defines the span from HOST memory; the same steps timed from
+pinned host buffers (PCIe included) are reported next to it as `h2d_inclusive` — never as `value`.
 
-Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed inside this process) and
-"cpu_baseline" (the CPU oracle = port of the reference's CPU path, timed on this box's host cores on a bounded sample).
+Workloads (--workload; all synthetic, seeded, equal-size clouds):
+  c4_multisession (default)  50 M vs 50 M, est = union of three independent scans with their own drifts     (configs[3])
+  campus                     50 M vs 50 M, est = one independent scan (drift + noise + outliers + thinning)
+  c3_20m                     20 M vs 20 M, full suite                                                          (configs[2])
+  c5_tunnel                  100 M-point ground truth: tunnel + flat field + staircase, vmd_voxel_size 2.0     (configs[4])
+--points / --density / --nn-radius / --voxel override the workload's values.
+
+Multi-GPU (N > 1, strong scaling of the same pair): every rank holds 1/N of each cloud (as if each had read its part of
+the files); one all-to-all moves every point to the rank that owns its slab or needs it as halo, then each rank sorts,
+indexes and searches only that (cloud_map_evaluation_amd/dist.py::suite_step_dist).
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed inside this process), "h2d_inclusive", and
+"cpu_baseline" (the CPU oracle = port of the reference's CPU path, on this box's host cores: full-size KD-trees, 1 % query
+subsample, best of 3 — BASELINE.md section 3).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,62 +42,174 @@ BYTES_PER_NN_QUERY = 60.0   # 24 B query + 24 B reference point + 12 B result (M
 BYTES_PER_MME_QUERY = 33.0  # 24 B point + 8 B entropy + 1 B valid
 OVERLAP = True  # --no-overlap switches the second lane off (the per-kernel timing pass always runs without it)
 
+WORKLOADS = {
+    "c4_multisession": dict(points=50_000_000, density=2500.0, radius=0.1, voxel=3.0,
+                            what="multisession_pair: GT campus scene, est = union of 3 independent scans with their own drifts"),
+    "campus": dict(points=50_000_000, density=2500.0, radius=0.1, voxel=3.0,
+                   what="scan_pair: GT campus scene, est = one independent scan (drift, noise, outliers, thinning)"),
+    "c3_20m": dict(points=20_000_000, density=2500.0, radius=0.1, voxel=3.0, what="scan_pair at 20 M"),
+    "c5_tunnel": dict(points=100_000_000, density=2500.0, radius=0.1, voxel=2.0,
+                      what="tunnel_pair: tunnel + flat field + staircase (degenerate voxel covariances), est = perturbed GT"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--points", type=int, default=50_000_000, help="GT points (est is ~15 %% thinner)")
-    ap.add_argument("--density", type=float, default=2500.0, help="surface density, points / m^2")
-    ap.add_argument("--nn-radius", type=float, default=0.1)
-    ap.add_argument("--voxel", type=float, default=3.0)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c4_multisession")
+    ap.add_argument("--points", type=int, default=0, help="points per cloud (0 = the workload's size)")
+    ap.add_argument("--density", type=float, default=0.0, help="surface density, points / m^2 (0 = the workload's)")
+    ap.add_argument("--nn-radius", type=float, default=0.0)
+    ap.add_argument("--voxel", type=float, default=0.0)
     ap.add_argument("--no-gt-mme", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="GT points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-baseline", choices=("full", "sample", "off"), default="full",
+                    help="full: full-size KD-trees + 1 %% query subsample (BASELINE.md 3); sample: a 2 M-point pair; off")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="(compat) 0 = --cpu-baseline off")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive timing")
     ap.add_argument("--no-overlap", action="store_true", help="single lane: every stage back to back on one stream")
-    return ap.parse_args()
+    a = ap.parse_args()
+    w = WORKLOADS[a.workload]
+    a.points = a.points or w["points"]
+    a.density = a.density or w["density"]
+    a.nn_radius = a.nn_radius or w["radius"]
+    a.voxel = a.voxel or w["voxel"]
+    if a.cpu_sample == 0:
+        a.cpu_baseline = "off"
+    return a
 
 
-def suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme):
-    """One full pass; returns the scalars.  All ranks run it; per-point passes are slab-sharded, partial sums are
-    all-reduced over RCCL (cloud_map_evaluation_amd/dist.py)."""
+def make_pair(args, device):
+    from cloud_map_evaluation_amd import synth
+
+    if args.workload == "c4_multisession":
+        return synth.multisession_pair(args.points, 3, density=args.density, seed=100, device=device)
+    if args.workload == "c5_tunnel":
+        return synth.tunnel_pair(args.points, density=args.density, seed=300, device=device)
+    return synth.scan_pair(args.points, density=args.density, seed=100, device=device)
+
+
+def kernel_source_sha() -> str:
+    """Fingerprint of the kernel sources: committed rocprofv3 figures are only quoted when they were taken at this code."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "cloud_map_evaluation_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def suite_step(eng, dist, world, est_d, gt_d, P, evaluate_gt_mme):
+    """One full pass; returns the scalars.  All ranks run it (cloud_map_evaluation_amd/dist.py)."""
     import torch
 
     from cloud_map_evaluation_amd import dist as medist
 
     dev = torch.device("cuda", torch.cuda.current_device())
     if world > 1:
-        # spatial slabs: every rank sorts / indexes / searches only its slab (+ 1 m halo) of both clouds
-        return medist.suite_step_slab(eng, dist, dev, est_d, gt_d, P, dist.get_rank(), world, evaluate_gt_mme, halo=1.0,
-                                      overlap=OVERLAP)
+        # est_d / gt_d are this rank's 1/N of the clouds: slabs + one all-to-all halo exchange
+        return medist.suite_step_dist(eng, dist, dev, est_d, gt_d, P, dist.get_rank(), world, evaluate_gt_mme, halo=1.0)
     # single GPU: the HBM-bound stages (index of the ground truth, both voxel tables) run on the engine's second lane
     # under the VALU-bound MME / 1-NN kernels (dist._Lane); same calls, same results
     return medist.suite_step(eng, None, dev, est_d, gt_d, P, evaluate_gt_mme, overlap=OVERLAP)
 
 
-def cpu_baseline(args, P, evaluate_gt_mme):
-    """The oracle (port of the reference CPU path, same parallel structure: OpenMP CD, block-range MME, serial
-    AC/COM loops, serial GT-MME, serial voxel build) on a bounded sample of the same scene generator."""
+def _best_of(fn, reps=3):
+    best = float("inf")
+    out = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        best = min(best, time.perf_counter() - t0)
+    return best, out
+
+
+def cpu_baseline_full(est, gt, P, evaluate_gt_mme, frac=0.01):
+    """BASELINE.md section 3.  The oracle (port of the reference's CPU path) on THIS workload's clouds: KD-trees over the FULL
+    clouds, a seeded `frac` subsample of the queries of every per-point loop, each loop best of 3, extrapolated to all
+    queries.  Two totals over the same span as the GPU step (clouds in host memory -> scalars):
+      value         the reference's own parallel structure: serial SetGeometry, 6 tree builds (MME est, MME gt, AC/COM x2,
+                    CD x2: map_eval.cpp:1619,1449,1214,1227,1401-1402), TBB-like parallel est-MME (:1717), SERIAL gt-MME
+                    (:1451), SERIAL AC/COM loops (:1215,:1228), OpenMP CD loops (:1411,:1420), serial voxel build
+                    (voxel_calculator.cpp:25);
+      all_parallel  every loop and every tree build on all cores (the fair upper end).
+    Tree builds and the voxel build are timed once (a 50 M-point serial build takes tens of seconds)."""
+    import numpy as np
+
+    import oracle
+
+    cores = os.cpu_count() or 1
+    n_e, n_g = len(est), len(gt)
+    rng = np.random.default_rng(7)
+    sel_e = np.sort(rng.choice(n_e, max(1, int(n_e * frac)), replace=False))
+    sel_g = np.sort(rng.choice(n_g, max(1, int(n_g * frac)), replace=False))
+    t = {}
+    t0 = time.perf_counter(); te = oracle.KDTree(est, 1); t["build_est_serial"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); tg = oracle.KDTree(gt, 1); t["build_gt_serial"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); tp = oracle.KDTree(est, 0); t["build_est_parallel"] = time.perf_counter() - t0
+    tp.close()
+    t0 = time.perf_counter(); tp = oracle.KDTree(gt, 0); t["build_gt_parallel"] = time.perf_counter() - t0
+    tp.close()
+    sc_e, sc_g = n_e / len(sel_e), n_g / len(sel_g)
+    r = P.nn_radius_
+    # per-point loops on the subsample (seconds for the subsample; scaled below)
+    t["mme_est_par"] = _best_of(lambda: te.mme_points(sel_e, r, 10, threads=0))[0] * sc_e
+    t["mme_gt_par"] = _best_of(lambda: tg.mme_points(sel_g, r, 5, threads=0))[0] * sc_g
+    t["mme_gt_serial"] = _best_of(lambda: tg.mme_points(sel_g[::8], r, 5, threads=1), 1)[0] * sc_g * 8
+    qe, qg = est[sel_e], gt[sel_g]
+    t["nn_est_gt_par"] = _best_of(lambda: tg.nn1(qe, threads=0))[0] * sc_e
+    t["nn_gt_est_par"] = _best_of(lambda: te.nn1(qg, threads=0))[0] * sc_g
+    t["nn_est_gt_serial"] = _best_of(lambda: tg.nn1(qe[::4], threads=1), 1)[0] * sc_e * 4
+    t["nn_gt_est_serial"] = _best_of(lambda: te.nn1(qg[::4], threads=1), 1)[0] * sc_g * 4
+    te.close()
+    tg.close()
+    # voxel build: serial hash insert + Welford per point; a prefix of the (shuffled) cloud touches the same voxels, so the
+    # per-point cost is that of the whole cloud
+    m = max(1, int(n_g * 0.04))
+    t0 = time.perf_counter()
+    vg, ve = oracle.VoxelMap(gt[:m], P.vmd_voxel_size_), oracle.VoxelMap(est[:m], P.vmd_voxel_size_)
+    t["voxel_serial"] = (time.perf_counter() - t0) * (n_g + n_e) / (2.0 * m)
+    t0 = time.perf_counter(); oracle.awd_scs(vg, ve); t["awd_scs"] = time.perf_counter() - t0
+    gt_mme = 1.0 if evaluate_gt_mme else 0.0
+    ref = ((3 if evaluate_gt_mme else 2) * t["build_gt_serial"] + 3 * t["build_est_serial"]  # est: MME, AC, CD; gt: (MME), AC, CD
+           + t["mme_est_par"] + gt_mme * t["mme_gt_serial"]
+           + t["nn_est_gt_serial"] + t["nn_gt_est_serial"]      # AC / COM loops (serial in the reference)
+           + t["nn_est_gt_par"] + t["nn_gt_est_par"]            # CD loops (OpenMP)
+           + t["voxel_serial"] + t["awd_scs"])
+    par = ((3 if evaluate_gt_mme else 2) * t["build_gt_parallel"] + 3 * t["build_est_parallel"]
+           + t["mme_est_par"] + gt_mme * t["mme_gt_par"] + 2 * (t["nn_est_gt_par"] + t["nn_gt_est_par"])
+           + t["voxel_serial"] + t["awd_scs"])  # (the voxel hash build has no parallel form in the reference)
+    n = n_e + n_g
+    return {"value": n / 1e6 / ref, "unit": "Mpts/s", "cores": cores, "kind": "port",
+            "sample": f"this workload's clouds ({n_g} + {n_e} pts): full-size KD-trees, {frac:.0%} seeded query subsample of every "
+                      f"per-point loop (best of 3, extrapolated x{sc_e:.0f}), tree builds timed once, voxel build on a 4 % prefix; "
+                      "reference parallel structure (serial builds x6, serial AC/COM and GT-MME loops, parallel est-MME and CD)",
+            "extrapolated_suite_seconds": ref,
+            "all_parallel": {"value": n / 1e6 / par, "unit": "Mpts/s", "extrapolated_suite_seconds": par,
+                             "note": "every tree build and every per-point loop on all cores"},
+            "seconds": {k: round(v, 3) for k, v in t.items()}}
+
+
+def cpu_baseline_sample(args, P, evaluate_gt_mme, n=2_000_000):
+    """Quick variant: the oracle end to end on a small pair of the same generator (trees are NOT full size)."""
     import oracle
     from cloud_map_evaluation_amd import synth
 
-    est, gt = synth.campus_pair(args.cpu_sample, density=args.density, seed=100)
+    est, gt = synth.scan_pair(n, density=args.density, seed=100)
     est, gt = est.numpy(), gt.numpy()
-    cores = os.cpu_count() or 1
     t0 = time.perf_counter()
-    oracle.mme(est, P.nn_radius_, 10, mode=2, threads=0)                       # TBB-like (map_eval.cpp:1717)
+    oracle.mme(est, P.nn_radius_, 10, mode=2, threads=0)
     if evaluate_gt_mme:
-        oracle.mme(gt, P.nn_radius_, 5, mode=0, threads=1)                     # serial (map_eval.cpp:1451)
-    oracle.reg_stats(est, gt, P.icp_max_distance_, 0, P.trunc_dist_, threads=1)  # serial (map_eval.cpp:1215)
-    oracle.reg_stats(gt, est, P.icp_max_distance_, 0, P.trunc_dist_, threads=1)  # serial (map_eval.cpp:1228)
-    oracle.chamfer(est, gt, threads=0)                                         # OpenMP (map_eval.cpp:1411)
-    g, e = oracle.VoxelMap(gt, P.vmd_voxel_size_), oracle.VoxelMap(est, P.vmd_voxel_size_)  # serial (voxel_calculator.cpp:25)
-    oracle.awd_scs(g, e)
+        oracle.mme(gt, P.nn_radius_, 5, mode=0, threads=1)
+    oracle.reg_stats(est, gt, P.icp_max_distance_, 0, P.trunc_dist_, threads=1)
+    oracle.reg_stats(gt, est, P.icp_max_distance_, 0, P.trunc_dist_, threads=1)
+    oracle.chamfer(est, gt, threads=0)
+    oracle.awd_scs(oracle.VoxelMap(gt, P.vmd_voxel_size_), oracle.VoxelMap(est, P.vmd_voxel_size_))
     dt = time.perf_counter() - t0
-    n = len(est) + len(gt)
-    return {"value": n / 1e6 / dt, "unit": "Mpts/s", "cores": cores, "kind": "port",
-            "sample": f"campus_pair GT={len(gt)} est={len(est)} pts, same density/radius/voxel, full suite, {dt:.1f} s wall"}
+    return {"value": 2 * n / 1e6 / dt, "unit": "Mpts/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": f"scan_pair {n} + {n} pts end to end (small trees), reference parallel structure, {dt:.1f} s wall"}
 
 
 def main():
@@ -110,16 +233,25 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from cloud_map_evaluation_amd import synth
     from cloud_map_evaluation_amd.engine import Engine, Param
 
     evaluate_gt_mme = not args.no_gt_mme
     P = Param(icp_max_distance_=1.0, nn_radius_=args.nn_radius, vmd_voxel_size_=args.voxel,
               evaluate_gt_mme_=evaluate_gt_mme)
     # synthetic, seeded, generated directly in HBM (identical on every rank)
-    est_d, gt_d = synth.campus_pair(args.points, density=args.density, seed=100, device=dev)
+    est_d, gt_d = make_pair(args, dev)
     n_e, n_g = est_d.shape[0], gt_d.shape[0]
+    if world > 1:
+        # distributed input: rank r holds the r-th of `world` contiguous pieces of each (shuffled) cloud, as if it had read
+        # its part of the files; the rest is dropped before the timed region
+        from cloud_map_evaluation_amd.dist import shard_range
+
+        b, e = shard_range(n_e, rank, world)
+        est_d = est_d[b:e].clone()
+        b, e = shard_range(n_g, rank, world)
+        gt_d = gt_d[b:e].clone()
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
 
     eng = Engine(local_rank)
 
@@ -129,35 +261,39 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    res = None
-    for _ in range(args.warmup):
-        res = suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / max(1, args.steps) * 1e3
+    def timed(est, gt, steps, warmup):
+        res = None
+        for _ in range(warmup):
+            res = suite_step(eng, dist, world, est, gt, P, evaluate_gt_mme)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = suite_step(eng, dist, world, est, gt, P, evaluate_gt_mme)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / max(1, steps) * 1e3, res
+
+    ms_per_step, res = timed(est_d, gt_d, args.steps, args.warmup)
     value = (n_e + n_g) / 1e6 / (ms_per_step / 1e3)
 
+    w = WORKLOADS[args.workload]
     line = {
         "metric": "Mpts/sec full metric suite (CD+MME+AWD) on 50M-pt pair",
         "value": value, "unit": "Mpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"campus_pair GT={n_g} est={n_e} pts @ {args.density:g} pts/m^2 (seed 100): AC/COM/CD + "
+        "config": {"workload": f"{args.workload}: {w['what']}; GT={n_g} est={n_e} pts @ {args.density:g} pts/m^2 (seeded): AC/COM/CD + "
                                f"est-MME{'+GT-MME' if evaluate_gt_mme else ''} (r={args.nn_radius}) + voxel Gaussians/AWD/CDF/SCS "
                                f"(voxel={args.voxel}), clouds resident in HBM, index build included",
-                   "n_est": n_e, "n_gt": n_g, "nn_radius": args.nn_radius, "vmd_voxel_size": args.voxel,
+                   "n_est": n_e, "n_gt": n_g, "nn_radius": args.nn_radius, "vmd_voxel_size": args.voxel, "density": args.density,
                    "parallelism": ("single GPU" if world == 1 else
-                                   f"spatial slabs x{world} along the longest axis (+1 m halo): each rank sorts/indexes/searches "
-                                   "1/N of both clouds; cross-rank 1-NN resolve (all-gather + min-reduce), all-reduced partial "
-                                   "sums, all-gathered voxel partials (RCCL)")},
+                                   f"distributed input (1/{world} of each cloud per rank), spatial slabs x{world} along the longest axis "
+                                   "(+1 m halo) filled by one all-to-all halo exchange; cross-rank 1-NN resolve (all-gather + "
+                                   "min-reduce), all-reduced partial sums, all-gathered voxel partials merged on the device (RCCL)")},
         "results": {"AC": [float(x) for x in res["ac"]], "COM": [float(x) for x in res["com"]], "CD": float(res["cd"]),
                     "MME_est": float(res["mme_est"]), "MME_gt": float(res["mme_gt"]), "AWD": float(res["awd"]),
                     "SCS": float(res["scs"]), "W_voxels": int(res["n_w"]), "MME_valid": res["mme_valid"]},
@@ -168,10 +304,11 @@ def main():
         eng.timers_enable(True)
         eng.timers_reset()
         OVERLAP = False  # kernels timed one at a time
-        suite_step(eng, dist, world, est_d, gt_d, P, n_e, n_g, evaluate_gt_mme)
+        suite_step(eng, dist, world, est_d, gt_d, P, evaluate_gt_mme)
+        OVERLAP = not args.no_overlap
         fam = {}
         for name in ("nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "slab_filter", "voxel",
-                     "w2", "scs"):
+                     "w2", "scs", "halo_pack"):
             ms, cnt = eng.timer(name)
             if cnt:
                 fam[name] = (ms, cnt)
@@ -193,29 +330,22 @@ def main():
                 units = (n_e + n_g) / cnt
                 alg_bytes = 24.0 * units
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-            traffic = None
+            # HBM bytes per launch from the rocprofv3 PMC passes (profiles/run_profile.sh, separate --pmc runs of this very
+            # command): quoted only when they were collected at THIS kernel source and workload, otherwise null
+            traffic, traffic_src = None, None
+            sha = kernel_source_sha()
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(dom)
+                    tj = json.load(open(tpath))
+                    if tj.get("_kernel_source_sha") == sha and tj.get("_workload") == args.workload and tj.get("_points") == args.points:
+                        traffic = tj.get(dom)
+                        traffic_src = {"file": "profiles/traffic.json", "kernel_source_sha": sha, "collected": tj.get("_tag")}
                 except Exception:
                     traffic = None
-            # What actually limits the kernel (reported next to the contractual HBM figure, not instead of it): fp64
-            # VALU issue.  Instructions per wavefront come from the committed rocprofv3 SQ pass (same scene density),
-            # the launch time is measured live; 256 CUs x 4 SIMDs, one VALU instruction per SIMD per 4 cycles, 2.4 GHz.
-            valu = None
-            spath = os.path.join(ROOT, "profiles", "r01_sq_per_wave.json")
-            if os.path.exists(spath) and dom in ("mme", "nn_grid"):
-                try:
-                    per_wave = json.load(open(spath))[f"me::k_{dom}"]["SQ_INSTS_VALU"]
-                    issue_cycles = per_wave * (units / 64.0) * 4.0
-                    valu = {"valu_insts_per_wave": per_wave, "frac_of_valu_issue_peak":
-                            issue_cycles / (avg_ms * 1e-3 * 2.4e9 * 1024.0), "source": "profiles/r01_sq_per_wave.json"}
-                except Exception:
-                    valu = None
-            line["roofline"] = {"bound": "hbm", "kernel": dom, "valu_issue": valu, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
-                                "units_per_launch": units, "algorithmic_bytes_per_launch": alg_bytes,
+            line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                                "avg_launch_ms": avg_ms, "units_per_launch": units, "algorithmic_bytes_per_launch": alg_bytes,
                                 "kernel_ms_per_step": {k: v[0] for k, v in fam.items()},
                                 "nn_fallback_fraction": (nn_fallback / nn_total) if nn_total else None,
                                 "queries_per_s": {"nn": (n_e + n_g) * shard / ((fam.get("nn1", (0, 0))[0] + fam.get("nn_grid", (0, 0))[0]) * 1e-3)
@@ -223,8 +353,28 @@ def main():
                                                   "mme": (n_e + (n_g if evaluate_gt_mme else 0)) * shard / (fam["mme"][0] * 1e-3)
                                                   if "mme" in fam else None}}
 
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        line["cpu_baseline"] = cpu_baseline(args, P, evaluate_gt_mme)
+    # ---- the same step from pinned HOST buffers (SURVEY.md 8d span: H2D included) ----
+    est_h = gt_h = None
+    need_host = world == 1 and rank == 0 and (not args.no_h2d or args.cpu_baseline == "full")
+    if need_host:
+        est_h, gt_h = est_d.cpu(), gt_d.cpu()
+    if world == 1 and not args.no_h2d:
+        est_p, gt_p = est_h.pin_memory(), gt_h.pin_memory()
+        h_ms, h_res = timed(est_p, gt_p, max(2, min(3, args.steps)), 1)
+        line["h2d_inclusive"] = {"ms_per_step": h_ms, "value": (n_e + n_g) / 1e6 / (h_ms / 1e3), "unit": "Mpts/s",
+                                 "note": "same step with both clouds starting in pinned host memory (2 x 24 B/pt over PCIe Gen5, "
+                                         "uploads of the two clouds on the two lanes) and every scalar back on the host",
+                                 "bytes_h2d": 24 * (n_e + n_g),
+                                 "same_results": bool(h_res["mme_valid"] == res["mme_valid"] and h_res["cd"] == res["cd"])}
+        del est_p, gt_p
+
+    if rank == 0 and world == 1 and args.cpu_baseline != "off":
+        del est_d, gt_d
+        torch.cuda.empty_cache()
+        if args.cpu_baseline == "full":
+            line["cpu_baseline"] = cpu_baseline_full(est_h.numpy(), gt_h.numpy(), P, evaluate_gt_mme)
+        else:
+            line["cpu_baseline"] = cpu_baseline_sample(args, P, evaluate_gt_mme)
 
     eng.close()
     if world > 1:

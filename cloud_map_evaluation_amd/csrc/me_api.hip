@@ -355,6 +355,34 @@ int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t co
     return me::nn_patch(ctx, query_slot, d2_device, count);
 }
 
+int me_transform_points_device(me_ctx *ctx, double *xyz_device, int64_t n, const double *T) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::transform_points_device(ctx, xyz_device, n, T);
+}
+
+int me_halo_pack_device(me_ctx *ctx, const double *xyz_device, int64_t n, int axis, const double *cuts, int world, double halo,
+                        double *out_device, int64_t capacity, int64_t *counts) {
+    if (!ctx) return ME_ERR_ARG;
+    long long c[64];
+    if (world < 1 || world > 64 || !counts) return ctx->fail(ME_ERR_ARG, "me_halo_pack_device: need 1 <= world <= 64 and counts");
+    const int rc = me::halo_pack(ctx, xyz_device, n, axis, cuts, world, halo, out_device, capacity, c);
+    for (int k = 0; k < world; ++k) counts[k] = c[k];
+    return rc;
+}
+
+int me_voxel_partial_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, int64_t capacity, int64_t *n_rows) {
+    if (!ctx) return ME_ERR_ARG;
+    long long n = 0;
+    const int rc = me::voxel_rows_device(ctx, slot, voxel_size, rows_device, capacity, &n);
+    if (n_rows) *n_rows = n;
+    return rc;
+}
+
+int me_voxel_merge_device(me_ctx *ctx, int slot, double voxel_size, const double *rows_device, int64_t n_rows) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::voxel_merge(ctx, slot, voxel_size, rows_device, n_rows);
+}
+
 int me_awd_scs(me_ctx *ctx, double voxel_size, int min_pts, int scs_radius, double *rows, double *w_sorted, int64_t *n_rows,
                double *awd, double *scs, int64_t counts[3]) {
     if (!ctx) return ME_ERR_ARG;

@@ -1,0 +1,305 @@
+// me_dist.hip — device-side pieces of the multi-GPU step (no reference counterpart: the reference is one process).
+//
+//   halo_pack          the send side of the one-shot halo exchange: every point of this rank's part of a cloud is copied
+//                      into the send segment of EVERY rank whose slab (+ halo) contains it — a deterministic multi-split,
+//                      destination-major, ready for one all_to_all.
+//   voxel_rows_device  this rank's voxel partials as rows on the device (what the all-gather carries).
+//   voxel_merge        Chan's parallel update of the gathered partials -> the cloud's voxel table exactly as
+//                      VoxelCalculator::buildVoxelMap leaves it (voxel_calculator.cpp:21-56), so that me_awd_scs runs on it.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "me_internal.hpp"
+
+namespace me {
+
+constexpr int kSplitPerLane = 32;  // a wavefront splits 64 x 32 = 2048 consecutive points
+constexpr int kSplitUnit = 64 * kSplitPerLane;
+constexpr int kMaxWorld = 64;      // one lane of the wavefront keeps the running count of one destination
+
+struct Cuts {
+    double lo[kMaxWorld], hi[kMaxWorld];  // [lo_k, hi_k) = slab k grown by the halo: the filter me_set_slab applies
+};
+
+// does destination k hold coordinate v?  (the expression of k_slab_flags: v >= reg_lo && v < reg_hi)
+__device__ __forceinline__ bool slab_holds(const Cuts &c, int k, double v) { return v >= c.lo[k] && v < c.hi[k]; }
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256)
+k_halo_split(const double *__restrict__ xyz, long long n, int axis, Cuts cuts, int world, long long n_units,
+             unsigned int *__restrict__ unit_counts /* [world][n_units] */, const unsigned int *__restrict__ unit_off,
+             double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long u = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= n_units) return;
+    // lane k keeps the running count (SCATTER: the running output position) of destination k
+    unsigned int mine = 0;
+    if (SCATTER && lane < world) mine = unit_off[(long long) lane * n_units + u];
+    for (int it = 0; it < kSplitPerLane; ++it) {
+        const long long i = u * kSplitUnit + (long long) it * 64 + lane;
+        const bool live = i < n;
+        double p[3] = {0, 0, 0};
+        if (live) {
+            p[0] = xyz[3 * i];
+            p[1] = xyz[3 * i + 1];
+            p[2] = xyz[3 * i + 2];
+        }
+        const double v = p[axis];
+        for (int k = 0; k < world; ++k) {
+            const bool member = live && slab_holds(cuts, k, v);
+            const unsigned long long m = __ballot(member);
+            if (!m) continue;
+            if (SCATTER) {
+                const unsigned int base = (unsigned int) __builtin_amdgcn_readlane((int) mine, k);
+                if (member) {
+                    const long long o = (long long) base + __popcll(m & ((1ULL << lane) - 1ULL));
+                    out[3 * o] = p[0];
+                    out[3 * o + 1] = p[1];
+                    out[3 * o + 2] = p[2];
+                }
+            }
+            if (lane == k) mine += (unsigned int) __popcll(m);
+        }
+    }
+    if (!SCATTER && lane < world) unit_counts[(long long) lane * n_units + u] = mine;
+}
+
+int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, const double *cuts_host, int world, double halo,
+              double *out_device, long long capacity, long long *counts_host) {
+    if (!xyz_device || n < 0 || axis < 0 || axis > 2 || !cuts_host || world < 1 || world > kMaxWorld || !(halo >= 0) || !counts_host)
+        return ctx->fail(ME_ERR_ARG, "me_halo_pack_device: bad argument (1 <= world <= 64)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    Cuts c{};
+    for (int k = 0; k < world; ++k) {
+        if (!(cuts_host[k] < cuts_host[k + 1])) return ctx->fail(ME_ERR_ARG, "me_halo_pack_device: cuts must be strictly ascending");
+        c.lo[k] = cuts_host[k] - halo;      // me_set_slab: reg_lo = lo - halo
+        c.hi[k] = cuts_host[k + 1] + halo;  //              reg_hi = hi + halo
+    }
+    for (int k = 0; k < world; ++k) counts_host[k] = 0;
+    if (n == 0) return ME_OK;
+    const long long n_units = (n + kSplitUnit - 1) / kSplitUnit;
+    const long long n_cnt = n_units * world;
+    DevBuf &cnt = ctx->tmp[0], &off = ctx->tmp[1];
+    ME_CHECK(ctx, cnt.ensure((size_t) n_cnt * 4));
+    ME_CHECK(ctx, off.ensure((size_t) n_cnt * 4));
+    const dim3 grid((unsigned int) ((n_units + 3) / 4));
+    TimerScope ts(ctx, "halo_pack");
+    hipLaunchKernelGGL(k_halo_split<false>, grid, dim3(256), 0, ctx->stream, xyz_device, n, axis, c, world, n_units,
+                       cnt.as<unsigned int>(), (const unsigned int *) nullptr, (double *) nullptr);
+    ME_TRY(exclusive_scan_u32(ctx, cnt.as<unsigned int>(), off.as<unsigned int>(), n_cnt));
+    // destination k's segment starts at off[k * n_units]; the total is off[last] + cnt[last]
+    std::vector<unsigned int> seg((size_t) world + 1);
+    for (int k = 0; k < world; ++k)
+        ME_CHECK(ctx, hipMemcpyAsync(&seg[k], off.as<unsigned int>() + (long long) k * n_units, 4, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned int last_cnt = 0;
+    ME_CHECK(ctx, hipMemcpyAsync(&seg[world], off.as<unsigned int>() + (n_cnt - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(&last_cnt, cnt.as<unsigned int>() + (n_cnt - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    seg[world] += last_cnt;
+    long long total = 0;
+    for (int k = 0; k < world; ++k) {
+        counts_host[k] = (long long) seg[k + 1] - (long long) seg[k];
+        total += counts_host[k];
+    }
+    if (!out_device) return ME_OK;  // counts only
+    if (capacity < total) return ctx->fail(ME_ERR_CAPACITY, "me_halo_pack_device: capacity too small (counts returned)");
+    hipLaunchKernelGGL(k_halo_split<true>, grid, dim3(256), 0, ctx->stream, xyz_device, n, axis, c, world, n_units,
+                       (unsigned int *) nullptr, off.as<unsigned int>(), out_device);
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_CHECK(ctx, hipGetLastError());
+    return ME_OK;
+}
+
+// ---- voxel partial rows: [kx, ky, kz, n, mu(3), M2(9)] = 16 doubles per voxel ----
+constexpr int kRow = 16;
+
+__device__ __forceinline__ void unpack3(unsigned long long k, int &kx, int &ky, int &kz) {
+    const int bias = 1 << 20;
+    kx = (int) ((k >> 42) & 0x1fffff) - bias;
+    ky = (int) ((k >> 21) & 0x1fffff) - bias;
+    kz = (int) (k & 0x1fffff) - bias;
+}
+
+__global__ void k_vox_rows(const unsigned long long *__restrict__ key, const int *__restrict__ vn, const double *__restrict__ mu,
+                           const double *__restrict__ m2, long long V, double *__restrict__ rows) {
+    const long long v = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    int kx, ky, kz;
+    unpack3(key[v], kx, ky, kz);
+    double *r = rows + kRow * v;
+    r[0] = kx;
+    r[1] = ky;
+    r[2] = kz;
+    r[3] = vn[v];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[4 + k] = mu[3 * v + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[7 + k] = m2[9 * v + k];
+}
+
+int voxel_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, long long capacity, long long *n_rows) {
+    if (slot < 0 || slot > 1 || !n_rows) return ctx->fail(ME_ERR_ARG, "me_voxel_partial_rows_device: bad argument");
+    ME_TRY(voxel_build(ctx, slot, voxel_size, true));
+    Cloud &c = ctx->cloud[slot];
+    *n_rows = c.n_vox;
+    if (!rows_device || c.n_vox == 0) return ME_OK;
+    if (capacity < c.n_vox) return ctx->fail(ME_ERR_CAPACITY, "me_voxel_partial_rows_device: capacity too small");
+    hipLaunchKernelGGL(k_vox_rows, dim3((unsigned int) ((c.n_vox + 255) / 256)), dim3(256), 0, ctx->stream,
+                       c.vox_key.as<unsigned long long>(), c.vox_n.as<int>(), c.vox_mu.as<double>(), c.vox_sigma.as<double>(),
+                       c.n_vox, rows_device);
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_CHECK(ctx, hipGetLastError());
+    return ME_OK;
+}
+
+// ---- merge of gathered partial rows ----
+constexpr unsigned long long kRowSentinel = 0x7fffffffffffffffULL;  // padding rows (n == 0) sort last
+
+__global__ void k_row_keys(const double *__restrict__ rows, long long m, unsigned long long *__restrict__ keys,
+                           unsigned int *__restrict__ iota) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double *r = rows + kRow * i;
+    const int bias = 1 << 20;
+    unsigned long long k = kRowSentinel;
+    if (r[3] > 0.0)
+        k = ((unsigned long long) (unsigned int) ((int) r[0] + bias) << 42) | ((unsigned long long) (unsigned int) ((int) r[1] + bias) << 21) |
+            (unsigned long long) (unsigned int) ((int) r[2] + bias);
+    keys[i] = k;
+    iota[i] = (unsigned int) i;
+}
+
+__global__ void k_row_heads(const unsigned long long *__restrict__ keys, long long m, unsigned int *__restrict__ flags) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+__global__ void k_row_segments(const unsigned long long *__restrict__ keys, const unsigned int *__restrict__ flags,
+                               const unsigned int *__restrict__ pos, long long m, unsigned long long *__restrict__ vkey,
+                               unsigned int *__restrict__ seg_start) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    if (flags[i]) {
+        vkey[pos[i]] = keys[i];
+        seg_start[pos[i]] = (unsigned int) i;
+    }
+}
+
+// One thread per voxel: n = sum n_i, mu = sum n_i mu_i / n, M2 = sum (M2_i + n_i (mu_i - mu)(mu_i - mu)^T) over its partials in
+// (rank, row) order, then the reference's finalisation (two divisions for n > 10 and the entropy, voxel_calculator.cpp:48,102-109).
+__global__ void k_vox_merge(const double *__restrict__ rows, const unsigned int *__restrict__ perm,
+                            const unsigned int *__restrict__ seg_start, long long V, long long m_end, int *__restrict__ vn,
+                            double *__restrict__ vmu, double *__restrict__ vsig, double *__restrict__ vent) {
+    const long long v = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const long long b = seg_start[v], e = (v + 1 < V) ? (long long) seg_start[v + 1] : m_end;
+    double n = 0, sx = 0, sy = 0, sz = 0;
+    for (long long j = b; j < e; ++j) {
+        const double *r = rows + kRow * (long long) perm[j];
+        n += r[3];
+        sx += r[3] * r[4];
+        sy += r[3] * r[5];
+        sz += r[3] * r[6];
+    }
+    const double mx = sx / n, my = sy / n, mz = sz / n;
+    double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long j = b; j < e; ++j) {
+        const double *r = rows + kRow * (long long) perm[j];
+        const double d[3] = {r[4] - mx, r[5] - my, r[6] - mz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S[3 * a + c] += r[7 + 3 * a + c] + r[3] * (d[a] * d[c]);
+    }
+    const long long cnt = (long long) n;
+    double ent = 0.0;
+    if (cnt > 10) {  // (:47)
+        const double nm1 = (double) (cnt - 1);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S[k] = S[k] / nm1;  // (:48)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S[k] = S[k] / nm1;  // (:102)
+        const double det = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+        if (det > 0) {
+            const double PI = 3.141592653589793238463;
+            ent = 0.5 * log(pow(2 * PI * exp(1.0), 3.0) * det);  // (:109)
+        }
+    }
+    vn[v] = (int) cnt;
+    vmu[3 * v] = mx;
+    vmu[3 * v + 1] = my;
+    vmu[3 * v + 2] = mz;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) vsig[9 * v + k] = S[k];
+    vent[v] = ent;
+}
+
+int voxel_merge(me_ctx *ctx, int slot, double voxel_size, const double *rows_device, long long m) {
+    if (slot < 0 || slot > 1 || m < 0 || (m > 0 && !rows_device) || !(voxel_size > 0))
+        return ctx->fail(ME_ERR_ARG, "me_voxel_merge_device: bad argument");
+    Cloud &c = ctx->cloud[slot];
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    c.vox_valid = false;
+    c.vox_merged = false;
+    long long V = 0;
+    if (m > 0) {
+        DevBuf &kin = ctx->tmp[0], &kout = ctx->tmp[1], &iota = ctx->tmp[2], &perm = ctx->tmp[3], &fl = ctx->tmp[4];
+        ME_CHECK(ctx, kin.ensure((size_t) m * 8));
+        ME_CHECK(ctx, kout.ensure((size_t) m * 8));
+        ME_CHECK(ctx, iota.ensure((size_t) m * 4));
+        ME_CHECK(ctx, perm.ensure((size_t) m * 4));
+        ME_CHECK(ctx, fl.ensure((size_t) m * 8));
+        unsigned int *flags = fl.as<unsigned int>(), *pos = flags + m;
+        const dim3 g((unsigned int) ((m + 255) / 256));
+        hipLaunchKernelGGL(k_row_keys, g, dim3(256), 0, ctx->stream, rows_device, m, kin.as<unsigned long long>(), iota.as<unsigned int>());
+        // stable: the partials of one voxel stay in (rank, row) order -> a fixed summation order
+        ME_TRY(sort_pairs_u64_u32(ctx, kin.as<unsigned long long>(), kout.as<unsigned long long>(), iota.as<unsigned int>(),
+                                  perm.as<unsigned int>(), m, 0, 63));
+        hipLaunchKernelGGL(k_row_heads, g, dim3(256), 0, ctx->stream, kout.as<unsigned long long>(), m, flags);
+        ME_TRY(exclusive_scan_u32(ctx, flags, pos, m));
+        unsigned int last_pos = 0, last_flag = 0;
+        unsigned long long last_key = 0;
+        ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos + (m - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags + (m - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ME_CHECK(ctx, hipMemcpyAsync(&last_key, kout.as<unsigned long long>() + (m - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+        ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const long long segs = (long long) last_pos + last_flag;
+        const bool pad = last_key == kRowSentinel;
+        V = pad ? segs - 1 : segs;
+        ME_CHECK(ctx, c.vox_key.ensure((size_t) (segs + 1) * 8));
+        ME_CHECK(ctx, c.vox_tmp.ensure((size_t) (segs + 2) * 4));
+        ME_CHECK(ctx, c.vox_n.ensure((size_t) std::max<long long>(V, 1) * 4));
+        ME_CHECK(ctx, c.vox_mu.ensure((size_t) std::max<long long>(V, 1) * 24));
+        ME_CHECK(ctx, c.vox_sigma.ensure((size_t) std::max<long long>(V, 1) * 72));
+        ME_CHECK(ctx, c.vox_entropy.ensure((size_t) std::max<long long>(V, 1) * 8));
+        unsigned int *seg_start = c.vox_tmp.as<unsigned int>();
+        hipLaunchKernelGGL(k_row_segments, g, dim3(256), 0, ctx->stream, kout.as<unsigned long long>(), flags, pos, m,
+                           c.vox_key.as<unsigned long long>(), seg_start);
+        if (V > 0) {
+            // the rows of the last real voxel end where the padding segment starts (entry V of seg_start) or at m
+            long long m_end = m;
+            if (pad) {
+                unsigned int s = 0;
+                ME_CHECK(ctx, hipMemcpyAsync(&s, seg_start + V, 4, hipMemcpyDeviceToHost, ctx->stream));
+                ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                m_end = s;
+            }
+            TimerScope ts(ctx, "voxel");
+            hipLaunchKernelGGL(k_vox_merge, dim3((unsigned int) ((V + 255) / 256)), dim3(256), 0, ctx->stream, rows_device,
+                               perm.as<unsigned int>(), seg_start, V, m_end, c.vox_n.as<int>(), c.vox_mu.as<double>(),
+                               c.vox_sigma.as<double>(), c.vox_entropy.as<double>());
+        }
+        ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ME_CHECK(ctx, hipGetLastError());
+    }
+    c.n_vox = V;
+    c.vox_size = voxel_size;
+    c.vox_raw = false;
+    c.vox_valid = true;
+    c.vox_merged = true;
+    return ME_OK;
+}
+
+}  // namespace me

@@ -336,6 +336,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
     c.n_vox = 0;
     c.vox_size = 0;
     c.vox_valid = false;
+    c.vox_merged = false;
     // any result that used this cloud as the reference is stale now
     ctx->cloud[1 - slot].nn_ref_slot = -1;
     c.n = n;
@@ -408,6 +409,7 @@ int cloud_finish(me_ctx *ctx, int slot, bool bbox_ready) {
     c.index_valid = false;
     c.nn_ref_slot = -1;
     c.vox_valid = false;
+    c.vox_merged = false;
     c.n_vox = 0;
     ctx->cloud[1 - slot].nn_ref_slot = -1;
     // bbox
@@ -446,6 +448,20 @@ int cloud_transform(me_ctx *ctx, int slot, const double *T) {
     hipLaunchKernelGGL(k_transform, dim3(grid_for(c.n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), c.n, m);
     ME_TRY(rotate_attributes(ctx, slot, T));  // normals / covariances follow the points (Open3D PointCloud::Transform)
     return cloud_finish(ctx, slot);
+}
+
+// Open3D PointCloud::Transform (map_eval.cpp:1206) on a raw device buffer, in place: what a rank applies to its part of the
+// estimated map BEFORE the halo exchange, so that the slab a point lands in is decided on the exact transformed coordinate
+int transform_points_device(me_ctx *ctx, double *xyz_device, long long n, const double *T) {
+    if (n < 0 || (n > 0 && !xyz_device) || !T) return ctx->fail(ME_ERR_ARG, "me_transform_points_device: bad argument");
+    if (n == 0) return ME_OK;
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    Mat4 m;
+    std::memcpy(m.m, T, sizeof(m.m));
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(256), 0, ctx->stream, xyz_device, n, m);
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_CHECK(ctx, hipGetLastError());
+    return ME_OK;
 }
 
 int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {

@@ -141,6 +141,7 @@ struct Cloud {
     double vox_size = 0;
     long long n_vox = 0;
     bool vox_valid = false, vox_raw = false;
+    bool vox_merged = false;  // the table is the cross-rank merge of partials (me_voxel_merge_device): complete on every rank
     DevBuf mme_ent, mme_val;  // last me_mme of this cloud, Morton order: entropy (0 where invalid), validity byte
     bool mme_have = false;
     DevBuf vox_tmp;    // build scratch (segment starts when they outgrow the shared scratch)
@@ -279,6 +280,13 @@ int icp_lsq_sums(me_ctx *ctx, int qslot, int mode, double max_distance, me_icp_l
 // ---- me_mme.hip ----
 int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, uint8_t *valid, double *sum_H,
             long long *n_valid);
+
+// ---- me_dist.hip (multi-GPU pieces) ----
+int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, const double *cuts_host, int world, double halo,
+              double *out_device, long long capacity, long long *counts_host);
+int voxel_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, long long capacity, long long *n_rows);
+int voxel_merge(me_ctx *ctx, int slot, double voxel_size, const double *rows_device, long long m);
+int transform_points_device(me_ctx *ctx, double *xyz_device, long long n, const double *T);
 
 // ---- me_render.hip ----
 int render_distance(me_ctx *ctx, int qslot, double dis, double gate, int gate_mode, double *rgb, uint8_t *inlier);

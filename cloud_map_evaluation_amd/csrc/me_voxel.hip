@@ -673,8 +673,9 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
     if (!(voxel_size > 0)) return ctx->fail(ME_ERR_ARG, "voxel_size must be > 0");
     Cloud &c = ctx->cloud[slot];
     if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "voxel pass: cloud not uploaded");
-    if (c.vox_valid && c.vox_size == voxel_size && c.vox_raw == raw) return ME_OK;  // cached
+    if (c.vox_valid && !c.vox_merged && c.vox_size == voxel_size && c.vox_raw == raw) return ME_OK;  // cached
     c.vox_valid = false;
+    c.vox_merged = false;
     if (c.n == 0) {  // empty slab
         c.n_vox = 0;
         c.vox_size = voxel_size;
@@ -797,11 +798,15 @@ int voxel_export(me_ctx *ctx, int slot, int32_t *keys, int32_t *npts, double *mu
 int awd_scs(me_ctx *ctx, double voxel_size, int min_pts, int scs_radius, double *rows, double *w_sorted, int64_t *n_rows,
             double *awd, double *scs, int64_t counts[3]) {
     if (scs_radius < 1 || scs_radius > 10) return ctx->fail(ME_ERR_ARG, "scs_radius must be in [1, 10]");
-    if (ctx->cloud[0].slab.axis >= 0 || ctx->cloud[1].slab.axis >= 0)
-        return ctx->fail(ME_ERR_STATE, "me_awd_scs: in slab mode merge me_voxel_partials across ranks, then use me_w2_batch / me_scs_table");
-    ME_TRY(voxel_build(ctx, ME_SLOT_GT, voxel_size, false));
-    ME_TRY(voxel_build(ctx, ME_SLOT_EST, voxel_size, false));
     Cloud &E = ctx->cloud[ME_SLOT_EST], &G = ctx->cloud[ME_SLOT_GT];
+    // multi-GPU: both tables were merged from every rank's partials (me_voxel_merge_device) and are complete here
+    const bool merged = E.vox_merged && G.vox_merged && E.vox_valid && G.vox_valid && E.vox_size == voxel_size && G.vox_size == voxel_size;
+    if (!merged) {
+        if (E.slab.axis >= 0 || G.slab.axis >= 0)
+            return ctx->fail(ME_ERR_STATE, "me_awd_scs: in slab mode merge the partials of all ranks first (me_voxel_merge_device)");
+        ME_TRY(voxel_build(ctx, ME_SLOT_GT, voxel_size, false));
+        ME_TRY(voxel_build(ctx, ME_SLOT_EST, voxel_size, false));
+    }
     const long long Ve = E.n_vox, Vg = G.n_vox;
     DevBuf &gi = ctx->tmp[0], &match = ctx->tmp[1], &active = ctx->tmp[2], &mpos = ctx->tmp[3];
     ME_CHECK(ctx, gi.ensure((size_t) Ve * 4));

@@ -289,6 +289,237 @@ def _slab_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
                 n_est=n_e, n_gt=n_g, n_cross_rank_queries=int(vec[o + 4]), slab=slab)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Distributed input (the north-star shape): every rank starts with 1/world of each cloud; ONE all-to-all
+# moves every point to the rank that owns its slab or needs it as halo; after that a rank touches ~1/world of the data only.
+# Collectives of a step, in dependency order (all but the halo payload are a few hundred bytes):
+#   1. all-reduce MIN  [bbox_lo, -bbox_hi] of the ground truth            -> the slab axis (longest extent)
+#   2. all-reduce SUM  histogram of the ground truth along that axis       -> equal-count cuts, identical on every rank
+#   3. all-to-all      per-destination point counts (est, gt)              -> split sizes of (4)
+#   4. all-to-all      THE HALO EXCHANGE: [est | gt] points per destination (~2 x 24 B x N / world per rank + halo)
+#   5. all-gather      [open 1-NN queries est, gt; voxel partial rows est, gt; local cloud sizes] per rank
+#   6. all-gather + 7. all-reduce MIN   the open queries and their answers (only when some rank has any: outliers,
+#                      points whose ball crosses the slab's outer faces), both directions in one message
+#   8. all-reduce SUM  the 39 partial sums;   9. all-reduce SUM  the 2 x 5 sigma numerators (need the global means of (8))
+#  10. all-gather      voxel partial rows of both clouds (one padded message), merged on the device (Chan)
+# ---------------------------------------------------------------------------------------------------------------
+def _comm(t, comm_device):
+    return t if t.device == comm_device else t.to(comm_device)
+
+
+def dist_slab_cuts(gt_part, dist, comm_device, world: int, bins: int = 8192):
+    """Equal-count slab faces along the longest axis of the GLOBAL ground-truth cloud, from each rank's part of it.
+    Returns (axis, cuts[world + 1]) with cuts[0] = -inf, cuts[-1] = +inf; identical on every rank (collectives 1 and 2)."""
+    import torch
+
+    t = gt_part
+    inf = float("inf")
+    if t.shape[0]:
+        t = t[::max(1, t.shape[0] * max(world, 1) // 1_000_000)].contiguous()  # ~1 M points in total balance the slabs
+        ext = torch.cat([t.amin(0), -t.amax(0)])
+    else:
+        ext = torch.full((6,), inf, dtype=torch.float64, device=t.device)
+    if not _single(dist):
+        ext = _all_reduce(ext, dist, comm_device, dist.ReduceOp.MIN)
+    e = ext.tolist()
+    mn, mx = e[:3], [-x for x in e[3:]]
+    axis = int(np.argmax([mx[d] - mn[d] for d in range(3)]))
+    a, b = mn[axis], mx[axis]
+    if world == 1:
+        return axis, [-inf, inf]
+    if not b > a:  # no extent at all: any strictly ascending faces will do (everything lands on one rank)
+        return axis, [-inf] + [a + k for k in range(1, world)] + [inf]
+    if t.shape[0]:
+        h = torch.histc(t[:, axis].to(torch.float64), bins=bins, min=a, max=b)
+    else:
+        h = torch.zeros(bins, dtype=torch.float64, device=t.device)
+    if not _single(dist):
+        h = _all_reduce(h, dist, comm_device)
+    cum = torch.cumsum(h, 0).tolist()
+    total = cum[-1]
+    cuts = [-inf]
+    for k in range(1, world):
+        idx = int(np.searchsorted(cum, total * k / world, side="left"))
+        c = a + (b - a) * min(idx + 1, bins) / bins
+        if cuts[-1] > -inf and not c > cuts[-1]:
+            c = float(np.nextafter(cuts[-1], inf))  # strictly ascending
+        cuts.append(c)
+    cuts.append(inf)
+    return axis, cuts
+
+
+def halo_exchange(eng, dist, comm_device, parts, axis: int, cuts, halo: float):
+    """parts: this rank's pieces of the clouds (device tensors, already transformed).  Every point goes to every rank whose slab
+    + halo holds it (collectives 3 and 4).  Returns the received clouds, one tensor per input."""
+    import torch
+
+    world = len(cuts) - 1
+    packed, counts = [], []
+    for p in parts:
+        o, c = eng.halo_pack(p, axis, cuts, halo)
+        packed.append(o)
+        counts.append(c)
+    if _single(dist):
+        return packed
+    nc = len(parts)
+    sc = torch.tensor([[counts[c][k] for c in range(nc)] for k in range(world)], dtype=torch.int64)  # (world, clouds)
+    sc_c = sc.to(comm_device)
+    rc_c = torch.empty_like(sc_c)
+    dist.all_to_all_single(rc_c, sc_c)                                                    # collective 3
+    rc = rc_c.cpu()
+    offs = [np.concatenate([[0], np.cumsum(counts[c])]) for c in range(nc)]
+    send = torch.cat([packed[c][int(offs[c][k]):int(offs[c][k + 1])] for k in range(world) for c in range(nc)])
+    in_splits = [int(sc[k].sum()) for k in range(world)]
+    out_splits = [int(rc[k].sum()) for k in range(world)]
+    send_c = _comm(send, comm_device)
+    recv_c = torch.empty((sum(out_splits), 3), dtype=torch.float64, device=comm_device)
+    dist.all_to_all_single(recv_c, send_c, out_splits, in_splits)                         # collective 4: the halo exchange
+    recv = recv_c if recv_c.device == packed[0].device else recv_c.to(packed[0].device)
+    out, base = [[] for _ in range(nc)], 0
+    for k in range(world):
+        for c in range(nc):
+            m = int(rc[k][c])
+            out[c].append(recv[base:base + m])
+            base += m
+    return [torch.cat(o).contiguous() for o in out]
+
+
+def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, world: int, evaluate_gt_mme: bool = True,
+                    halo: float = 1.0, overlap: bool = True):
+    """Full suite from DISTRIBUTED input: est_part / gt_part are this rank's 1/world of each cloud (device tensors; any
+    split, e.g. a contiguous piece of the file).  Returns the same dict as suite_step on every rank."""
+    import torch
+
+    halo = max(float(halo), 1.0001 * float(P.nn_radius_))
+    T = np.asarray(P.initial_matrix_, dtype=np.float64)
+    if not np.array_equal(T, np.eye(4)):
+        est_part = eng.transform_points(est_part.clone(), T)  # (:1206) before the exchange: slabs are cut in the map frame
+    axis, cuts = dist_slab_cuts(gt_part, dist, comm_device, world)
+    est_r, gt_r = halo_exchange(eng, dist, comm_device, [est_part, gt_part], axis, cuts, halo)
+    n_loc = (int(est_part.shape[0]), int(gt_part.shape[0]))
+    eng.set_slab(axis, cuts[rank], cuts[rank + 1], halo)
+    lane = _Lane(eng, gt_r, P, True, partials="rows") if (overlap and hasattr(eng, "twin")) else None
+    try:
+        eng.upload(ME_SLOT_EST, est_r, cell_size=P.nn_radius_)
+        if lane is None:
+            eng.upload(ME_SLOT_GT, gt_r, cell_size=P.nn_radius_)
+        else:
+            lane.est_ready.set()
+        return _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_loc, lane,
+                                  (axis, cuts[rank], cuts[rank + 1], halo))
+    except BaseException:
+        if lane is not None:
+            lane.abort()
+        raise
+
+
+def _pad_rows(t, rows: int, width: int, device):
+    import torch
+
+    out = torch.zeros((rows, width), dtype=torch.float64, device=device)
+    if t is not None and t.shape[0]:
+        out[:t.shape[0]] = t.to(device)
+    return out
+
+
+def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_loc, lane, slab):
+    import torch
+
+    single = _single(dist)
+    # --- MME: exact with halo >= radius ---
+    m_e = m_g = (0.0, 0)
+    if P.evaluate_mme_:
+        m = eng.mme(ME_SLOT_EST, P.nn_radius_, 10, per_point=False)
+        m_e = (m[4], m[3])
+    if lane is not None:
+        lane.wait_gt()
+    if P.evaluate_mme_ and evaluate_gt_mme:
+        m = eng.mme(ME_SLOT_GT, P.nn_radius_, 5, per_point=False)
+        m_g = (m[4], m[3])
+    # --- 1-NN, local part of both directions ---
+    dirs = ((ME_SLOT_EST, ME_SLOT_GT), (ME_SLOT_GT, ME_SLOT_EST))
+    cnt = []
+    for q, r in dirs:
+        eng.nn1(q, r, fetch=False)
+        cnt.append(eng.nn_unresolved_count(q))
+    # --- voxel partial rows of the owned points (second lane, or here) ---
+    if lane is not None:
+        lane.join()
+        rows = [lane.rows[ME_SLOT_EST], lane.rows[ME_SLOT_GT]]
+    else:
+        rows = [eng.voxel_partial_rows(slot, P.vmd_voxel_size_) for slot in (ME_SLOT_EST, ME_SLOT_GT)]
+    work = rows[0].device
+    # --- collective 5: everybody learns everybody's counts (and the global cloud sizes) ---
+    mine = torch.tensor([cnt[0], cnt[1], rows[0].shape[0], rows[1].shape[0], n_loc[0], n_loc[1]], dtype=torch.int64)
+    if single:
+        table = mine[None, :]
+    else:
+        parts = [torch.empty(6, dtype=torch.int64, device=comm_device) for _ in range(world)]
+        dist.all_gather(parts, mine.to(comm_device))
+        table = torch.stack(parts).cpu()
+    n_e, n_g = int(table[:, 4].sum()), int(table[:, 5].sum())
+    # --- collectives 6 + 7: open queries of both directions in one all-gather, their answers in one MIN-reduce ---
+    n_cross = int(table[:, 0].sum() + table[:, 1].sum())
+    if not single and n_cross > 0:
+        cmax = [int(table[:, 0].max()), int(table[:, 1].max())]
+        blocks = [_pad_rows(eng.nn_unresolved(q, with_d2=True) if cnt[i] else None, cmax[i], 4, comm_device)
+                  for i, (q, r) in enumerate(dirs)]
+        msg = torch.cat(blocks)                                   # (cmax_e + cmax_g, 4): xyz + the bound to beat
+        parts = [torch.empty_like(msg) for _ in range(world)]
+        dist.all_gather(parts, msg)
+        allq = torch.stack(parts)                                 # (world, cmax_e + cmax_g, 4)
+        d2 = torch.full(allq.shape[:2], float("inf"), dtype=torch.float64, device=comm_device)
+        base = 0
+        for i, (q, r) in enumerate(dirs):
+            sel = [(k, int(table[k, i])) for k in range(world) if k != rank and int(table[k, i]) > 0]
+            if sel:
+                qs = torch.cat([allq[k, base:base + c] for k, c in sel])
+                ans = eng.nn_points(r, qs[:, :3].contiguous().to(work), bound=qs[:, 3].contiguous().to(work)).to(comm_device)
+                o = 0
+                for k, c in sel:
+                    d2[k, base:base + c] = ans[o:o + c]
+                    o += c
+            if cnt[i]:
+                d2[rank, base:base + cnt[i]] = allq[rank, base:base + cnt[i], 3]  # the owner's own search is its answer
+            base += cmax[i]
+        dist.all_reduce(d2, op=dist.ReduceOp.MIN)
+        base = 0
+        for i, (q, r) in enumerate(dirs):
+            if cnt[i]:
+                eng.nn_patch(q, d2[rank, base:base + cnt[i]].contiguous().to(work))
+            base += cmax[i]
+    # --- collectives 8 + 9: partial sums, then the sigma numerators (second pass of map_eval.cpp:1132-1138) ---
+    parts = [eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_) for q, r in dirs]
+    vec = all_reduce_sum(pack_partials(parts, m_e, m_g), dist, comm_device)
+    sig_local = []
+    for i, (q, r) in enumerate(dirs):
+        C = vec[i * _DIR]
+        mean = vec[i * _DIR + 6:i * _DIR + 11] / C if C > 0 else np.zeros(5)
+        sig_local.append(eng.nn_sigma_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, mean))
+    sig = all_reduce_sum(np.concatenate(sig_local), dist, comm_device)
+    s_eg = direction_stats(vec, 0, sig[:5], n_e)
+    s_ge = direction_stats(vec, 1, sig[5:], n_g)
+    o = 2 * _DIR
+    mme_est = vec[o] / vec[o + 1] if vec[o + 1] > 0 else 0.0
+    mme_gt = vec[o + 2] / vec[o + 3] if vec[o + 3] > 0 else 0.0
+    # --- collective 10: voxel partial rows of both clouds in one padded all-gather, merged on the device ---
+    if single:
+        gathered = rows
+    else:
+        vmax = [max(int(table[:, 2].max()), 1), max(int(table[:, 3].max()), 1)]
+        msg = torch.cat([_pad_rows(rows[0], vmax[0], 16, comm_device), _pad_rows(rows[1], vmax[1], 16, comm_device)])
+        parts = [torch.empty_like(msg) for _ in range(world)]
+        dist.all_gather(parts, msg)
+        allr = torch.stack(parts)
+        gathered = [allr[:, :vmax[0]].reshape(-1, 16), allr[:, vmax[0]:].reshape(-1, 16)]
+    for slot, g in zip((ME_SLOT_EST, ME_SLOT_GT), gathered):
+        eng.voxel_merge(slot, P.vmd_voxel_size_, g.contiguous())
+    v = eng.calculateVMD(P.vmd_voxel_size_, rows=False)
+    return dict(est_gt=s_eg, gt_est=s_ge, ac=s_eg["rmse"], com=s_eg["fitness"], cd=s_eg["mean_nn"] + s_ge["mean_nn"],
+                mme_est=mme_est, mme_gt=mme_gt, mme_valid=int(vec[o + 1]), awd=v["awd"], scs=v["scs"], n_w=v["n_rows"],
+                n_est=n_e, n_gt=n_g, n_cross_rank_queries=n_cross, slab=slab)
+
+
 class _Lane:
     """The second lane of an overlapped step: a host thread driving the engine's twin context (me_twin).  It does the
     HBM-bound work (index of the ground truth, both voxel tables) while the main lane runs the VALU-bound MME / 1-NN
@@ -335,7 +566,9 @@ class _Lane:
             self.gt_ready.set()
 
     def _voxel(self, lane, slot, P):
-        if self.partials:
+        if self.partials == "rows":  # distributed mode: the partial rows stay on the device (the all-gather's payload)
+            self.rows[slot] = lane.voxel_partial_rows(slot, P.vmd_voxel_size_)
+        elif self.partials:
             self.rows[slot] = _partial_rows(lane, slot, P.vmd_voxel_size_)
         else:
             lane.voxel_build(slot, P.vmd_voxel_size_)

@@ -415,6 +415,56 @@ class Engine:
                                                C.byref(nv)))
         return keys, n, mu, m2.reshape(v, 3, 3)
 
+    # ---- multi-GPU with distributed input (include/mapeval_hip.h: me_halo_pack_device ...) ----
+    def transform_points(self, xyz, T):
+        """Open3D Transform (map_eval.cpp:1206) on a cuda tensor (n,3) float64, in place; returns it."""
+        import torch
+
+        Tm = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        assert xyz.is_cuda and xyz.dtype == torch.float64 and xyz.is_contiguous()
+        torch.cuda.current_stream(xyz.device).synchronize()
+        self._ck(self._L.me_transform_points_device(self._ctx, xyz.data_ptr(), int(xyz.shape[0]), _addr(Tm)))
+        return xyz
+
+    def halo_pack(self, xyz, axis: int, cuts, halo: float):
+        """Send side of the halo exchange: xyz (n,3) cuda float64 -> (packed (m,3) cuda tensor, destination-major; counts
+        list[world]).  Rank k receives every point with cuts[k] - halo <= p[axis] < cuts[k+1] + halo."""
+        import torch
+
+        world = len(cuts) - 1
+        c = np.ascontiguousarray(cuts, dtype=np.float64)
+        counts = np.zeros(world, np.int64)
+        assert xyz.is_cuda and xyz.dtype == torch.float64 and xyz.is_contiguous()
+        torch.cuda.current_stream(xyz.device).synchronize()
+        n = int(xyz.shape[0])
+        self._ck(self._L.me_halo_pack_device(self._ctx, xyz.data_ptr(), n, int(axis), _addr(c), world, float(halo), 0, 0, _addr(counts)))
+        total = int(counts.sum())
+        out = torch.empty((total, 3), dtype=torch.float64, device=xyz.device)
+        if total:
+            self._ck(self._L.me_halo_pack_device(self._ctx, xyz.data_ptr(), n, int(axis), _addr(c), world, float(halo), out.data_ptr(),
+                                                 total, _addr(counts)))
+        return out, [int(x) for x in counts]
+
+    def voxel_partial_rows(self, slot: int, voxel_size: float):
+        """This rank's voxel partials as a (V,16) cuda tensor [kx,ky,kz,n,mu(3),M2(9)] (no host copy)."""
+        import torch
+
+        nv = C.c_int64(0)
+        self._ck(self._L.me_voxel_partial_rows_device(self._ctx, slot, float(voxel_size), 0, 0, C.byref(nv)))
+        rows = torch.empty((nv.value, 16), dtype=torch.float64, device=torch.device("cuda", self.device))
+        if nv.value:
+            self._ck(self._L.me_voxel_partial_rows_device(self._ctx, slot, float(voxel_size), rows.data_ptr(), nv.value, C.byref(nv)))
+        return rows
+
+    def voxel_merge(self, slot: int, voxel_size: float, rows):
+        """Chan merge of the gathered partial rows of ALL ranks (cuda tensor (m,16); n == 0 rows are padding) into the slot's
+        voxel table; calculateVMD then runs on the merged tables."""
+        import torch
+
+        rows = rows.to(torch.device("cuda", self.device), torch.float64).contiguous()
+        torch.cuda.current_stream(rows.device).synchronize()
+        self._ck(self._L.me_voxel_merge_device(self._ctx, slot, float(voxel_size), rows.data_ptr(), int(rows.shape[0])))
+
     # ---- whole suite ----
     def run_suite(self, p: Param, gate_mode: int = ME_GATE_LE_UNSQUARED) -> _lib.SuiteOut:
         sp = _lib.SuiteParams()

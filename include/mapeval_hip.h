@@ -118,6 +118,27 @@ int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t co
 int me_voxel_partials(me_ctx *ctx, int slot, double voxel_size, int32_t *keys /*V x 3*/, int32_t *npts /*V*/,
                       double *mu /*V x 3*/, double *m2 /*V x 9*/, int64_t *n_voxels);
 
+/* Multi-GPU with DISTRIBUTED INPUT (no reference counterpart): every rank starts with 1/world of each cloud.
+ *   me_transform_points_device   *cloud = cloud->Transform(T) (map_eval.cpp:1206) on a raw device buffer, in place — applied to
+ *                                a rank's part of the estimated map BEFORE the exchange, so that slab membership is decided
+ *                                on the exact transformed coordinate.
+ *   me_halo_pack_device          the send side of the one-shot halo exchange.  cuts[world + 1] (host, ascending, cuts[0] = -inf,
+ *                                cuts[world] = +inf) are the slab faces along `axis`; point p goes to EVERY rank k with
+ *                                cuts[k] - halo <= p[axis] < cuts[k+1] + halo (the filter me_set_slab applies on the
+ *                                receiving side).  out_device (capacity x 3) receives the points destination-major, in input
+ *                                order inside a destination (deterministic); counts[world] the segment sizes — exactly the
+ *                                send buffer and split sizes of one all_to_all.  out_device == NULL: counts only.
+ *   me_voxel_partial_rows_device me_voxel_partials as rows [kx, ky, kz, n, mu(3), M2(9)] (16 doubles) in a device buffer:
+ *                                what the all-gather of the voxel partials carries (rows with n == 0 are padding).
+ *   me_voxel_merge_device        Chan's parallel update of the gathered rows of all ranks -> the slot's voxel table exactly as
+ *                                VoxelCalculator::buildVoxelMap leaves it (voxel_calculator.cpp:21-56: M2/(n-1)^2 for n > 10);
+ *                                when both slots hold a merged table of the same voxel size, me_awd_scs runs on them. */
+int me_transform_points_device(me_ctx *ctx, double *xyz_device, int64_t n, const double *T_rowmajor4x4);
+int me_halo_pack_device(me_ctx *ctx, const double *xyz_device, int64_t n, int axis, const double *cuts, int world, double halo,
+                        double *out_device, int64_t capacity, int64_t *counts);
+int me_voxel_partial_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, int64_t capacity, int64_t *n_rows);
+int me_voxel_merge_device(me_ctx *ctx, int slot, double voxel_size, const double *rows_device, int64_t n_rows);
+
 /* ---- clouds ------------------------------------------------------------------------------------------------ */
 /* Replaces: *map_3d_ = map_3d_->Transform(initial_matrix) (map_eval.cpp:1206) + every KDTreeFlann::SetGeometry
  * (map_eval.cpp:1214,1227,1401-1402,1449,1551,1619): uploads the cloud, applies T (row-major 4x4, NULL = none;
@@ -288,7 +309,7 @@ int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out);
 
 /* ---- instrumentation (bench.py roofline leg) ------------------------------------------------------------- */
 /* Average device time (ms, HIP events on the context's stream) and launch count of a named kernel family since
- * the last me_timers_reset: "nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "voxel", "w2", "scs", "slab_filter".  Enabled by me_timers_enable(1). */
+ * the last me_timers_reset: "nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "voxel", "w2", "scs", "slab_filter", "halo_pack".  Enabled by me_timers_enable(1). */
 int me_timers_enable(me_ctx *ctx, int on);
 int me_timers_reset(me_ctx *ctx);
 int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
