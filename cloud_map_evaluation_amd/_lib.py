@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapeval_hip.so")
 
 ME_OK = 0
+ME_ERR_CAPACITY = -4
 ME_SLOT_EST = 0
 ME_SLOT_GT = 1
 ME_GATE_LE_UNSQUARED = 0

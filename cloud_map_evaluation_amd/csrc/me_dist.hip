@@ -65,9 +65,16 @@ k_halo_split(const double *__restrict__ xyz, long long n, int axis, Cuts cuts, i
     if (!SCATTER && lane < world) unit_counts[(long long) lane * n_units + u] = mine;
 }
 
+__global__ void k_split_segments(const unsigned int *__restrict__ off, const unsigned int *__restrict__ cnt, long long n_units,
+                                 int world, unsigned int *__restrict__ seg) {
+    const int k = threadIdx.x;
+    if (k < world) seg[k] = off[(long long) k * n_units];
+    if (k == world) seg[world] = off[n_units * world - 1] + cnt[n_units * world - 1];
+}
+
 int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, const double *cuts_host, int world, double halo,
               double *out_device, long long capacity, long long *counts_host) {
-    if (!xyz_device || n < 0 || axis < 0 || axis > 2 || !cuts_host || world < 1 || world > kMaxWorld || !(halo >= 0) || !counts_host)
+    if ((n > 0 && !xyz_device) || n < 0 || axis < 0 || axis > 2 || !cuts_host || world < 1 || world > kMaxWorld || !(halo >= 0) || !counts_host)
         return ctx->fail(ME_ERR_ARG, "me_halo_pack_device: bad argument (1 <= world <= 64)");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     Cuts c{};
@@ -88,15 +95,14 @@ int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, cons
     hipLaunchKernelGGL(k_halo_split<false>, grid, dim3(256), 0, ctx->stream, xyz_device, n, axis, c, world, n_units,
                        cnt.as<unsigned int>(), (const unsigned int *) nullptr, (double *) nullptr);
     ME_TRY(exclusive_scan_u32(ctx, cnt.as<unsigned int>(), off.as<unsigned int>(), n_cnt));
-    // destination k's segment starts at off[k * n_units]; the total is off[last] + cnt[last]
+    // destination k's segment starts at off[k * n_units]; the total is off[last] + cnt[last]: one small kernel collects the
+    // world + 1 numbers, ONE copy brings them to the host (world separate 4-byte copies cost ~10 us each)
+    ME_CHECK(ctx, ctx->red.ensure((size_t) (world + 1) * 4));
+    hipLaunchKernelGGL(k_split_segments, dim3(1), dim3(kMaxWorld + 1), 0, ctx->stream, off.as<unsigned int>(), cnt.as<unsigned int>(),
+                       n_units, world, ctx->red.as<unsigned int>());
     std::vector<unsigned int> seg((size_t) world + 1);
-    for (int k = 0; k < world; ++k)
-        ME_CHECK(ctx, hipMemcpyAsync(&seg[k], off.as<unsigned int>() + (long long) k * n_units, 4, hipMemcpyDeviceToHost, ctx->stream));
-    unsigned int last_cnt = 0;
-    ME_CHECK(ctx, hipMemcpyAsync(&seg[world], off.as<unsigned int>() + (n_cnt - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&last_cnt, cnt.as<unsigned int>() + (n_cnt - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(seg.data(), ctx->red.p, (size_t) (world + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    seg[world] += last_cnt;
     long long total = 0;
     for (int k = 0; k < world; ++k) {
         counts_host[k] = (long long) seg[k + 1] - (long long) seg[k];

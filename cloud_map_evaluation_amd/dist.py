@@ -398,7 +398,9 @@ def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, wor
     est_r, gt_r = halo_exchange(eng, dist, comm_device, [est_part, gt_part], axis, cuts, halo)
     n_loc = (int(est_part.shape[0]), int(gt_part.shape[0]))
     eng.set_slab(axis, cuts[rank], cuts[rank + 1], halo)
-    lane = _Lane(eng, gt_r, P, True, partials="rows") if (overlap and hasattr(eng, "twin")) else None
+    # second lane: the ground truth's filter + index, both voxel partial tables, then the ground-truth -> map search (its
+    # latency-bound octree tail runs under the main lane's kernels)
+    lane = _Lane(eng, gt_r, P, True, partials="rows", nn_back="search") if (overlap and hasattr(eng, "twin")) else None
     try:
         eng.upload(ME_SLOT_EST, est_r, cell_size=P.nn_radius_)
         if lane is None:
@@ -440,6 +442,10 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     dirs = ((ME_SLOT_EST, ME_SLOT_GT), (ME_SLOT_GT, ME_SLOT_EST))
     cnt = []
     for q, r in dirs:
+        if lane is not None and lane.nn_back and q == ME_SLOT_GT:
+            lane.join()  # the second lane has searched this direction meanwhile
+            cnt.append(lane.unres_back)
+            continue
         eng.nn1(q, r, fetch=False)
         cnt.append(eng.nn_unresolved_count(q))
     # --- voxel partial rows of the owned points (second lane, or here) ---
@@ -539,6 +545,7 @@ class _Lane:
         # has collectives inside the search)
         self.nn_back = nn_back
         self.parts_back = None
+        self.unres_back = 0
         self.rows = {}
         self.gt_ready = threading.Event()
         self.est_ready = threading.Event()
@@ -560,7 +567,10 @@ class _Lane:
                 self._voxel(lane, ME_SLOT_EST, P)
             if self.err is None and self.nn_back:
                 lane.nn1(ME_SLOT_GT, ME_SLOT_EST, fetch=False)
-                self.parts_back = lane.nn_partial_sums(ME_SLOT_GT, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_)
+                if self.nn_back == "search":  # distributed mode: the sums wait for the cross-rank step
+                    self.unres_back = lane.nn_unresolved_count(ME_SLOT_GT)
+                else:
+                    self.parts_back = lane.nn_partial_sums(ME_SLOT_GT, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_)
         except BaseException as e:  # re-raised by join()
             self.err = e
             self.gt_ready.set()

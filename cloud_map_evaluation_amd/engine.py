@@ -437,12 +437,19 @@ class Engine:
         assert xyz.is_cuda and xyz.dtype == torch.float64 and xyz.is_contiguous()
         torch.cuda.current_stream(xyz.device).synchronize()
         n = int(xyz.shape[0])
-        self._ck(self._L.me_halo_pack_device(self._ctx, xyz.data_ptr(), n, int(axis), _addr(c), world, float(halo), 0, 0, _addr(counts)))
+        # one call: count + scatter into a buffer sized for the usual case (every point to its owner, a thin halo to the
+        # neighbours); the rare overflow (halo wider than the slabs) comes back as ME_ERR_CAPACITY with the exact counts
+        cap = n + n // 2 + 4096
+        out = torch.empty((cap, 3), dtype=torch.float64, device=xyz.device)
+        rc = self._L.me_halo_pack_device(self._ctx, xyz.data_ptr(), n, int(axis), _addr(c), world, float(halo), out.data_ptr(), cap,
+                                         _addr(counts))
         total = int(counts.sum())
-        out = torch.empty((total, 3), dtype=torch.float64, device=xyz.device)
-        if total:
-            self._ck(self._L.me_halo_pack_device(self._ctx, xyz.data_ptr(), n, int(axis), _addr(c), world, float(halo), out.data_ptr(),
-                                                 total, _addr(counts)))
+        if rc == _lib.ME_ERR_CAPACITY:
+            out = torch.empty((total, 3), dtype=torch.float64, device=xyz.device)
+            rc = self._L.me_halo_pack_device(self._ctx, xyz.data_ptr(), n, int(axis), _addr(c), world, float(halo), out.data_ptr(),
+                                             total, _addr(counts))
+        self._ck(rc)
+        out = out[:total]
         return out, [int(x) for x in counts]
 
     def voxel_partial_rows(self, slot: int, voxel_size: float):

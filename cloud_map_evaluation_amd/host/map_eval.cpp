@@ -42,6 +42,24 @@ std::string eigen_row(const Vector5d &v, int precision) {
     return out;
 }
 
+// Eigen's default IOFormat for `os << Matrix4d` (row-major input): common width over all 16 coefficients
+std::string eigen_matrix4(const double *m, int precision) {
+    std::string s[16];
+    size_t w = 0;
+    for (int i = 0; i < 16; ++i) {
+        std::ostringstream o;
+        o << std::fixed << std::setprecision(precision) << m[i];
+        s[i] = o.str();
+        w = std::max(w, s[i].size());
+    }
+    std::string out;
+    for (int r = 0; r < 4; ++r) {
+        for (int c = 0; c < 4; ++c) out += (c ? " " : "") + std::string(w - s[4 * r + c].size(), ' ') + s[4 * r + c];
+        if (r < 3) out += "\n";
+    }
+    return out;
+}
+
 Vector5d to5(const double *p) { return Vector5d{{p[0], p[1], p[2], p[3], p[4]}}; }
 
 void push_results(std::vector<Vector5d> &dst, const me_nn_stats_out &o) {
@@ -179,7 +197,10 @@ int MapEval::process() {
     else if (ext == "ply") ok_gt = pcio::read_ply(param_.map_gt_path_, gt_3d_->points_, &err, &gt_normals);
     else return fail("Unsupported ground truth file format: " + param_.map_gt_path_);
     if (!ok_gt) std::cerr << "WARNING: " << err << std::endl;
-    const bool success = pcio::read_pcd(param_.evaluation_map_pcd_path_ + param_.pcd_file_name_, map_3d_->points_, &err);
+    // the estimated map's own normal_x/y/z, if its PCD has them: Open3D's InitializePointCloudForGeneralizedICP uses a
+    // cloud's normals when it carries them and estimates them (KNN 20) only otherwise
+    std::vector<double> map_normals;
+    const bool success = pcio::read_pcd(param_.evaluation_map_pcd_path_ + param_.pcd_file_name_, map_3d_->points_, &err, &map_normals);
     if (param_.enable_debug)
         std::cout << "INFO: Loading map point cloud from: " << param_.evaluation_map_pcd_path_ + param_.pcd_file_name_ << std::endl;
     if (!success) return fail("Failed to load point cloud from the specified path.");
@@ -199,6 +220,9 @@ int MapEval::process() {
     if (gt_normals.size() == gt_3d_->points_.size() && !gt_normals.empty() &&
         me_set_normals(ctx_, ME_SLOT_GT, gt_normals.data()) != ME_OK)
         return fail(me_last_error(ctx_));
+    if (map_normals.size() == map_3d_->points_.size() && !map_normals.empty() &&
+        me_set_normals(ctx_, ME_SLOT_EST, map_normals.data()) != ME_OK)
+        return fail(me_last_error(ctx_));
     // map_3d_ = map_3d_->VoxelDownSample(downsample_size) (:38-39), on the device (normals are averaged with the points)
     if (param_.downsample_size > 0) {
         int64_t ne = 0, ng = 0;
@@ -207,8 +231,9 @@ int MapEval::process() {
             return fail(me_last_error(ctx_));
         map_3d_->points_.resize((size_t) ne * 3);
         gt_3d_->points_.resize((size_t) ng * 3);
-        me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data());
-        me_download_cloud(ctx_, ME_SLOT_GT, gt_3d_->points_.data());
+        if (me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data()) != ME_OK ||
+            me_download_cloud(ctx_, ME_SLOT_GT, gt_3d_->points_.data()) != ME_OK)
+            return fail(me_last_error(ctx_));
     }
     file_result << std::fixed << std::setprecision(15) << "Estimated-Ground Truth point count: " << map_3d_->size() << " / "
                 << gt_3d_->size() << std::endl;
@@ -236,8 +261,9 @@ int MapEval::process() {
     if (param_.evaluate_using_initial_) {
         if (param_.enable_debug) std::cout << "INFO: Using initial matrix without registration." << std::endl;
         if (T && !identity) {  // *map_3d_ = map_3d_->Transform(param_.initial_matrix_) (:1206)
-            if (me_transform_cloud(ctx_, ME_SLOT_EST, T) != ME_OK) return fail(me_last_error(ctx_));
-            me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data());
+            if (me_transform_cloud(ctx_, ME_SLOT_EST, T) != ME_OK ||
+                me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data()) != ME_OK)
+                return fail(me_last_error(ctx_));
         }
         calculateMetricsWithInitialMatrix();
         if (!last_error.empty()) return -1;
@@ -440,7 +466,8 @@ int MapEval::performRegistration() {
     }
     t3 = 0;  // no mesh stage
     t4 = tic_toc.toc();
-    me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data());  // *map_3d_ = map_3d_->Transform(trans) (:1392)
+    if (me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data()) != ME_OK)  // *map_3d_ = map_3d_->Transform(trans) (:1392)
+        return fail(me_last_error(ctx_));
     std::cout << "INFO: ICP registration time: " << t4 / 1000.0 << " [s]" << std::endl;
     std::cout << "INFO: Aligned transformation: \n";
     for (int r = 0; r < 4; ++r)
@@ -449,11 +476,9 @@ int MapEval::performRegistration() {
     std::cout << "INFO: ICP correspondences RMSE: " << rmse << std::endl;
     std::cout << "INFO: ICP correspondences size: " << s.n_corr << std::endl;
     // "Aligned cloud:" / "Aligned results:" lines (map_eval.cpp:223-225)
-    file_result << std::fixed << std::setprecision(5) << "Aligned cloud: ";
-    for (int r = 0; r < 4; ++r) {
-        for (int c = 0; c < 4; ++c) file_result << (c ? " " : "") << trans[4 * r + c];
-        file_result << std::endl;
-    }
+    // (`file_result << matrix`: Eigen's default IOFormat pads every coefficient to the width of the widest one of the WHOLE
+    //  matrix, one space between columns, one row per line)
+    file_result << std::fixed << std::setprecision(5) << "Aligned cloud: " << eigen_matrix4(trans.data(), 5) << std::endl;
     file_result << std::fixed << std::setprecision(5) << "Aligned results: " << fit << " " << s.n_corr << std::endl;
     calculateMetrics();
     t5 = tic_toc.toc();
@@ -508,7 +533,15 @@ bool MapEval::renderEntropy(int slot, std::vector<double> &xyz, std::vector<doub
     }
     xyz.clear();
     rgb.clear();
-    if (!want_points || m == 0) return true;
+    if (m == 0) {
+        // no point had enough neighbours (sparse cloud / small nn_radius): the entropy range is undefined (the reference
+        // reads min/max of an empty set there).  Say so, and report NaN rather than the +-inf of an empty reduction.
+        std::cerr << "WARNING: no valid entropy value (0 points with enough neighbours within nn_radius): MME range is undefined, "
+                     "no entropy map is written" << std::endl;
+        min_abs_entropy = max_abs_entropy = std::nan("");
+        return true;
+    }
+    if (!want_points) return true;
     xyz.resize((size_t) m * 3);
     rgb.resize((size_t) m * 3);
     if (me_render_entropy(ctx_, slot, xyz.data(), rgb.data(), m, &m, &min_abs_entropy, &max_abs_entropy) != ME_OK) {
@@ -654,10 +687,12 @@ void MapEval::saveMmeResults() {
     file_result << std::fixed << std::setprecision(5) << "MME: " << mme_est << " " << mme_gt << " " << min_abs_entropy << " "
                 << max_abs_entropy << std::endl;  // (:395-396)
     // map_entropy.pcd / gt_entropy.pcd (:404, :412): valid points + Jet colour of the log-mapped entropy
-    pcio::write_pcd(results_subfolder + "map_entropy.pcd", map_entropy_xyz.data(), map_entropy_xyz.size() / 3,
-                    pack_rgb(map_entropy_rgb).data());
-    std::cout << "INFO: Saved rendered entropy map to " << results_subfolder + "map_entropy.pcd" << std::endl;
-    if (param_.evaluate_gt_mme_) {
+    if (!map_entropy_xyz.empty()) {  // (nothing to draw when no point has a valid entropy; renderEntropy has said so)
+        pcio::write_pcd(results_subfolder + "map_entropy.pcd", map_entropy_xyz.data(), map_entropy_xyz.size() / 3,
+                        pack_rgb(map_entropy_rgb).data());
+        std::cout << "INFO: Saved rendered entropy map to " << results_subfolder + "map_entropy.pcd" << std::endl;
+    }
+    if (param_.evaluate_gt_mme_ && !gt_entropy_xyz.empty()) {
         pcio::write_pcd(results_subfolder + "gt_entropy.pcd", gt_entropy_xyz.data(), gt_entropy_xyz.size() / 3,
                         pack_rgb(gt_entropy_rgb).data());
         std::cout << "INFO: Saved rendered entropy ground truth map to " << results_subfolder + "gt_entropy.pcd" << std::endl;

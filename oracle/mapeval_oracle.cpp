@@ -571,7 +571,9 @@ orc_kdtree *orc_kdtree_build_mt(const double *xyz, int64_t n, int threads) {
         }
         t->nodes = static_cast<Node *>(std::malloc((size_t) (2 * n + 2) * sizeof(Node)));
         double lo[3] = {t->bb_lo[0], t->bb_lo[1], t->bb_lo[2]}, hi[3] = {t->bb_hi[0], t->bb_hi[1], t->bb_hi[2]};
-        const int nt = resolve_threads(threads);
+        // (more than a few dozen threads only fight over the task queue and the first touch of the node array: on a
+        // 256-core host the task build with all cores was slower than the serial one)
+        const int nt = std::min(resolve_threads(threads), 32);
         if (nt > 1 && n > 100000) {
             t->task_cutoff = std::max<int64_t>(20000, n / (64 * (int64_t) nt));
 #pragma omp parallel num_threads(nt)

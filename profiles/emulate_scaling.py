@@ -1,7 +1,10 @@
 #!/usr/bin/env python
-"""Strong-scaling estimate on ONE GPU: runs the slab-mode step of every rank of an N-rank job one after another with
-stub collectives (all_reduce = identity, all_gather = own buffer repeated), so the metric VALUES are partial but the
-per-rank compute time is what a real rank would spend between collectives.  usage: python profiles/emulate_scaling.py"""
+"""Strong-scaling ESTIMATE on ONE GPU for the distributed-input step (dist.suite_step_dist): every rank of an N-rank job is
+run one after another with a stand-in process group whose collectives return what the real ones would (the all-to-all
+delivers the points the other ranks would have sent — precomputed, untimed; all-reduces are identities; all-gathers repeat
+the rank's own message), so a rank's time is the compute + host work it would spend between collectives.  RCCL latency of
+the ~10 small collectives (~0.3-0.5 ms per step) and the halo payload (2 x 24 B x N / world^2 per link: < 0.3 ms at 8 ranks
+over xGMI) are NOT included.  usage: python profiles/emulate_scaling.py [points] [--workload campus|c4_multisession]"""
 import json
 import sys
 import time
@@ -17,8 +20,9 @@ class FakeDist:
     class ReduceOp:
         SUM, MAX, MIN = "sum", "max", "min"
 
-    def __init__(self, world, rank):
+    def __init__(self, world, rank, recv_counts=None, recv_points=None):
         self.world, self.rank = world, rank
+        self.recv_counts, self.recv_points = recv_counts, recv_points
 
     def is_initialized(self):
         return True
@@ -36,37 +40,93 @@ class FakeDist:
         for p in parts:
             p.copy_(buf)
 
+    def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+        if out.dtype == torch.int64:
+            out.copy_(self.recv_counts)   # what every rank sends to this one
+        else:
+            out.copy_(self.recv_points)
+
     def barrier(self):
         pass
 
 
-def main(points=50_000_000, overlap=True):
+def main(points, workload):
     dev = torch.device("cuda", 0)
-    est, gt = synth.campus_pair(points, density=2500.0, seed=100, device=dev)
+    if workload == "c4_multisession":
+        est, gt = synth.multisession_pair(points, 3, density=2500.0, seed=100, device=dev)
+    else:
+        est, gt = synth.scan_pair(points, density=2500.0, seed=100, device=dev)
     P = Param(icp_max_distance_=1.0, nn_radius_=0.1, vmd_voxel_size_=3.0)
     eng = Engine(0)
+    halo = 1.0
     out = {}
     for world in (1, 2, 4, 8):
-        per_rank = []
+        pieces = [(est[slice(*medist.shard_range(est.shape[0], r, world))], gt[slice(*medist.shard_range(gt.shape[0], r, world))])
+                  for r in range(world)]
+        per_rank, detail = [], []
+        if world > 1:
+            # what the halo exchange delivers to every rank (untimed): the cuts are those every rank computes
+            axis, cuts = medist.dist_slab_cuts(gt, None, dev, world)
+            packs = [[eng.halo_pack(p, axis, cuts, halo) for p in pc] for pc in pieces]  # [src][cloud] -> (points, counts)
         for rank in range(world):
-            fd = FakeDist(world, rank)
-            best = 1e9
+            if world == 1:
+                fd, args = None, None
+            else:
+                rc = torch.tensor([[packs[s][c][1][rank] for c in range(2)] for s in range(world)], dtype=torch.int64, device=dev)
+                segs = []
+                for s in range(world):
+                    for c in range(2):
+                        pts, cnts = packs[s][c]
+                        o = sum(cnts[:rank])
+                        segs.append(pts[o:o + cnts[rank]])
+                fd = FakeDist(world, rank, rc, torch.cat(segs))
+
+                GLOBAL["cuts"] = (axis, cuts)
+                medist.dist_slab_cuts = _patched_cuts
+            best, best_t = 1e9, None
             for rep in range(3):
+                eng.timers_enable(rep == 2)
+                if rep == 2:
+                    eng.timers_reset()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 if world == 1:
-                    medist.suite_step(eng, None, dev, est, gt, P, True, overlap=overlap)
+                    medist.suite_step(eng, None, dev, est, gt, P, True, overlap=True)
                 else:
-                    medist.suite_step_slab(eng, fd, dev, est, gt, P, rank, world, True, halo=1.0, overlap=overlap)
+                    medist.suite_step_dist(eng, fd, dev, pieces[rank][0], pieces[rank][1], P, rank, world, True, halo=halo, overlap=True)
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
+            best_t = {k: round(eng.timer(k)[0], 2) for k in ("mme", "nn_grid", "nn1", "sort", "morton", "gather", "cells", "voxel",
+                                                            "slab_filter", "halo_pack", "nn_stats") if eng.timer(k)[1]}
+            eng.timers_enable(False)
+            medist.dist_slab_cuts = _orig_cuts
             per_rank.append(best * 1e3)
-        out[world] = {"max_ms": max(per_rank), "mean_ms": sum(per_rank) / len(per_rank)}
+            detail.append(best_t)
+        worst = max(range(world), key=lambda r: per_rank[r])
+        out[world] = {"max_ms": per_rank[worst], "mean_ms": sum(per_rank) / world, "slowest_rank_kernel_ms": detail[worst]}
         print(world, out[world], flush=True)
+        if world > 1:
+            del packs
     base = out[1]["max_ms"]
-    print(json.dumps({"points": points, "overlap": overlap, "per_world": out,
-                      "speedup_vs_1": {w: base / v["max_ms"] for w, v in out.items()}}))
+    print(json.dumps({"points": points, "workload": workload, "driver": "suite_step_dist (distributed input, all-to-all halo)",
+                      "per_world": out, "speedup_vs_1": {w: base / v["max_ms"] for w, v in out.items()}}))
+
+
+_orig_cuts = medist.dist_slab_cuts
+GLOBAL = {}
+
+
+def _patched_cuts(gt_part, d, cd, w, bins=8192):
+    """Collectives 1 + 2 are identities here, so a rank alone would cut by its OWN histogram: do the same device work, then
+    hand back the global cuts (those the precomputed exchange was made for)."""
+    _orig_cuts(gt_part, None, cd, w, bins)
+    return GLOBAL["cuts"]
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000, overlap=("--no-overlap" not in sys.argv))
+    a = [x for x in sys.argv[1:] if not x.startswith("--")]
+    wl = "campus"
+    if "--workload" in sys.argv:
+        wl = sys.argv[sys.argv.index("--workload") + 1]
+        a = [x for x in a if x != wl]
+    main(int(a[0]) if a else 50_000_000, wl)

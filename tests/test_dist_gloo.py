@@ -465,3 +465,148 @@ def test_a_failure_on_the_second_lane_surfaces_and_does_not_hang():
     P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=0.5)
     with pytest.raises(RuntimeError, match="lane failure"):
         medist.suite_step(_TwoLaneEngine(fail_in="voxel_build"), None, torch.device("cpu"), est, gt, P, overlap=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# distributed input (suite_step_dist): every rank starts with 1/world of each cloud, one all-to-all halo exchange
+# ---------------------------------------------------------------------------------------------------------------
+class OracleDistEngine(OracleSlabEngine):
+    """Stand-in for Engine with the distributed-input primitives restated in numpy (host tensors, gloo collectives)."""
+
+    def __init__(self):
+        super().__init__()
+        self.merged = {}
+
+    def transform_points(self, xyz, T):
+        import oracle
+        import torch
+
+        return torch.from_numpy(oracle.transform(xyz.numpy(), T))
+
+    def halo_pack(self, xyz, axis, cuts, halo):
+        import torch
+
+        p = xyz.numpy()
+        v = p[:, axis]
+        segs, counts = [], []
+        for k in range(len(cuts) - 1):
+            keep = (v >= cuts[k] - halo) & (v < cuts[k + 1] + halo)  # the filter of me_set_slab, input order kept
+            segs.append(p[keep])
+            counts.append(int(keep.sum()))
+        return torch.from_numpy(np.concatenate(segs) if segs else np.zeros((0, 3))), counts
+
+    def upload(self, slot, xyz, T=None, cell_size=0.0):
+        super().upload(slot, xyz.numpy() if hasattr(xyz, "numpy") else xyz, T, cell_size)
+
+    def voxel_partial_rows(self, slot, vs):
+        import torch
+
+        k, n, mu, m2 = self.voxel_partials(slot, vs)
+        if len(n) == 0:
+            return torch.zeros((0, 16), dtype=torch.float64)
+        return torch.from_numpy(np.concatenate([k.astype(np.float64), n[:, None].astype(np.float64), mu, m2.reshape(-1, 9)], 1))
+
+    def voxel_merge(self, slot, vs, rows):
+        from cloud_map_evaluation_amd.dist import merge_voxel_partials
+
+        self.merged[slot] = merge_voxel_partials(rows.numpy())
+
+    def calculateVMD(self, vs, rows=False):
+        from cloud_map_evaluation_amd.dist import awd_scs_from_tables
+
+        return awd_scs_from_tables(self, self.merged[0], self.merged[1])
+
+
+def _dist_worker(rank, world, port, est, gt, T, q):
+    import torch
+    import torch.distributed as dist
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Param
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=0.5, initial_matrix_=T)
+        # this rank's part of the input: a contiguous piece of each cloud (rank 1 of a 3-rank job holds NO ground truth at all)
+        be, ee = medist.shard_range(len(est), rank, world)
+        if world == 3:
+            bg, eg = [(0, len(gt) // 2), (0, 0), (len(gt) // 2, len(gt))][rank]
+        else:
+            bg, eg = medist.shard_range(len(gt), rank, world)
+        res = medist.suite_step_dist(OracleDistEngine(), dist, torch.device("cpu"), torch.from_numpy(est[be:ee].copy()),
+                                     torch.from_numpy(gt[bg:eg].copy()), P, rank, world, halo=0.3, overlap=False)
+        q.put((rank, {k: (v if not isinstance(v, dict) else {kk: np.asarray(vv) for kk, vv in v.items()}) for k, v in res.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_input_suite_gloo_equals_single_process_oracle(world):
+    """1/world of each cloud per rank -> slab cuts from two collectives -> all-to-all halo exchange -> local passes ->
+    batched cross-rank resolve -> merged voxel tables: every rank ends with the single-process oracle's answer."""
+    import torch.multiprocessing as mp
+
+    import oracle
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.cube_pair(12000, seed=35)
+    est, gt = est.numpy() * 0.5, gt.numpy()[:11000] * 0.5
+    est = np.concatenate([est, est[:60] + np.array([0.9, 0.0, 1.5])])  # their nearest GT point is in another slab
+    rng = np.random.default_rng(1)
+    est, gt = est[rng.permutation(len(est))], gt[rng.permutation(len(gt))]  # a rank's piece of the file is NOT spatially compact
+    T = np.eye(4)
+    T[:3, 3] = [0.004, -0.003, 0.002]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, est, gt, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    est_t = oracle.transform(est, T)
+    o_eg = oracle.reg_stats(est_t, gt, 1.0, 0, TRUNC)
+    o_ge = oracle.reg_stats(gt, est_t, 1.0, 0, TRUNC)
+    o_me = oracle.mme(est_t, 0.1, 10)
+    o_mg = oracle.mme(gt, 0.1, 5)
+    o_v = oracle.awd_scs(oracle.VoxelMap(gt, 0.5), oracle.VoxelMap(est_t, 0.5))
+    for rank in range(world):
+        r = results[rank]
+        assert r["n_est"] == len(est) and r["n_gt"] == len(gt)
+        assert r["n_cross_rank_queries"] > 0  # the protocol's cross-rank step was exercised
+        for got, exp in ((r["est_gt"], o_eg), (r["gt_est"], o_ge)):
+            assert got["n_corr"] == exp.n_corr
+            assert np.array_equal(got["number"], exp.number)
+            assert np.array_equal(got["fitness"], exp.fitness)
+            for k in ("mean", "rmse", "sigma"):
+                np.testing.assert_allclose(got[k], getattr(exp, k), rtol=1e-12)
+        np.testing.assert_allclose(r["cd"], oracle.chamfer(est_t, gt), rtol=1e-12)
+        assert r["mme_valid"] == o_me[3]
+        np.testing.assert_allclose(r["mme_est"], o_me[0], rtol=1e-12)
+        np.testing.assert_allclose(r["mme_gt"], o_mg[0], rtol=1e-12)
+        assert r["n_w"] == len(o_v["rows"])
+        np.testing.assert_allclose(r["awd"], o_v["awd"], rtol=1e-9)
+        np.testing.assert_allclose(r["scs"], o_v["scs"], rtol=1e-9)
+
+
+def test_dist_slab_cuts_single_process_are_balanced_and_ascending():
+    import torch
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd import synth
+
+    _, gt = synth.cube_pair(50_000, seed=2)
+    axis, cuts = medist.dist_slab_cuts(gt, None, torch.device("cpu"), 4)
+    assert cuts[0] == -np.inf and cuts[-1] == np.inf and all(cuts[i] < cuts[i + 1] for i in range(4))
+    v = gt[:, axis].numpy()
+    share = [((v >= cuts[k]) & (v < cuts[k + 1])).mean() for k in range(4)]
+    assert abs(sum(share) - 1.0) < 1e-12 and max(share) < 0.33  # equal-count slabs (cube faces make the histogram lumpy)
+    assert medist.dist_slab_cuts(gt[:0], None, torch.device("cpu"), 1)[1] == [-np.inf, np.inf]
+    same = torch.ones((100, 3), dtype=torch.float64)
+    _, c = medist.dist_slab_cuts(same, None, torch.device("cpu"), 3)
+    assert all(c[i] < c[i + 1] for i in range(3))

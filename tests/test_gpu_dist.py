@@ -1,0 +1,222 @@
+"""Distributed-input multi-GPU step (north-star shape) exercised on ONE GPU.
+
+1. the device primitives against numpy: the multi-split of the halo exchange (me_halo_pack_device), the exact transform on
+   a raw buffer, the Chan merge of voxel partial rows (me_voxel_merge_device) against the single-context table;
+2. the real driver (cloud_map_evaluation_amd.dist.suite_step_dist) with TWO processes sharing this GPU, each starting with
+   half of each (shuffled) cloud, gloo collectives on the CPU — the code path the 8-GPU run takes with RCCL — against the oracle;
+3. a one-rank `nccl` group with ME_FORCE_COLLECTIVES=1: every collective of the step (all-to-all included) through RCCL on
+   device tensors must reproduce the plain single-GPU step.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TRUNC = (0.2, 0.1, 0.08, 0.05, 0.01)
+
+
+def _scene(n=120_000):
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.campus_pair(n, density=2500.0, seed=5, origin=(100.0, -50.0, 3.0))
+    return est.numpy(), gt.numpy()
+
+
+def test_halo_pack_is_the_numpy_multi_split():
+    import torch
+
+    from cloud_map_evaluation_amd.engine import Engine
+
+    rng = np.random.default_rng(3)
+    p = rng.uniform(-5, 5, (300_001, 3))
+    cuts = [-np.inf, -2.5, -2.4, 0.7, 3.0, np.inf]  # one very thin slab: its halo reaches over several neighbours
+    dev = torch.device("cuda", 0)
+    with Engine(0) as eng:
+        for axis, halo in ((0, 0.3), (2, 0.0), (1, 1.5)):
+            out, counts = eng.halo_pack(torch.from_numpy(p).to(dev), axis, cuts, halo)
+            v = p[:, axis]
+            exp = [p[(v >= cuts[k] - halo) & (v < cuts[k + 1] + halo)] for k in range(5)]
+            assert counts == [len(e) for e in exp]
+            assert np.array_equal(out.cpu().numpy(), np.concatenate(exp))  # destination-major, input order inside a destination
+            if halo == 0.0:
+                assert sum(counts) == len(p)  # without a halo the slabs partition the cloud
+        out, counts = eng.halo_pack(torch.zeros((0, 3), dtype=torch.float64, device=dev), 0, cuts, 0.5)
+        assert counts == [0] * 5 and out.shape == (0, 3)
+        out, counts = eng.halo_pack(torch.from_numpy(p[:77]).to(dev), 1, [-np.inf, np.inf], 0.5)
+        assert counts == [77] and np.array_equal(out.cpu().numpy(), p[:77])
+
+
+def test_transform_points_device_is_the_upload_transform():
+    import torch
+
+    import oracle
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, _ = _scene(20_000)
+    T = np.array([[0.999, -0.02, 0.01, 0.3], [0.02, 0.9995, 0.003, -0.2], [-0.01, -0.003, 0.9999, 0.05], [0, 0, 0, 1.0]])
+    with Engine(0) as eng:
+        got = eng.transform_points(torch.from_numpy(est).to("cuda:0"), T).cpu().numpy()
+    assert np.array_equal(got, oracle.transform(est, T))  # Open3D's operation order, bit for bit
+
+
+def test_voxel_merge_device_reproduces_the_whole_table():
+    import torch
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, gt = _scene()
+    world = 4
+    with Engine(0) as eng:
+        eng.upload(0, est, cell_size=0.1)
+        eng.upload(1, gt, cell_size=0.1)
+        whole = {s: eng.voxel_gaussians(s, 1.0) for s in (0, 1)}
+        whole_v = eng.calculateVMD(1.0)
+        axis, cuts = medist.dist_slab_cuts(torch.from_numpy(gt), None, torch.device("cpu"), world)
+        rows = {0: [], 1: []}
+        for rank in range(world):
+            eng.set_slab(axis, cuts[rank], cuts[rank + 1], 0.5)
+            eng.upload(0, est, cell_size=0.1)
+            eng.upload(1, gt, cell_size=0.1)
+            for s in (0, 1):
+                r = eng.voxel_partial_rows(s, 1.0)
+                # what the padded all-gather delivers: this rank's rows + padding rows (n == 0)
+                rows[s].append(torch.cat([r, torch.zeros((7, 16), dtype=torch.float64, device=r.device)]))
+        for s in (0, 1):
+            eng.voxel_merge(s, 1.0, torch.cat(rows[s]))
+        v = eng.calculateVMD(1.0)  # runs on the merged tables (the clouds are still in slab mode)
+        eng.set_slab(-1)
+        assert v["n_rows"] == whole_v["n_rows"] > 50 and v["counts"] == whole_v["counts"]
+        np.testing.assert_allclose(v["awd"], whole_v["awd"], rtol=1e-10)
+        np.testing.assert_allclose(v["scs"], whole_v["scs"], rtol=1e-10)
+        np.testing.assert_allclose(v["rows"], whole_v["rows"], rtol=1e-6, atol=1e-15)
+        assert np.array_equal(v["rows"][:, :6], whole_v["rows"][:, :6]) and np.array_equal(v["rows"][:, 10:12], whole_v["rows"][:, 10:12])
+        # and the numpy restatement of the merge (dist.merge_voxel_partials, what the CPU stand-in of the gloo tests uses)
+        for s in (0, 1):
+            keys, n, mu, sig = medist.merge_voxel_partials(torch.cat(rows[s]).cpu().numpy())
+            wk, wn, wmu, wsig, _ = whole[s]
+            assert np.array_equal(keys, wk) and np.array_equal(n, wn)
+            np.testing.assert_allclose(mu, wmu, rtol=1e-13)
+        # an empty gather (a cloud nobody holds) leaves an empty table, not an error
+        eng.voxel_merge(0, 1.0, torch.zeros((5, 16), dtype=torch.float64, device="cuda:0"))
+        assert eng.calculateVMD(1.0)["n_rows"] == 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, est, gt, T, q, overlap, backend="gloo"):
+    import torch
+    import torch.distributed as dist
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Engine, Param
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if backend == "nccl":
+        os.environ["ME_FORCE_COLLECTIVES"] = "1"  # one rank, but every collective of the step goes through RCCL
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=1.0, initial_matrix_=T)
+        dev = torch.device("cuda", 0)
+        comm = dev if backend == "nccl" else torch.device("cpu")
+        be, ee = medist.shard_range(len(est), rank, world)
+        bg, eg = medist.shard_range(len(gt), rank, world)
+        with Engine(0) as eng:
+            res = medist.suite_step_dist(eng, dist, comm, torch.from_numpy(est[be:ee].copy()).to(dev),
+                                         torch.from_numpy(gt[bg:eg].copy()).to(dev), P, rank, world, halo=0.5, overlap=overlap)
+        q.put((rank, {k: (v if not isinstance(v, dict) else {kk: np.asarray(vv) for kk, vv in v.items()}) for k, v in res.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_against_oracle(results, est, gt, T, world, min_cross):
+    import oracle
+
+    est_t = oracle.transform(est, T)
+    o_eg = oracle.reg_stats(est_t, gt, 1.0, 0, TRUNC)
+    o_ge = oracle.reg_stats(gt, est_t, 1.0, 0, TRUNC)
+    o_me = oracle.mme(est_t, 0.1, 10)
+    o_mg = oracle.mme(gt, 0.1, 5)
+    o_v = oracle.awd_scs(oracle.VoxelMap(gt, 1.0), oracle.VoxelMap(est_t, 1.0))
+    for rank in range(world):
+        r = results[rank]
+        assert r["n_est"] == len(est) and r["n_gt"] == len(gt)
+        assert r["n_cross_rank_queries"] >= min_cross
+        for got, exp in ((r["est_gt"], o_eg), (r["gt_est"], o_ge)):
+            assert got["n_corr"] == exp.n_corr
+            assert np.array_equal(got["number"], exp.number)          # bit-exact inlier counts
+            for k in ("mean", "rmse", "sigma"):
+                np.testing.assert_allclose(got[k], getattr(exp, k), rtol=1e-9)
+        np.testing.assert_allclose(r["cd"], oracle.chamfer(est_t, gt), rtol=1e-9)
+        assert r["mme_valid"] == o_me[3]
+        np.testing.assert_allclose(r["mme_est"], o_me[0], rtol=1e-9)
+        np.testing.assert_allclose(r["mme_gt"], o_mg[0], rtol=1e-9)
+        assert r["n_w"] == len(o_v["rows"])
+        np.testing.assert_allclose(r["awd"], o_v["awd"], rtol=1e-9)
+        np.testing.assert_allclose(r["scs"], o_v["scs"], rtol=1e-9)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_process_distributed_suite_matches_oracle(overlap):
+    import torch.multiprocessing as mp
+
+    est, gt = _scene(100_000)
+    est = np.concatenate([est, est[:150] + np.array([2.0, 0.0, 30.0])])  # far points: the cross-rank 1-NN step
+    rng = np.random.default_rng(9)
+    est = est[rng.permutation(len(est))]
+    T = np.eye(4)
+    T[:3, 3] = [0.003, -0.002, 0.001]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, est, gt, T, q, overlap)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _check_against_oracle(results, est, gt, T, 2, 100)
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_distributed_step_through_rccl_matches_oracle_and_plain_step():
+    """One GPU: the RCCL calls cannot cross ranks, but a one-rank `nccl` group with ME_FORCE_COLLECTIVES=1 still sends the
+    all-reduces, the all-to-alls and the all-gathers of the step through RCCL on device tensors."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Engine, Param
+
+    est, gt = _scene(60_000)
+    T = np.eye(4)
+    T[:3, 3] = [0.003, -0.002, 0.001]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), est, gt, T, q, True, "nccl"))
+    p.start()
+    rank, r = q.get(timeout=500)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and rank == 0
+    _check_against_oracle({0: r}, est, gt, T, 1, 0)
+    # the plain single-GPU step (no slabs, no process group): counts identical, sums to rounding
+    P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=1.0, initial_matrix_=T)
+    with Engine(0) as eng:
+        ref = medist.suite_step(eng, None, torch.device("cuda", 0), est, gt, P, overlap=True)
+    assert r["mme_valid"] == ref["mme_valid"] and r["n_w"] == ref["n_w"]
+    for d in ("est_gt", "gt_est"):
+        assert np.array_equal(np.asarray(r[d]["number"]), np.asarray(ref[d]["number"]))
+    for k in ("cd", "mme_est", "mme_gt", "awd", "scs"):
+        np.testing.assert_allclose(r[k], ref[k], rtol=1e-12)
