@@ -235,10 +235,12 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
         auto test = [&](const float4 &c, int j) {
             const float u = fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
             const bool hi = u < t_hi;
-            if (__ballot(hi)) {  // some lane may hold this candidate inside its radius
+            const unsigned long long mh = __ballot(hi);
+            if (mh) {  // some lane may hold this candidate inside its radius
                 bool acc = u < t_lo;
                 const double dx = tdx[j] - qx, dy = tdy[j] - qy, dz = tdz[j] - qz;
-                if (__builtin_expect(__ballot(hi != acc) != 0, 0)) {  // a lane in the band: its exact test decides
+                // (both compares land in scalar register pairs: the band test is scalar work, no VALU instruction)
+                if (__builtin_expect(mh != __ballot(acc), 0)) {  // a lane in the band: its exact test decides
                     asm volatile("; band: exact test" ::: "memory");     // (keeps the compiler from evaluating it always)
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
                     acc = acc || (hi && d2 < r2);                        // strict, nanoflann RadiusResultSet [upstream]

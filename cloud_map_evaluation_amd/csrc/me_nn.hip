@@ -247,11 +247,14 @@ __device__ __forceinline__ double octet_min(double v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256)
+constexpr int kNn1Block = 128;  // 16 octets per block: 16 x 18 levels x (8 floats + 9 ints) = 19.6 KB of walk cache
+__global__ void __launch_bounds__(kNn1Block)
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
       OctView oct, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
       const unsigned int *__restrict__ list_count, int use_bound) {
     __shared__ long long s_off[kMaxLevels];
+    __shared__ float s_lb[kNn1Block / 8][kMaxLevels + 1][8];          // per octet, per level: the children's lower bounds
+    __shared__ unsigned int s_beg[kNn1Block / 8][kMaxLevels + 1][9];  // ... and their [begin, end) on the level below
     if (threadIdx.x < kMaxLevels) s_off[threadIdx.x] = oct.off[threadIdx.x];
     __syncthreads();
     const int L = oct.n_levels - 1;  // root level
@@ -274,13 +277,10 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
         } else if (use_bound && alive) {
             best = d2_out[i];  // caller's upper bound (me_nn_points_bounded): only closer points are of interest
         }
-        // scan of one leaf cell by the octets flagged `go` (the shuffles run converged over the whole wave)
-        auto scan_cells = [&](bool go, long long leaf) {
-            long long jb = 0, je = 0;
-            if (go) {
-                jb = nodes[leaf].begin;
-                je = nodes[leaf + 1].begin;
-            }
+        // scan of one run of sorted points [jb, je) (a leaf cell) by the octets flagged `go` (the shuffles run converged over
+        // the whole wave)
+        auto scan_points = [&](bool go, long long jb, long long je) {
+            if (!go) jb = je = 0;
             double lb = best;
             long long li = best_i;
             for (long long j = jb + sub; __ballot(j < je); j += 8) {
@@ -308,31 +308,56 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
             }
         };
         if (L == 0) {
-            scan_cells(alive, 0);  // the whole cloud is one cell
+            scan_points(alive, 0, nr);  // the whole cloud is one cell
         } else {
-            int l = L;          // current node = (l, n); its children live on level l-1
-            long long n = 0;
-            // "children already entered" of the current node of every level on the path: one byte per level
-            unsigned long long taken_lo = 0, taken_hi = 0;  // levels 1..8 / 9..16
+            // Walk state: level l = the level of the node whose CHILDREN (level l-1) are being considered.  Lane `sub` owns
+            // child `sub`: after the one burst that fetches the <= 8 child records (+ the `begin` of the record after
+            // each, i.e. the child's end) it keeps, per level, the child's lower bound (a float rounded DOWN: still a
+            // lower bound) and its [begin, end) in a block-local LDS cache.  Returning to a parent therefore costs no memory
+            // round trip at all (the first version re-fetched the parent's header and its children and recomputed the
+            // bounds: three dependent round trips per node visited), and a descent costs one.  These few hundred far
+            // queries are pure pointer chasing: the kernel's time IS the longest chain of dependent fetches.
+            float *c_lb = s_lb[threadIdx.x >> 3][0];       // [level][8]
+            unsigned int *c_beg = s_beg[threadIdx.x >> 3][0];  // [level][9]: child begins + the end of the last one
+            unsigned long long taken_lo = 0, taken_hi = 0;  // "children already entered" per level: levels 1..8 / 9..16
             double bound = best;  // pruning bound: min(best found, tightest box upper bound seen)
             bool walking = alive;
-            while (__ballot(walking)) {
-                const ONode *__restrict__ me = nodes + s_off[l] + n;
-                const long long cb = me[0].begin;
-                const int cnt = (int) (me[1].begin - cb);  // 1..8 children, contiguous on the level below
-                const unsigned int parent = me[0].parent;
-                // lane `sub` owns child `sub` (the buffer has 8 records of slack: short groups are masked, not skipped)
-                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(nodes + s_off[l - 1] + cb + sub);
+            int l = L;
+            // fetch the children [cb, ce) of a node onto level l's cache line; lane `sub` bounds child `sub`
+            auto open_node = [&](bool go, int lev, long long cb, long long ce) {
+                if (!go) {  // (an idle octet's cb / ce may be POINT indices of the leaf it has just scanned)
+                    cb = ce = 0;
+                    lev = 1;
+                }
+                const int cnt = (int) (ce - cb);
+                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(nodes + s_off[lev - 1] + cb + sub);
+                // (the buffer has 8 records of slack: short groups are masked, not skipped)
                 const float4 a = g[0], bb = g[1];
+                const unsigned int nxt = nodes[s_off[lev - 1] + cb + sub + 1].begin;
                 const float f[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
-                const bool mine = sub < cnt;
-                const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
-                                                 : (unsigned int) (taken_hi >> (8 * (l - 9))) & 0xffu;
+                const bool mine = go && sub < cnt;
                 // every child box also yields an UPPER bound on the answer (some point lies inside it, no farther than
                 // its farthest corner): keeps the depth-first walk from sweeping a wide region on a loose `best`
-                bound = fmin(bound, octet_min(mine ? box_upper_bound(f, qx, qy, qz) : INFINITY));
+                const double ub = octet_min(mine ? box_upper_bound(f, qx, qy, qz) : INFINITY);
                 const double lbd = box_lower_bound(f, qx, qy, qz);
-                const bool ok = mine && !((tk >> sub) & 1u) && lbd <= bound;  // <=: ties may hold a smaller index
+                if (go) {
+                    bound = fmin(bound, ub);
+                    c_lb[lev * 8 + sub] = mine ? __double2float_rd(lbd) : INFINITY;
+                    c_beg[lev * 9 + sub] = __float_as_uint(bb.z);  // ONode::begin
+                    if (sub == 7 || sub == cnt - 1) c_beg[lev * 9 + sub + 1] = nxt;
+                }
+            };
+            {
+                const ONode *__restrict__ root = nodes + s_off[L];
+                open_node(walking, L, root[0].begin, root[1].begin);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            while (__ballot(walking)) {
+                const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
+                                                 : (unsigned int) (taken_hi >> (8 * (l - 9))) & 0xffu;
+                const double lbd = walking ? (double) c_lb[l * 8 + sub] : INFINITY;
+                const bool ok = walking && !((tk >> sub) & 1u) && lbd <= bound;  // <=: ties may hold a smaller index
                 double kd = ok ? lbd : INFINITY;
                 int kc = ok ? sub : 8;
 #pragma unroll
@@ -344,33 +369,35 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                         kc = oc;
                     }
                 }
-                bool go = false;
-                long long leaf = 0;
+                bool go_leaf = false, go_down = false;
+                long long cb = 0, ce = 0;
                 if (walking) {
-                    if (kc >= 8) {  // nothing left under this node: return to the parent
-                        if (l == L) {
-                            walking = false;
-                        } else {
-                            n = parent;
-                            ++l;
-                        }
+                    if (kc >= 8) {  // nothing left under this node: back to the parent's cache line
+                        if (l == L) walking = false;
+                        else ++l;
                     } else {
                         if (l <= 8) taken_lo |= 1ULL << (8 * (l - 1) + kc);
                         else taken_hi |= 1ULL << (8 * (l - 9) + kc);
+                        cb = c_beg[l * 9 + kc];
+                        ce = c_beg[l * 9 + kc + 1];
                         if (l == 1) {
-                            go = true;
-                            leaf = s_off[0] + cb + kc;
+                            go_leaf = true;  // [cb, ce) are the points of a leaf cell
                         } else {
+                            go_down = true;  // [cb, ce) are the chosen child's children, on level l - 2
                             --l;
-                            n = cb + kc;
                             if (l <= 8) taken_lo &= ~(0xffULL << (8 * (l - 1)));  // fresh node on the level below
                             else taken_hi &= ~(0xffULL << (8 * (l - 9)));
                         }
                     }
                 }
-                if (__ballot(go)) {
-                    scan_cells(go, leaf);
+                if (__ballot(go_leaf)) {
+                    scan_points(go_leaf, cb, ce);
                     bound = fmin(bound, best);
+                }
+                if (__ballot(go_down)) {
+                    open_node(go_down, go_down ? l : 1, cb, ce);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
@@ -628,9 +655,9 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         }
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)
-            const unsigned int nbf = (unsigned int) std::min<long long>(nb, 256 * 16);
+            const unsigned int nbf = (unsigned int) std::min<long long>(2LL * nb, 256 * 32);
             TimerScope ts(ctx, "nn1");
-            hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
+            hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
                                r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0);
         }
         if (ctx->timers_on) {  // fallback share, for the bench report
@@ -684,7 +711,7 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
         ME_CHECK(ctx, qi.ensure((size_t) m * 4));
         hipLaunchKernelGGL(k_points_to_sp, dim3(nb), dim3(256), 0, ctx->stream, xyz_device, m, qs.as<SPoint>());
         TimerScope ts(ctx, "nn1");
-        hipLaunchKernelGGL(k_nn1, dim3(std::min<unsigned int>(nb, 256 * 16)), dim3(256), 0, ctx->stream, qs.as<SPoint>(), 0LL, m,
+        hipLaunchKernelGGL(k_nn1, dim3(std::min<unsigned int>(2 * nb, 256 * 32)), dim3(kNn1Block), 0, ctx->stream, qs.as<SPoint>(), 0LL, m,
                            r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
                            (const unsigned int *) nullptr, bounded ? 1 : 0);
     }

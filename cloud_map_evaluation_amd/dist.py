@@ -297,12 +297,41 @@ def _slab_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
 #   2. all-reduce SUM  histogram of the ground truth along that axis       -> equal-count cuts, identical on every rank
 #   3. all-to-all      per-destination point counts (est, gt)              -> split sizes of (4)
 #   4. all-to-all      THE HALO EXCHANGE: [est | gt] points per destination (~2 x 24 B x N / world per rank + halo)
-#   5. all-gather      [open 1-NN queries est, gt; voxel partial rows est, gt; local cloud sizes] per rank
+#   5. all-gather      [open 1-NN queries est, gt; local cloud sizes] per rank
 #   6. all-gather + 7. all-reduce MIN   the open queries and their answers (only when some rank has any: outliers,
 #                      points whose ball crosses the slab's outer faces), both directions in one message
-#   8. all-reduce SUM  the 39 partial sums;   9. all-reduce SUM  the 2 x 5 sigma numerators (need the global means of (8))
+#   8. all-reduce SUM  the 39 partial sums + the per-rank voxel row counts (one-hot);
+#   9. all-reduce SUM  the 2 x 5 sigma numerators (need the global means of (8))
 #  10. all-gather      voxel partial rows of both clouds (one padded message), merged on the device (Chan)
+# Schedule on a rank: the main lane filters + indexes the map and searches map -> ground truth, the second lane does the same
+# for the ground truth and the opposite direction; then the second lane runs both MME passes and the voxel partials (the long,
+# VALU-bound part) WHILE the main lane goes through (5)-(7), whose octree pass and collectives are latency-bound.
 # ---------------------------------------------------------------------------------------------------------------
+class _Trace:
+    """Wall-clock marks between the phases of a distributed step (ME_DIST_TRACE=1 prints them per step: where a rank's time goes
+    between collectives; every engine call ends with a stream synchronisation, so the marks are device-complete)."""
+
+    def __init__(self):
+        import os
+        import time
+
+        self.on = os.environ.get("ME_DIST_TRACE", "0") == "1"
+        self.t = time.perf_counter
+        self.last = self.t()
+        self.marks = []
+
+    def mark(self, name):
+        if self.on:
+            now = self.t()
+            self.marks.append((name, (now - self.last) * 1e3))
+            self.last = now
+
+    def dump(self, rank):
+        if self.on:
+            print(f"[dist trace rank {rank}] " + " ".join(f"{k}={v:.2f}" for k, v in self.marks) +
+                  f" total={sum(v for _, v in self.marks):.2f} ms", flush=True)
+
+
 def _comm(t, comm_device):
     return t if t.device == comm_device else t.to(comm_device)
 
@@ -315,7 +344,7 @@ def dist_slab_cuts(gt_part, dist, comm_device, world: int, bins: int = 8192):
     t = gt_part
     inf = float("inf")
     if t.shape[0]:
-        t = t[::max(1, t.shape[0] * max(world, 1) // 1_000_000)].contiguous()  # ~1 M points in total balance the slabs
+        t = t[::max(1, t.shape[0] * max(world, 1) // 262_144)].contiguous()  # ~256 k points in total balance the slabs
         ext = torch.cat([t.amin(0), -t.amax(0)])
     else:
         ext = torch.full((6,), inf, dtype=torch.float64, device=t.device)
@@ -390,25 +419,29 @@ def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, wor
     split, e.g. a contiguous piece of the file).  Returns the same dict as suite_step on every rank."""
     import torch
 
+    tr = _Trace()
     halo = max(float(halo), 1.0001 * float(P.nn_radius_))
     T = np.asarray(P.initial_matrix_, dtype=np.float64)
     if not np.array_equal(T, np.eye(4)):
         est_part = eng.transform_points(est_part.clone(), T)  # (:1206) before the exchange: slabs are cut in the map frame
     axis, cuts = dist_slab_cuts(gt_part, dist, comm_device, world)
+    tr.mark("cuts")
     est_r, gt_r = halo_exchange(eng, dist, comm_device, [est_part, gt_part], axis, cuts, halo)
+    tr.mark("halo_exchange")
     n_loc = (int(est_part.shape[0]), int(gt_part.shape[0]))
     eng.set_slab(axis, cuts[rank], cuts[rank + 1], halo)
-    # second lane: the ground truth's filter + index, both voxel partial tables, then the ground-truth -> map search (its
-    # latency-bound octree tail runs under the main lane's kernels)
-    lane = _Lane(eng, gt_r, P, True, partials="rows", nn_back="search") if (overlap and hasattr(eng, "twin")) else None
+    lane = _DistLane(eng, gt_r, P, evaluate_gt_mme) if (overlap and hasattr(eng, "twin")) else None
     try:
         eng.upload(ME_SLOT_EST, est_r, cell_size=P.nn_radius_)
         if lane is None:
             eng.upload(ME_SLOT_GT, gt_r, cell_size=P.nn_radius_)
         else:
             lane.est_ready.set()
-        return _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_loc, lane,
-                                  (axis, cuts[rank], cuts[rank + 1], halo))
+        tr.mark("upload_est")
+        res = _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_loc, lane,
+                                 (axis, cuts[rank], cuts[rank + 1], halo), tr)
+        tr.dump(rank)
+        return res
     except BaseException:
         if lane is not None:
             lane.abort()
@@ -424,53 +457,55 @@ def _pad_rows(t, rows: int, width: int, device):
     return out
 
 
-def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_loc, lane, slab):
+def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_loc, lane, slab, tr=None):
     import torch
 
+    tr = tr or _Trace()
     single = _single(dist)
-    # --- MME: exact with halo >= radius ---
-    m_e = m_g = (0.0, 0)
-    if P.evaluate_mme_:
-        m = eng.mme(ME_SLOT_EST, P.nn_radius_, 10, per_point=False)
-        m_e = (m[4], m[3])
-    if lane is not None:
-        lane.wait_gt()
-    if P.evaluate_mme_ and evaluate_gt_mme:
-        m = eng.mme(ME_SLOT_GT, P.nn_radius_, 5, per_point=False)
-        m_g = (m[4], m[3])
-    # --- 1-NN, local part of both directions ---
     dirs = ((ME_SLOT_EST, ME_SLOT_GT), (ME_SLOT_GT, ME_SLOT_EST))
-    cnt = []
-    for q, r in dirs:
-        if lane is not None and lane.nn_back and q == ME_SLOT_GT:
-            lane.join()  # the second lane has searched this direction meanwhile
-            cnt.append(lane.unres_back)
-            continue
-        eng.nn1(q, r, fetch=False)
-        cnt.append(eng.nn_unresolved_count(q))
-    # --- voxel partial rows of the owned points (second lane, or here) ---
-    if lane is not None:
-        lane.join()
-        rows = [lane.rows[ME_SLOT_EST], lane.rows[ME_SLOT_GT]]
+    cnt = [0, 0]
+    m_e = m_g = (0.0, 0)
+    if lane is None:
+        # one lane: MME (exact with halo >= radius), then the local part of both searches
+        if P.evaluate_mme_:
+            m = eng.mme(ME_SLOT_EST, P.nn_radius_, 10, per_point=False)
+            m_e = (m[4], m[3])
+            if evaluate_gt_mme:
+                m = eng.mme(ME_SLOT_GT, P.nn_radius_, 5, per_point=False)
+                m_g = (m[4], m[3])
+        tr.mark("mme")
+        for i, (q, r) in enumerate(dirs):
+            eng.nn1(q, r, fetch=False)
+            cnt[i] = eng.nn_unresolved_count(q)
+        tr.mark("nn1")
     else:
-        rows = [eng.voxel_partial_rows(slot, P.vmd_voxel_size_) for slot in (ME_SLOT_EST, ME_SLOT_GT)]
-    work = rows[0].device
-    # --- collective 5: everybody learns everybody's counts (and the global cloud sizes) ---
-    mine = torch.tensor([cnt[0], cnt[1], rows[0].shape[0], rows[1].shape[0], n_loc[0], n_loc[1]], dtype=torch.int64)
+        # two lanes: this one searches map -> ground truth; the other searches the opposite direction and then runs the MME
+        # passes and the voxel partials UNDER the cross-rank step below
+        lane.wait_gt()
+        tr.mark("wait_gt")
+        eng.nn1(ME_SLOT_EST, ME_SLOT_GT, fetch=False)
+        cnt[0] = eng.nn_unresolved_count(ME_SLOT_EST)
+        tr.mark("nn1")
+        lane.wait_nn()
+        cnt[1] = lane.unres_back
+        tr.mark("wait_nn_back")
+    # --- collective 5: everybody learns everybody's open-query counts (and the global cloud sizes) ---
+    mine = torch.tensor([cnt[0], cnt[1], n_loc[0], n_loc[1]], dtype=torch.int64)
     if single:
         table = mine[None, :]
     else:
-        parts = [torch.empty(6, dtype=torch.int64, device=comm_device) for _ in range(world)]
+        parts = [torch.empty(4, dtype=torch.int64, device=comm_device) for _ in range(world)]
         dist.all_gather(parts, mine.to(comm_device))
         table = torch.stack(parts).cpu()
-    n_e, n_g = int(table[:, 4].sum()), int(table[:, 5].sum())
+    n_e, n_g = int(table[:, 2].sum()), int(table[:, 3].sum())
+    tr.mark("counts")
     # --- collectives 6 + 7: open queries of both directions in one all-gather, their answers in one MIN-reduce ---
     n_cross = int(table[:, 0].sum() + table[:, 1].sum())
     if not single and n_cross > 0:
         cmax = [int(table[:, 0].max()), int(table[:, 1].max())]
-        blocks = [_pad_rows(eng.nn_unresolved(q, with_d2=True) if cnt[i] else None, cmax[i], 4, comm_device)
-                  for i, (q, r) in enumerate(dirs)]
-        msg = torch.cat(blocks)                                   # (cmax_e + cmax_g, 4): xyz + the bound to beat
+        mineq = [eng.nn_unresolved(q, with_d2=True) if cnt[i] else None for i, (q, r) in enumerate(dirs)]
+        wdev = next((t.device for t in mineq if t is not None), comm_device)
+        msg = torch.cat([_pad_rows(mineq[i], cmax[i], 4, comm_device) for i in range(2)])  # xyz + the bound to beat
         parts = [torch.empty_like(msg) for _ in range(world)]
         dist.all_gather(parts, msg)
         allq = torch.stack(parts)                                 # (world, cmax_e + cmax_g, 4)
@@ -480,7 +515,7 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
             sel = [(k, int(table[k, i])) for k in range(world) if k != rank and int(table[k, i]) > 0]
             if sel:
                 qs = torch.cat([allq[k, base:base + c] for k, c in sel])
-                ans = eng.nn_points(r, qs[:, :3].contiguous().to(work), bound=qs[:, 3].contiguous().to(work)).to(comm_device)
+                ans = eng.nn_points(r, qs[:, :3].contiguous().to(wdev), bound=qs[:, 3].contiguous().to(wdev)).to(comm_device)
                 o = 0
                 for k, c in sel:
                     d2[k, base:base + c] = ans[o:o + c]
@@ -492,11 +527,25 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         base = 0
         for i, (q, r) in enumerate(dirs):
             if cnt[i]:
-                eng.nn_patch(q, d2[rank, base:base + cnt[i]].contiguous().to(work))
+                eng.nn_patch(q, d2[rank, base:base + cnt[i]].contiguous().to(wdev))
             base += cmax[i]
-    # --- collectives 8 + 9: partial sums, then the sigma numerators (second pass of map_eval.cpp:1132-1138) ---
+    tr.mark("cross_rank_nn")
     parts = [eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_) for q, r in dirs]
-    vec = all_reduce_sum(pack_partials(parts, m_e, m_g), dist, comm_device)
+    tr.mark("nn_sums")
+    # --- the other lane's products: MME sums and the voxel partial rows of the owned points ---
+    if lane is not None:
+        lane.join()
+        m_e, m_g = lane.m_e, lane.m_g
+        rows = [lane.rows[ME_SLOT_EST], lane.rows[ME_SLOT_GT]]
+    else:
+        rows = [eng.voxel_partial_rows(slot, P.vmd_voxel_size_) for slot in (ME_SLOT_EST, ME_SLOT_GT)]
+    tr.mark("join_lane")
+    # --- collectives 8 + 9: partial sums, then the sigma numerators (second pass of map_eval.cpp:1132-1138); the per-rank
+    #     voxel row counts ride on (8) as one-hot entries (exact in fp64), so the gather (10) needs no size exchange ---
+    onehot = np.zeros(2 * world)
+    onehot[rank], onehot[world + rank] = rows[0].shape[0], rows[1].shape[0]
+    vec = all_reduce_sum(np.concatenate([pack_partials(parts, m_e, m_g), onehot]), dist, comm_device)
+    vrows = vec[VEC_LEN:]
     sig_local = []
     for i, (q, r) in enumerate(dirs):
         C = vec[i * _DIR]
@@ -508,11 +557,12 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     o = 2 * _DIR
     mme_est = vec[o] / vec[o + 1] if vec[o + 1] > 0 else 0.0
     mme_gt = vec[o + 2] / vec[o + 3] if vec[o + 3] > 0 else 0.0
+    tr.mark("stats")
     # --- collective 10: voxel partial rows of both clouds in one padded all-gather, merged on the device ---
     if single:
         gathered = rows
     else:
-        vmax = [max(int(table[:, 2].max()), 1), max(int(table[:, 3].max()), 1)]
+        vmax = [max(int(vrows[:world].max()), 1), max(int(vrows[world:].max()), 1)]
         msg = torch.cat([_pad_rows(rows[0], vmax[0], 16, comm_device), _pad_rows(rows[1], vmax[1], 16, comm_device)])
         parts = [torch.empty_like(msg) for _ in range(world)]
         dist.all_gather(parts, msg)
@@ -520,10 +570,76 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         gathered = [allr[:, :vmax[0]].reshape(-1, 16), allr[:, vmax[0]:].reshape(-1, 16)]
     for slot, g in zip((ME_SLOT_EST, ME_SLOT_GT), gathered):
         eng.voxel_merge(slot, P.vmd_voxel_size_, g.contiguous())
+    tr.mark("voxel_gather_merge")
     v = eng.calculateVMD(P.vmd_voxel_size_, rows=False)
+    tr.mark("awd_scs")
     return dict(est_gt=s_eg, gt_est=s_ge, ac=s_eg["rmse"], com=s_eg["fitness"], cd=s_eg["mean_nn"] + s_ge["mean_nn"],
                 mme_est=mme_est, mme_gt=mme_gt, mme_valid=int(vec[o + 1]), awd=v["awd"], scs=v["scs"], n_w=v["n_rows"],
                 n_est=n_e, n_gt=n_g, n_cross_rank_queries=n_cross, slab=slab)
+
+
+class _DistLane:
+    """Second lane of the DISTRIBUTED step (a host thread on the engine's twin context).  It uploads (filters + indexes) the
+    ground truth, searches ground truth -> map, then runs BOTH MME passes and builds both voxel partial tables — the long,
+    VALU-bound part — while the main lane searches map -> ground truth and then sits in the cross-rank 1-NN step (collectives
+    and a latency-bound octree pass): the exchange hides under the MME kernels."""
+
+    def __init__(self, eng, gt, P, evaluate_gt_mme):
+        import threading
+
+        self.err = None
+        self.rows = {}
+        self.m_e = self.m_g = (0.0, 0)
+        self.unres_back = 0
+        self.gt_ready, self.est_ready, self.nn_done = threading.Event(), threading.Event(), threading.Event()
+        self._t = threading.Thread(target=self._run, args=(eng.twin(), gt, P, evaluate_gt_mme), daemon=True)
+        self._t.start()
+
+    def _run(self, lane, gt, P, evaluate_gt_mme):
+        try:
+            lane.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
+            self.gt_ready.set()
+            self.est_ready.wait()
+            if self.err is not None:
+                return
+            lane.nn1(ME_SLOT_GT, ME_SLOT_EST, fetch=False)
+            self.unres_back = lane.nn_unresolved_count(ME_SLOT_GT)
+            self.nn_done.set()
+            if P.evaluate_mme_:
+                m = lane.mme(ME_SLOT_EST, P.nn_radius_, 10, per_point=False)
+                self.m_e = (m[4], m[3])
+                if evaluate_gt_mme:
+                    m = lane.mme(ME_SLOT_GT, P.nn_radius_, 5, per_point=False)
+                    self.m_g = (m[4], m[3])
+            for slot in (ME_SLOT_EST, ME_SLOT_GT):
+                self.rows[slot] = lane.voxel_partial_rows(slot, P.vmd_voxel_size_)
+        except BaseException as e:  # re-raised by the waits
+            self.err = e
+        finally:
+            self.gt_ready.set()
+            self.nn_done.set()
+
+    def _check(self):
+        if self.err is not None:
+            raise self.err
+
+    def wait_gt(self):
+        self.gt_ready.wait()
+        self._check()
+
+    def wait_nn(self):
+        self.nn_done.wait()
+        self._check()
+
+    def abort(self):
+        self.err = self.err or RuntimeError("main lane failed")
+        self.est_ready.set()
+        self._t.join()
+
+    def join(self):
+        self.est_ready.set()
+        self._t.join()
+        self._check()
 
 
 class _Lane:

@@ -196,7 +196,7 @@ enable_debug: true
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     txt = open(est_dir / "map_results" / "map_results.txt").read()
     ref = _cpu_icp(est, gt, 0.3)
-    m = re.search(r"Aligned cloud: ((?:[-\d.e+]+\s+){16})", txt)
+    m = re.search(r"Aligned cloud:\s+((?:[-\d.e+]+\s+){16})", txt)
     assert m, txt
     Th = np.array([float(v) for v in m.group(1).split()]).reshape(4, 4)
     np.testing.assert_allclose(Th, ref["transformation"], atol=2e-5)  # 5 decimals in the file
@@ -271,7 +271,7 @@ def test_host_point_to_plane_and_generalized_icp(tmp_path, method):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     txt = open(est_dir / "map_results" / "map_results.txt").read()
     ref = oracle.registration_icp(method, est, gt, 0.5, tgt_normals=n_gt)
-    m = re.search(r"Aligned cloud: ((?:[-\d.e+]+\s+){16})", txt)
+    m = re.search(r"Aligned cloud:\s+((?:[-\d.e+]+\s+){16})", txt)
     Th = np.array([float(v) for v in m.group(1).split()]).reshape(4, 4)
     np.testing.assert_allclose(Th, ref["transformation"], atol=2e-5)  # 5 decimals in the file
     m = re.search(r"Aligned results: ([\d.]+) (\d+)", txt)
