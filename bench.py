@@ -362,8 +362,8 @@ def main():
         est_p, gt_p = est_h.pin_memory(), gt_h.pin_memory()
         h_ms, h_res = timed(est_p, gt_p, max(2, min(3, args.steps)), 1)
         line["h2d_inclusive"] = {"ms_per_step": h_ms, "value": (n_e + n_g) / 1e6 / (h_ms / 1e3), "unit": "Mpts/s",
-                                 "note": "same step with both clouds starting in pinned host memory (2 x 24 B/pt over PCIe Gen5, "
-                                         "uploads of the two clouds on the two lanes) and every scalar back on the host",
+                                 "note": "same step with both clouds starting in pinned host memory (2 x 24 B/pt over PCIe Gen5; the "
+                                         "ground truth crosses the link under the map's MME kernel) and every scalar back on the host",
                                  "bytes_h2d": 24 * (n_e + n_g),
                                  "same_results": bool(h_res["mme_valid"] == res["mme_valid"] and h_res["cd"] == res["cd"])}
         del est_p, gt_p

@@ -727,7 +727,10 @@ def suite_step(eng, dist, device, est, gt, P, evaluate_gt_mme: bool = True, uplo
     if overlap and upload and hasattr(eng, "twin"):
         import os
 
-        lane = _Lane(eng, gt, P, True, after_est=os.environ.get("ME_LANE_AFTER_EST", "0") == "1",
+        # clouds that start in HOST memory: the two uploads would share the PCIe link; one after the other, the ground truth
+        # crosses it under the map's MME kernel instead (after_est).  Device-resident clouds: both lanes start at once.
+        host_input = not bool(getattr(gt, "is_cuda", False))
+        lane = _Lane(eng, gt, P, True, after_est=os.environ.get("ME_LANE_AFTER_EST", "1" if host_input else "0") == "1",
                      nn_back=os.environ.get("ME_LANE_NN_BACK", "1") == "1")
     try:
         if upload:

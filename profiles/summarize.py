@@ -30,7 +30,20 @@ def short(name: str) -> str:
     return re.sub(r"\(.*", "", name)[:80]
 
 
-def main(src, out):
+def kernel_source_sha(root="."):
+    """The fingerprint bench.py compares (bench.kernel_source_sha): sha1 over cloud_map_evaluation_amd/csrc/*.hip|*.hpp."""
+    import hashlib
+    import os
+
+    h = hashlib.sha1()
+    d = os.path.join(root, "cloud_map_evaluation_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def main(src, out, tag="r02"):
     rows = defaultdict(lambda: [0, 0.0])
     for f in glob.glob(f"{src}/stats/*/*_kernel_stats.csv"):
         for r in csv.DictReader(open(f)):
@@ -63,8 +76,11 @@ def main(src, out):
         d["hbm_bytes_per_launch_fetch_x2"] = 2 * f_ + w_
     json.dump(traffic, open(out + "_hbm_traffic.json", "w"), indent=1, sort_keys=True)
     # per-family figure bench.py reports as roofline.traffic (raw FETCH+WRITE per launch)
-    fam = {k.replace("me::k_", ""): v["hbm_bytes_per_launch_raw"] for k, v in traffic.items()
-           if k in ("me::k_nn_grid", "me::k_mme", "me::k_nn1")}
+    fam = {{"me::k_mme3": "mme"}.get(k, k.replace("me::k_", "")): v["hbm_bytes_per_launch_raw"] for k, v in traffic.items()
+           if k in ("me::k_nn_grid", "me::k_mme", "me::k_mme3", "me::k_nn1")}
+    # provenance: bench.py quotes these figures only for the kernel sources and the workload they were collected with
+    fam["_kernel_source_sha"] = kernel_source_sha()
+    fam["_workload"], fam["_points"], fam["_tag"] = "c4_multisession", 50_000_000, tag
     fam["_note"] = ("HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes "
                     "(<tag>_hbm_traffic.json also lists the gfx950 FETCH x2 figure); workload = bench.py default")
     json.dump(fam, open(out + "_traffic.json", "w"), indent=1)
@@ -74,7 +90,7 @@ def main(src, out):
         for f in glob.glob(f"{src}/{sub}/*/*_counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
-                if k in ("me::k_nn_grid", "me::k_mme", "me::k_nn1"):
+                if k in ("me::k_nn_grid", "me::k_mme", "me::k_mme3", "me::k_nn1"):
                     sq[k][r["Counter_Name"]] += float(r["Counter_Value"])
     sqo = {}
     for k, d in sq.items():
@@ -86,8 +102,8 @@ def main(src, out):
     json.dump(sqo, open(out + "_sq_per_wave.json", "w"), indent=1, sort_keys=True)
     print(json.dumps(sqo, indent=1, sort_keys=True))
     print(open(out + "_kernel_stats.csv").read()[:1500])
-    print(json.dumps({k: v for k, v in traffic.items() if k in ("me::k_nn1", "me::k_mme")}, indent=1))
+    print(json.dumps({k: v for k, v in traffic.items() if k in ("me::k_nn1", "me::k_mme3", "me::k_nn_grid")}, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "r02")
