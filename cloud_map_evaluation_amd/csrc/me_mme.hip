@@ -179,16 +179,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
 k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
        GridView g, FrameView fr, SlabView slab, double r2, int min_k, double *__restrict__ ent_s,
        unsigned char *__restrict__ valid_s, double *__restrict__ part_sum, long long *__restrict__ part_cnt,
-       unsigned int xcd_chunk) {
+       unsigned int xcd_chunk, int dbg, double cell_h, float thr_lo, float thr_hi) {
+    // cell_h = edge of a radius-grid cell; thr_lo / thr_hi = r^2 -+ E in FP32 (E = 2^-12 cell_h^2): kernel arguments, i.e.
+    // scalar registers for the whole kernel (computed in the kernel they lived in VGPRs and were spilled around the loop).
+    // dbg: profiling switches (profiles/README.md) — 1: no candidate streaming at all, 2: pre-test only, nothing accepted.
     static_assert(TILE * 16 >= kGroupRows * 4, "the row masks of the cull alias the FP32 tile");
     const unsigned int vb = xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);
     const unsigned int loc = vb * blockDim.x + threadIdx.x;
     bool active = i_begin + (long long) loc < i_end;
     const int shift3 = 3 * g.shift;
     const int cell_lim = 1 << (kMortonBits - g.shift);
-    const double cell_h = ldexp(fr.fine_h, g.shift);
-    const float r2f = (float) r2;
-    const float band = (float) (0x1p-12 * cell_h * cell_h);
 
     double qx = 0, qy = 0, qz = 0;
     unsigned long long mycell = ~0ULL;
@@ -210,7 +210,7 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
     __shared__ int2 s_tab[4][kGroupTab + 1];
     __shared__ float4 s_tf[4][TILE];     // FP32 records of the staged run (the cull's row masks while the table is built)
     __shared__ double s_td[4][3][TILE];  // its fp64 coordinates, one array per axis
-    const int wv = threadIdx.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));  // scalar: the wave's LDS bases stay out of VGPRs
     int2 *tab = s_tab[wv];
     float4 *tf = s_tf[wv];
     double *tdx = s_td[wv][0], *tdy = s_td[wv][1], *tdz = s_td[wv][2];
@@ -231,8 +231,8 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
         const float ax = (float) (-2.0 * (qx - ox)), ay = (float) (-2.0 * (qy - oy)), az = (float) (-2.0 * (qz - oz));
         const float s = fmaf(az, az, fmaf(ay, ay, ax * ax));
         // (the group predicate rides on the thresholds: lanes outside the group accept nothing)
-        const float t_hi = in ? fmaf(-0.25f, s, r2f + band) : -INFINITY;
-        const float t_lo = in ? fmaf(-0.25f, s, r2f - band) : -INFINITY;
+        const float t_hi = (in && dbg != 2) ? fmaf(-0.25f, s, thr_hi) : -INFINITY;
+        const float t_lo = (in && dbg != 2) ? fmaf(-0.25f, s, thr_lo) : -INFINITY;
         int k = 0;
         double s1x = 0, s1y = 0, s1z = 0;
         double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
@@ -263,7 +263,7 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 }
             }
         };
-        wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) {
+        if (dbg != 1) wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) {
             for (int base = cs; base < ce; base += TILE) {
                 const int n = min(TILE, ce - base);
                 if (lane < n) {
@@ -327,7 +327,9 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 ok = true;
             }
         }
-        const long long i = i_begin + (long long) loc;
+        unsigned int loc_e = loc;
+        asm volatile("" : "+v"(loc_e));  // (recomputed, not carried: the 64-bit index was spilled across the whole kernel)
+        const long long i = i_begin + (long long) loc_e;
         ent_s[i] = H;                       // 0.0 where invalid (:1614)
         valid_s[i] = ok ? 1 : 0;
     }
@@ -418,6 +420,9 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
         static const int waves = std::getenv("ME_MME_WAVES") ? std::atoi(std::getenv("ME_MME_WAVES")) : 8;
         static const int tile = std::getenv("ME_MME_TILE") ? std::atoi(std::getenv("ME_MME_TILE")) : 32;
         const FrameView fr{c.origin[0], c.origin[1], c.origin[2], c.fine_h};
+        static const int dbg = std::getenv("ME_MME_DBG") ? std::atoi(std::getenv("ME_MME_DBG")) : 0;
+        const float band = (float) (0x1p-12 * c.cell_h * c.cell_h);  // E, see k_mme3
+        const float thr_lo = (float) r2 - band, thr_hi = (float) r2 + band;
         TimerScope ts(ctx, "mme");
         if (variant == 1) {
             hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
@@ -426,7 +431,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
 #define ME_LAUNCH_MME3(T, W)                                                                                                  \
     hipLaunchKernelGGL((k_mme3<T, W>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),                                \
                        c.codes.as<unsigned long long>(), b, e, c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(),             \
-                       val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting())
+                       val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), dbg, c.cell_h, thr_lo, thr_hi)
             if (tile == 32 && waves >= 8) ME_LAUNCH_MME3(32, 8);
             else if (tile == 32) ME_LAUNCH_MME3(32, 7);
             else if (waves >= 7) ME_LAUNCH_MME3(64, 7);
