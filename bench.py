@@ -101,7 +101,7 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:12]
 
 
-def suite_step(eng, dist, world, est_d, gt_d, P, evaluate_gt_mme):
+def suite_step(eng, dist, world, est_d, gt_d, P, evaluate_gt_mme, comm_dev=None):
     """One full pass; returns the scalars.  All ranks run it (cloud_map_evaluation_amd/dist.py)."""
     import torch
 
@@ -110,7 +110,7 @@ def suite_step(eng, dist, world, est_d, gt_d, P, evaluate_gt_mme):
     dev = torch.device("cuda", torch.cuda.current_device())
     if world > 1:
         # est_d / gt_d are this rank's 1/N of the clouds: slabs + one all-to-all halo exchange
-        return medist.suite_step_dist(eng, dist, dev, est_d, gt_d, P, dist.get_rank(), world, evaluate_gt_mme, halo=1.0)
+        return medist.suite_step_dist(eng, dist, comm_dev or dev, est_d, gt_d, P, dist.get_rank(), world, evaluate_gt_mme, halo=1.0)
     # single GPU: the HBM-bound stages (index of the ground truth, both voxel tables) run on the engine's second lane
     # under the VALU-bound MME / 1-NN kernels (dist._Lane); same calls, same results
     return medist.suite_step(eng, None, dev, est_d, gt_d, P, evaluate_gt_mme, overlap=OVERLAP)
@@ -223,15 +223,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # (test hooks, tests/test_gpu_dist.py: ME_BENCH_BACKEND=gloo + ME_BENCH_SINGLE_DEVICE=1 run the N > 1 path with several ranks
+    #  on ONE GPU — RCCL refuses two ranks on a device; the driver's runs use neither)
+    backend = os.environ.get("ME_BENCH_BACKEND", "nccl")
+    if os.environ.get("ME_BENCH_SINGLE_DEVICE", "0") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from cloud_map_evaluation_amd.engine import Engine, Param
 
@@ -264,15 +270,15 @@ def main():
     def timed(est, gt, steps, warmup):
         res = None
         for _ in range(warmup):
-            res = suite_step(eng, dist, world, est, gt, P, evaluate_gt_mme)
+            res = suite_step(eng, dist, world, est, gt, P, evaluate_gt_mme, comm_dev)
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
-            res = suite_step(eng, dist, world, est, gt, P, evaluate_gt_mme)
+            res = suite_step(eng, dist, world, est, gt, P, evaluate_gt_mme, comm_dev)
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt / max(1, steps) * 1e3, res
@@ -304,7 +310,7 @@ def main():
         eng.timers_enable(True)
         eng.timers_reset()
         OVERLAP = False  # kernels timed one at a time
-        suite_step(eng, dist, world, est_d, gt_d, P, evaluate_gt_mme)
+        suite_step(eng, dist, world, est_d, gt_d, P, evaluate_gt_mme, comm_dev)
         OVERLAP = not args.no_overlap
         fam = {}
         for name in ("nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "slab_filter", "voxel",

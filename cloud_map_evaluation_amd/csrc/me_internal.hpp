@@ -569,7 +569,10 @@ constexpr int kGroupRows = 128;  // LDS ints per wave for the CULL row masks (64
 
 // Calls f(begin, end, slot) once per non-empty run of the wave's table, with WAVE-UNIFORM arguments (so that a loop over
 // [begin, end) fetches candidates with scalar loads and all lanes test the same candidate); slot = its table index.
-template <class F>
+// MERGE: consecutive table slots whose runs are contiguous in the sorted array (x and x + 1 with x even are neighbours in
+// Morton order) are handed over as ONE run — with 6-point cells the per-run set-up of the 1-NN grid kernel (staging a tile,
+// two barriers, the tail of the group-of-four loop) costs more than ranking the run's candidates.
+template <bool MERGE = false, class F>
 __device__ __forceinline__ void wave_for_each_run(const int2 *tab, int n_keys, int lane, F &&f) {
     for (int base = 0; base < n_keys; base += 64) {
         const int t = base + lane;
@@ -579,7 +582,17 @@ __device__ __forceinline__ void wave_for_each_run(const int2 *tab, int n_keys, i
             const int n = __ffsll((long long) m) - 1;
             m &= m - 1;
             const int2 run = tab[base + n];
-            const int cs = __builtin_amdgcn_readfirstlane(run.x), cc = __builtin_amdgcn_readfirstlane(run.y);
+            const int cs = __builtin_amdgcn_readfirstlane(run.x);
+            int cc = __builtin_amdgcn_readfirstlane(run.y);
+            if (MERGE) {
+                while (m) {
+                    const int n2 = __ffsll((long long) m) - 1;
+                    const int2 nx = tab[base + n2];
+                    if (__builtin_amdgcn_readfirstlane(nx.x) != cs + cc) break;
+                    cc += __builtin_amdgcn_readfirstlane(nx.y);
+                    m &= m - 1;
+                }
+            }
             f(cs, cs + cc, base + n);
         }
     }

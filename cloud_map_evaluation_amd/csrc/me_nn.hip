@@ -179,7 +179,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             az = (float) (-2.0 * (qz - oz));
         }
         bias = in ? 0.0f : INFINITY;
-        wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) { stream_run(cs, ce); });
+        wave_for_each_run<true>(tab, nk, lane, [&](int cs, int ce, int) { stream_run(cs, ce); });
         if (in) done = true;
         __builtin_amdgcn_wave_barrier();
     }

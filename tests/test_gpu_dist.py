@@ -220,3 +220,36 @@ def test_one_rank_distributed_step_through_rccl_matches_oracle_and_plain_step():
         assert np.array_equal(np.asarray(r[d]["number"]), np.asarray(ref[d]["number"]))
     for k in ("cd", "mme_est", "mme_gt", "awd", "scs"):
         np.testing.assert_allclose(r[k], ref[k], rtol=1e-12)
+
+
+@pytest.mark.timeout(900)
+def test_bench_py_two_rank_path_runs_end_to_end():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with both ranks on this one
+    GPU and gloo collectives (test hooks; RCCL refuses two ranks on a device): the line it prints must carry the contract's
+    fields and the same scalars as the single-GPU run of the same workload."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "campus", "--points", "400000", "--steps", "2", "--warmup", "1", "--cpu-baseline", "off", "--no-h2d"]
+    env = dict(os.environ, ME_BENCH_BACKEND="gloo", ME_BENCH_SINGLE_DEVICE="1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                        capture_output=True, text=True, timeout=800, env=env, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    line2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=800, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    line1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in line2, k
+    assert line2["n_gpus"] == 2 and line1["n_gpus"] == 1 and line2["scaling"] == "strong" and line2["steps"] == 2
+    assert line2["config"]["n_est"] == line1["config"]["n_est"] == 400000  # the whole job's size, not a rank's share
+    ra, rb = line1["results"], line2["results"]
+    assert ra["MME_valid"] == rb["MME_valid"] and ra["W_voxels"] == rb["W_voxels"]
+    assert ra["COM"] == rb["COM"]  # inlier counts / N: bit-exact across the two drivers
+    for k in ("CD", "MME_est", "MME_gt", "AWD", "SCS"):
+        np.testing.assert_allclose(rb[k], ra[k], rtol=1e-9)
+    np.testing.assert_allclose(rb["AC"], ra["AC"], rtol=1e-9)
