@@ -152,6 +152,12 @@ int me_upload_cloud_device(me_ctx *ctx, int slot, const double *xyz_device, int6
     return me::cloud_upload(ctx, slot, xyz_device, true, n, T, cell_size);
 }
 
+int me_upload_slab_device(me_ctx *ctx, int slot, const double *xyz_device, int64_t n, double cell_size) {
+    if (!ctx) return ME_ERR_ARG;
+    if (ctx->slab.axis < 0) return ctx->fail(ME_ERR_STATE, "me_upload_slab_device: call me_set_slab first");
+    return me::cloud_upload(ctx, slot, xyz_device, true, n, nullptr, cell_size, true);
+}
+
 int64_t me_cloud_size(me_ctx *ctx, int slot) {
     if (!ctx || slot < 0 || slot > 1 || !ctx->cloud[slot].uploaded) return -1;
     return ctx->cloud[slot].n;

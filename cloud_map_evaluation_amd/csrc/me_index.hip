@@ -323,8 +323,22 @@ static int build_grid_table(me_ctx *ctx, Cloud &c, int shift, GridTable &t, Grid
 // host side
 // ------------------------------------------------------------------------------------------------------------
 int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, long long n, const double *T,
-                 double cell_size) {
+                 double cell_size, bool prefiltered) {
     if (slot < 0 || slot > 1) return ctx->fail(ME_ERR_ARG, "slot must be ME_SLOT_EST (0) or ME_SLOT_GT (1)");
+    if (prefiltered && n == 0) {  // this rank's slab (+ halo) holds nothing of this cloud: every pass returns empty partials
+        ME_CHECK(ctx, hipSetDevice(ctx->device));
+        Cloud &e = ctx->cloud[slot];
+        e.n = e.n_total = 0;
+        e.slab = ctx->slab;
+        e.n_unres = 0;
+        e.uploaded = true;
+        e.index_valid = false;
+        e.nn_ref_slot = -1;
+        e.vox_valid = e.vox_merged = false;
+        e.have_normals = e.have_cov = false;
+        ctx->cloud[1 - slot].nn_ref_slot = -1;
+        return ME_OK;
+    }
     if (!src) return ctx->fail(ME_ERR_ARG, "xyz is NULL");
     if (n <= 0) return ctx->fail(ME_ERR_ARG, "point cloud is empty");  // map_eval.cpp:32-35 returns -1
     if (n >= (1LL << 31)) return ctx->fail(ME_ERR_ARG, "point count must be < 2^31 (the reference indexes with int)");
@@ -345,7 +359,9 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
     c.slab = ctx->slab;
     c.n_unres = 0;
     bool bbox_ready = false;
-    if (ctx->slab.axis < 0 && src_on_device) {
+    // prefiltered: slab mode, but the caller guarantees that every point lies inside [reg_lo, reg_hi) (the halo exchange
+    // delivered exactly those): the flag / scan / compact filter and its host round trip are skipped
+    if ((ctx->slab.axis < 0 || prefiltered) && src_on_device) {
         // one pass: copy + transform + bounding-box partials
         ME_CHECK(ctx, c.xyz.ensure((size_t) n * 3 * sizeof(double)));
         const unsigned int nb = (unsigned int) std::min<long long>(1024, (n + 255) / 256);

@@ -252,7 +252,7 @@ int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n);
 
 // ---- me_index.hip ----
 int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, long long n, const double *T,
-                 double cell_size);
+                 double cell_size, bool prefiltered = false);
 int cloud_build_index(me_ctx *ctx, int slot, double cell_size);
 int cloud_finish(me_ctx *ctx, int slot, bool bbox_ready = false);
 int cloud_transform(me_ctx *ctx, int slot, const double *T);

@@ -293,19 +293,19 @@ def _slab_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
 # Distributed input (the north-star shape): every rank starts with 1/world of each cloud; ONE all-to-all
 # moves every point to the rank that owns its slab or needs it as halo; after that a rank touches ~1/world of the data only.
 # Collectives of a step, in dependency order (all but the halo payload are a few hundred bytes):
-#   1. all-reduce MIN  [bbox_lo, -bbox_hi] of the ground truth            -> the slab axis (longest extent)
-#   2. all-reduce SUM  histogram of the ground truth along that axis       -> equal-count cuts, identical on every rank
-#   3. all-to-all      per-destination point counts (est, gt)              -> split sizes of (4)
-#   4. all-to-all      THE HALO EXCHANGE: [est | gt] points per destination (~2 x 24 B x N / world per rank + halo)
-#   5. all-gather      [open 1-NN queries est, gt; local cloud sizes] per rank
-#   6. all-gather + 7. all-reduce MIN   the open queries and their answers (only when some rank has any: outliers,
+#   1. all-gather      a fixed-size sample of every rank's ground-truth points -> the slab axis (longest extent) and the
+#                      equal-count cuts (quantiles of the sorted sample), identical on every rank
+#   2. all-to-all      per-destination point counts (est, gt)              -> split sizes of (3)
+#   3. all-to-all      THE HALO EXCHANGE: [est | gt] points per destination (~2 x 24 B x N / world per rank + halo)
+#   4. all-gather      [open 1-NN queries est, gt; local cloud sizes] per rank
+#   5. all-gather + 6. all-reduce MIN   the open queries and their answers (only when some rank has any: outliers,
 #                      points whose ball crosses the slab's outer faces), both directions in one message
-#   8. all-reduce SUM  the 39 partial sums + the per-rank voxel row counts (one-hot);
-#   9. all-reduce SUM  the 2 x 5 sigma numerators (need the global means of (8))
-#  10. all-gather      voxel partial rows of both clouds (one padded message), merged on the device (Chan)
+#   7. all-reduce SUM  the 39 partial sums + the per-rank voxel row counts (one-hot);
+#   8. all-reduce SUM  the 2 x 5 sigma numerators (need the global means of (7))
+#   9. all-gather      voxel partial rows of both clouds (one padded message), merged on the device (Chan)
 # Schedule on a rank: the main lane filters + indexes the map and searches map -> ground truth, the second lane does the same
 # for the ground truth and the opposite direction; then the second lane runs both MME passes and the voxel partials (the long,
-# VALU-bound part) WHILE the main lane goes through (5)-(7), whose octree pass and collectives are latency-bound.
+# VALU-bound part) WHILE the main lane goes through (4)-(6), whose octree pass and collectives are latency-bound.
 # ---------------------------------------------------------------------------------------------------------------
 class _Trace:
     """Wall-clock marks between the phases of a distributed step (ME_DIST_TRACE=1 prints them per step: where a rank's time goes
@@ -336,50 +336,56 @@ def _comm(t, comm_device):
     return t if t.device == comm_device else t.to(comm_device)
 
 
-def dist_slab_cuts(gt_part, dist, comm_device, world: int, bins: int = 8192):
+def dist_slab_cuts(gt_part, dist, comm_device, world: int, sample: int = 16384):
     """Equal-count slab faces along the longest axis of the GLOBAL ground-truth cloud, from each rank's part of it.
-    Returns (axis, cuts[world + 1]) with cuts[0] = -inf, cuts[-1] = +inf; identical on every rank (collectives 1 and 2)."""
+    Returns (axis, cuts[world + 1]) with cuts[0] = -inf, cuts[-1] = +inf; identical on every rank.
+    ONE collective: every rank contributes a fixed-size strided sample of its points (NaN-padded when it holds fewer), the
+    all-gathered sample gives the extent (-> axis) and, sorted along that axis, the cuts at its k/world quantiles."""
     import torch
 
-    t = gt_part
     inf = float("inf")
-    if t.shape[0]:
-        t = t[::max(1, t.shape[0] * max(world, 1) // 262_144)].contiguous()  # ~256 k points in total balance the slabs
-        ext = torch.cat([t.amin(0), -t.amax(0)])
-    else:
-        ext = torch.full((6,), inf, dtype=torch.float64, device=t.device)
-    if not _single(dist):
-        ext = _all_reduce(ext, dist, comm_device, dist.ReduceOp.MIN)
-    e = ext.tolist()
-    mn, mx = e[:3], [-x for x in e[3:]]
-    axis = int(np.argmax([mx[d] - mn[d] for d in range(3)]))
-    a, b = mn[axis], mx[axis]
+    t = gt_part
+    n = int(t.shape[0])
     if world == 1:
-        return axis, [-inf, inf]
-    if not b > a:  # no extent at all: any strictly ascending faces will do (everything lands on one rank)
-        return axis, [-inf] + [a + k for k in range(1, world)] + [inf]
-    if t.shape[0]:
-        h = torch.histc(t[:, axis].to(torch.float64), bins=bins, min=a, max=b)
+        if n == 0:
+            return 0, [-inf, inf]
+        ext = (t.amax(0) - t.amin(0)).tolist()
+        return int(np.argmax(ext)), [-inf, inf]
+    smp = torch.full((sample, 3), float("nan"), dtype=torch.float64, device=t.device)
+    if n:
+        pick = t[::max(1, -(-n // sample))][:sample]
+        smp[:pick.shape[0]] = pick
+    if _single(dist):
+        allp = smp
     else:
-        h = torch.zeros(bins, dtype=torch.float64, device=t.device)
-    if not _single(dist):
-        h = _all_reduce(h, dist, comm_device)
-    cum = torch.cumsum(h, 0).tolist()
-    total = cum[-1]
+        buf = _comm(smp, comm_device).contiguous()
+        parts = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, buf)                                                       # collective 1
+        allp = torch.cat(parts)
+    ok = ~torch.isnan(allp[:, 0])
+    pts = allp[ok]
+    m = int(pts.shape[0])
+    if m == 0:
+        return 0, [-inf] + [float(k) for k in range(1, world)] + [inf]
+    ext = (pts.amax(0) - pts.amin(0)).tolist()
+    axis = int(np.argmax(ext))
+    v = torch.sort(pts[:, axis]).values
+    # face k sits between the two sample values around the k/world quantile (the midpoint: no sample point lies ON a face)
+    idx = [min(max((m * k) // world, 1), m - 1) for k in range(1, world)]
+    it = torch.tensor(idx, dtype=torch.int64, device=v.device)
+    faces = (0.5 * (v[it - 1] + v[it])).tolist()
     cuts = [-inf]
-    for k in range(1, world):
-        idx = int(np.searchsorted(cum, total * k / world, side="left"))
-        c = a + (b - a) * min(idx + 1, bins) / bins
+    for c in faces:
         if cuts[-1] > -inf and not c > cuts[-1]:
-            c = float(np.nextafter(cuts[-1], inf))  # strictly ascending
-        cuts.append(c)
+            c = float(np.nextafter(cuts[-1], inf))  # strictly ascending (duplicated coordinates)
+        cuts.append(float(c))
     cuts.append(inf)
     return axis, cuts
 
 
 def halo_exchange(eng, dist, comm_device, parts, axis: int, cuts, halo: float):
     """parts: this rank's pieces of the clouds (device tensors, already transformed).  Every point goes to every rank whose slab
-    + halo holds it (collectives 3 and 4).  Returns the received clouds, one tensor per input."""
+    + halo holds it (collectives 2 and 3).  Returns the received clouds, one tensor per input."""
     import torch
 
     world = len(cuts) - 1
@@ -394,7 +400,7 @@ def halo_exchange(eng, dist, comm_device, parts, axis: int, cuts, halo: float):
     sc = torch.tensor([[counts[c][k] for c in range(nc)] for k in range(world)], dtype=torch.int64)  # (world, clouds)
     sc_c = sc.to(comm_device)
     rc_c = torch.empty_like(sc_c)
-    dist.all_to_all_single(rc_c, sc_c)                                                    # collective 3
+    dist.all_to_all_single(rc_c, sc_c)                                                    # collective 2
     rc = rc_c.cpu()
     offs = [np.concatenate([[0], np.cumsum(counts[c])]) for c in range(nc)]
     send = torch.cat([packed[c][int(offs[c][k]):int(offs[c][k + 1])] for k in range(world) for c in range(nc)])
@@ -402,7 +408,7 @@ def halo_exchange(eng, dist, comm_device, parts, axis: int, cuts, halo: float):
     out_splits = [int(rc[k].sum()) for k in range(world)]
     send_c = _comm(send, comm_device)
     recv_c = torch.empty((sum(out_splits), 3), dtype=torch.float64, device=comm_device)
-    dist.all_to_all_single(recv_c, send_c, out_splits, in_splits)                         # collective 4: the halo exchange
+    dist.all_to_all_single(recv_c, send_c, out_splits, in_splits)                         # collective 3: the halo exchange
     recv = recv_c if recv_c.device == packed[0].device else recv_c.to(packed[0].device)
     out, base = [[] for _ in range(nc)], 0
     for k in range(world):
@@ -411,6 +417,15 @@ def halo_exchange(eng, dist, comm_device, parts, axis: int, cuts, halo: float):
             out[c].append(recv[base:base + m])
             base += m
     return [torch.cat(o).contiguous() for o in out]
+
+
+def _upload_received(eng, slot, pts, P):
+    """Index what the halo exchange delivered: exactly this rank's slab + halo, so the upload's slab filter is skipped where
+    the engine offers that (me_upload_slab_device)."""
+    if hasattr(eng, "upload_slab"):
+        eng.upload_slab(slot, pts, cell_size=P.nn_radius_)
+    else:
+        eng.upload(slot, pts, cell_size=P.nn_radius_)
 
 
 def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, world: int, evaluate_gt_mme: bool = True,
@@ -432,9 +447,9 @@ def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, wor
     eng.set_slab(axis, cuts[rank], cuts[rank + 1], halo)
     lane = _DistLane(eng, gt_r, P, evaluate_gt_mme) if (overlap and hasattr(eng, "twin")) else None
     try:
-        eng.upload(ME_SLOT_EST, est_r, cell_size=P.nn_radius_)
+        _upload_received(eng, ME_SLOT_EST, est_r, P)
         if lane is None:
-            eng.upload(ME_SLOT_GT, gt_r, cell_size=P.nn_radius_)
+            _upload_received(eng, ME_SLOT_GT, gt_r, P)
         else:
             lane.est_ready.set()
         tr.mark("upload_est")
@@ -489,7 +504,7 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         lane.wait_nn()
         cnt[1] = lane.unres_back
         tr.mark("wait_nn_back")
-    # --- collective 5: everybody learns everybody's open-query counts (and the global cloud sizes) ---
+    # --- collective 4: everybody learns everybody's open-query counts (and the global cloud sizes) ---
     mine = torch.tensor([cnt[0], cnt[1], n_loc[0], n_loc[1]], dtype=torch.int64)
     if single:
         table = mine[None, :]
@@ -499,7 +514,7 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         table = torch.stack(parts).cpu()
     n_e, n_g = int(table[:, 2].sum()), int(table[:, 3].sum())
     tr.mark("counts")
-    # --- collectives 6 + 7: open queries of both directions in one all-gather, their answers in one MIN-reduce ---
+    # --- collectives 5 + 6: open queries of both directions in one all-gather, their answers in one MIN-reduce ---
     n_cross = int(table[:, 0].sum() + table[:, 1].sum())
     if not single and n_cross > 0:
         cmax = [int(table[:, 0].max()), int(table[:, 1].max())]
@@ -540,8 +555,8 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     else:
         rows = [eng.voxel_partial_rows(slot, P.vmd_voxel_size_) for slot in (ME_SLOT_EST, ME_SLOT_GT)]
     tr.mark("join_lane")
-    # --- collectives 8 + 9: partial sums, then the sigma numerators (second pass of map_eval.cpp:1132-1138); the per-rank
-    #     voxel row counts ride on (8) as one-hot entries (exact in fp64), so the gather (10) needs no size exchange ---
+    # --- collectives 7 + 8: partial sums, then the sigma numerators (second pass of map_eval.cpp:1132-1138); the per-rank
+    #     voxel row counts ride on (7) as one-hot entries (exact in fp64), so the gather (9) needs no size exchange ---
     onehot = np.zeros(2 * world)
     onehot[rank], onehot[world + rank] = rows[0].shape[0], rows[1].shape[0]
     vec = all_reduce_sum(np.concatenate([pack_partials(parts, m_e, m_g), onehot]), dist, comm_device)
@@ -558,7 +573,7 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     mme_est = vec[o] / vec[o + 1] if vec[o + 1] > 0 else 0.0
     mme_gt = vec[o + 2] / vec[o + 3] if vec[o + 3] > 0 else 0.0
     tr.mark("stats")
-    # --- collective 10: voxel partial rows of both clouds in one padded all-gather, merged on the device ---
+    # --- collective 9: voxel partial rows of both clouds in one padded all-gather, merged on the device ---
     if single:
         gathered = rows
     else:
@@ -597,7 +612,7 @@ class _DistLane:
 
     def _run(self, lane, gt, P, evaluate_gt_mme):
         try:
-            lane.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
+            _upload_received(lane, ME_SLOT_GT, gt, P)
             self.gt_ready.set()
             self.est_ready.wait()
             if self.err is not None:

@@ -133,6 +133,18 @@ class Engine:
         self._ck(fn(self._ctx, slot, _addr(xyz), int(xyz.shape[0]), _addr(Tm), float(cell_size)))
         self._keepalive = xyz
 
+    def upload_slab(self, slot: int, xyz, cell_size: float = 0.0):
+        """upload() for a cuda tensor that already IS this rank's slab + halo (what the halo exchange delivered): no filter."""
+        import torch
+
+        if not xyz.is_cuda:
+            return self.upload(slot, xyz, cell_size=cell_size)  # (host tensor: the general path, with its filter)
+        if xyz.dtype != torch.float64 or not xyz.is_contiguous():
+            xyz = xyz.to(torch.float64).contiguous()
+        torch.cuda.current_stream(xyz.device).synchronize()
+        self._ck(self._L.me_upload_slab_device(self._ctx, slot, xyz.data_ptr(), int(xyz.shape[0]), float(cell_size)))
+        self._keepalive = xyz
+
     def voxel_downsample(self, slot: int, voxel_size: float) -> int:
         """open3d VoxelDownSample (map_eval.cpp:38-39) on the uploaded cloud, in place; returns the new point count."""
         n = C.c_int64(0)

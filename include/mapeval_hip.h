@@ -132,8 +132,12 @@ int me_voxel_partials(me_ctx *ctx, int slot, double voxel_size, int32_t *keys /*
  *                                what the all-gather of the voxel partials carries (rows with n == 0 are padding).
  *   me_voxel_merge_device        Chan's parallel update of the gathered rows of all ranks -> the slot's voxel table exactly as
  *                                VoxelCalculator::buildVoxelMap leaves it (voxel_calculator.cpp:21-56: M2/(n-1)^2 for n > 10);
- *                                when both slots hold a merged table of the same voxel size, me_awd_scs runs on them. */
+ *                                when both slots hold a merged table of the same voxel size, me_awd_scs runs on them.
+ *   me_upload_slab_device        me_upload_cloud_device for points that ARE this rank's slab + halo already (what the exchange
+ *                                delivered, transform applied): me_set_slab's filter pass is skipped, ownership still follows
+ *                                the slab. */
 int me_transform_points_device(me_ctx *ctx, double *xyz_device, int64_t n, const double *T_rowmajor4x4);
+int me_upload_slab_device(me_ctx *ctx, int slot, const double *xyz_device, int64_t n, double cell_size);
 int me_halo_pack_device(me_ctx *ctx, const double *xyz_device, int64_t n, int axis, const double *cuts, int world, double halo,
                         double *out_device, int64_t capacity, int64_t *counts);
 int me_voxel_partial_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, int64_t capacity, int64_t *n_rows);

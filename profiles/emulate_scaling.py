@@ -116,10 +116,10 @@ _orig_cuts = medist.dist_slab_cuts
 GLOBAL = {}
 
 
-def _patched_cuts(gt_part, d, cd, w, bins=8192):
-    """Collectives 1 + 2 are identities here, so a rank alone would cut by its OWN histogram: do the same device work, then
+def _patched_cuts(gt_part, d, cd, w, sample=16384):
+    """Collective 1 repeats the rank's own sample here, so a rank alone would cut by its OWN quantiles: do the same device work, then
     hand back the global cuts (those the precomputed exchange was made for)."""
-    _orig_cuts(gt_part, None, cd, w, bins)
+    _orig_cuts(gt_part, None, cd, w, sample)
     return GLOBAL["cuts"]
 
 

@@ -253,3 +253,38 @@ def test_bench_py_two_rank_path_runs_end_to_end():
     for k in ("CD", "MME_est", "MME_gt", "AWD", "SCS"):
         np.testing.assert_allclose(rb[k], ra[k], rtol=1e-9)
     np.testing.assert_allclose(rb["AC"], ra["AC"], rtol=1e-9)
+
+
+def test_prefiltered_slab_upload_equals_filtered_upload_and_copes_with_an_empty_slab():
+    """me_upload_slab_device (what the distributed step uses for the points the exchange delivered) against the filtering
+    upload on the same slab; and a rank whose slab holds nothing of a cloud."""
+    import torch
+
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, gt = _scene(60_000)
+    dev = torch.device("cuda", 0)
+    lo, hi, halo = float(np.quantile(gt[:, 0], 0.3)), float(np.quantile(gt[:, 0], 0.6)), 0.5
+    with Engine(0) as eng:
+        eng.set_slab(0, lo, hi, halo)
+        eng.upload(0, est, cell_size=0.1)
+        eng.upload(1, gt, cell_size=0.1)
+        a = (eng.mme(0, 0.1, 10, per_point=False)[3:], eng.size(0), eng.size(1))
+        eng.nn1(0, 1, fetch=False)
+        pa = eng.nn_partial_sums(0, 1.0, 0, TRUNC)
+        keep = lambda p: torch.from_numpy(p[(p[:, 0] >= lo - halo) & (p[:, 0] < hi + halo)]).to(dev)
+        eng.upload_slab(0, keep(est), cell_size=0.1)
+        eng.upload_slab(1, keep(gt), cell_size=0.1)
+        b = (eng.mme(0, 0.1, 10, per_point=False)[3:], eng.size(0), eng.size(1))
+        eng.nn1(0, 1, fetch=False)
+        pb = eng.nn_partial_sums(0, 1.0, 0, TRUNC)
+        assert a == b and pa.n_corr == pb.n_corr and list(pa.n_inl) == list(pb.n_inl) and pa.sum_sqrt_all == pb.sum_sqrt_all
+        # nothing of the map in this rank's slab
+        eng.upload_slab(0, torch.zeros((0, 3), dtype=torch.float64, device=dev), cell_size=0.1)
+        assert eng.size(0) == 0 and eng.mme(0, 0.1, 10, per_point=False)[3:] == (0, 0.0)
+        eng.nn1(0, 1, fetch=False)
+        assert eng.nn_partial_sums(0, 1.0, 0, TRUNC).n_corr == 0 and eng.nn_unresolved_count(0) == 0
+        eng.nn1(1, 0, fetch=False)  # every owned ground-truth point is unresolved: its neighbour lives on another rank
+        assert eng.nn_unresolved_count(1) > 0
+        assert eng.voxel_partial_rows(0, 1.0).shape == (0, 16)
+        eng.set_slab(-1)
