@@ -469,6 +469,7 @@ int me_timers_reset(me_ctx *ctx) {
     ctx->timers_collect();
     ctx->timers.clear();
     ctx->nn_fallback = ctx->nn_queries = 0;
+    if (ctx->nn1_dbg_buf.p) (void) hipMemset(ctx->nn1_dbg_buf.p, 0, 64);
     return ME_OK;
 }
 
@@ -481,6 +482,22 @@ int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launc
         if (total_ms) *total_ms = 0.0;
         if (launches) *launches = v;
         return ME_OK;
+    }
+    if (std::strncmp(name, "nn1_", 4) == 0 && std::strlen(name) > 4) {
+        // counters of the octree walk since the last reset (collected while timers are on): nodes opened, leaf cells scanned,
+        // points scanned, the longest chain (opened + scanned) of one query
+        static const char *names[4] = {"nn1_opened", "nn1_scans", "nn1_points", "nn1_max_opened"};
+        for (int k = 0; k < 4; ++k)
+            if (std::strcmp(name, names[k]) == 0) {
+                unsigned long long v = 0;
+                if (ctx->nn1_dbg_buf.p) {
+                    (void) hipDeviceSynchronize();
+                    (void) hipMemcpy(&v, ctx->nn1_dbg_buf.as<unsigned long long>() + k, 8, hipMemcpyDeviceToHost);
+                }
+                if (total_ms) *total_ms = 0.0;
+                if (launches) *launches = (int64_t) v;
+                return ME_OK;
+            }
     }
     auto it = ctx->timers.find(name);
     if (total_ms) *total_ms = it == ctx->timers.end() ? 0.0 : it->second.total_ms;

@@ -196,6 +196,14 @@ struct me_ctx {
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
     long long nn_fallback = 0, nn_queries = 0;  // counted only while timers are on
+    me::DevBuf nn1_dbg_buf;                      // octree-walk counters (nodes opened, leaves scanned, points, max per query)
+    unsigned long long *nn1_dbg() {
+        if (!nn1_dbg_buf.p) {
+            if (nn1_dbg_buf.ensure(64) != hipSuccess) return nullptr;
+            (void) hipMemset(nn1_dbg_buf.p, 0, 64);
+        }
+        return nn1_dbg_buf.as<unsigned long long>();
+    }
 
     int fail(int code, const std::string &msg) {
         err = msg;

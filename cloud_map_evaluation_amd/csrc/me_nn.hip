@@ -251,7 +251,7 @@ constexpr int kNn1Block = 128;  // 16 octets per block: 16 x 18 levels x (8 floa
 __global__ void __launch_bounds__(kNn1Block)
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
       OctView oct, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
-      const unsigned int *__restrict__ list_count, int use_bound) {
+      const unsigned int *__restrict__ list_count, int use_bound, unsigned long long *__restrict__ dbg) {
     __shared__ long long s_off[kMaxLevels];
     __shared__ float s_lb[kNn1Block / 8][kMaxLevels + 1][8];          // per octet, per level: the children's lower bounds
     __shared__ unsigned int s_beg[kNn1Block / 8][kMaxLevels + 1][9];  // ... and their [begin, end) on the level below
@@ -268,6 +268,8 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
         const long long i = q_begin + (alive ? (list ? (long long) list[t] : t) : 0);
         const SPoint q = qsp[i];
         const double qx = q.x, qy = q.y, qz = q.z;
+        unsigned int n_open = 0, n_scan = 0;  // nodes opened / leaf cells scanned by this octet (profiling counters, `dbg`)
+        unsigned long long n_pts = 0;
         double best = INFINITY;
         long long best_i = 0x7fffffffffffffffLL;
         if (list && alive) {
@@ -281,6 +283,8 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
         // the whole wave)
         auto scan_points = [&](bool go, long long jb, long long je) {
             if (!go) jb = je = 0;
+            n_scan += go ? 1u : 0u;
+            n_pts += (unsigned long long) (je - jb);
             double lb = best;
             long long li = best_i;
             for (long long j = jb + sub; __ballot(j < je); j += 8) {
@@ -330,6 +334,7 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                     lev = 1;
                 }
                 const int cnt = (int) (ce - cb);
+                n_open += go ? 1u : 0u;
                 const float4 *__restrict__ g = reinterpret_cast<const float4 *>(nodes + s_off[lev - 1] + cb + sub);
                 // (the buffer has 8 records of slack: short groups are masked, not skipped)
                 const float4 a = g[0], bb = g[1];
@@ -404,6 +409,12 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
         if (alive && sub == 0) {
             d2_out[i] = best;
             idx_out[i] = (int) best_i;
+            if (dbg) {  // (me_timer_get "nn1_opened" / "nn1_scans" / "nn1_points" / "nn1_max_opened"; only while timers are on)
+                atomicAdd(&dbg[0], (unsigned long long) n_open);
+                atomicAdd(&dbg[1], (unsigned long long) n_scan);
+                atomicAdd(&dbg[2], n_pts);
+                atomicMax(&dbg[3], (unsigned long long) (n_open + n_scan));
+            }
         }
     }  // grid-stride loop over octets
 }
@@ -658,7 +669,8 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
             const unsigned int nbf = (unsigned int) std::min<long long>(2LL * nb, 256 * 32);
             TimerScope ts(ctx, "nn1");
             hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
-                               r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0);
+                               r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0,
+                               ctx->timers_on ? ctx->nn1_dbg() : nullptr);
         }
         if (ctx->timers_on) {  // fallback share, for the bench report
             unsigned int h = 0;
@@ -713,7 +725,7 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
         TimerScope ts(ctx, "nn1");
         hipLaunchKernelGGL(k_nn1, dim3(std::min<unsigned int>(2 * nb, 256 * 32)), dim3(kNn1Block), 0, ctx->stream, qs.as<SPoint>(), 0LL, m,
                            r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
-                           (const unsigned int *) nullptr, bounded ? 1 : 0);
+                           (const unsigned int *) nullptr, bounded ? 1 : 0, ctx->timers_on ? ctx->nn1_dbg() : nullptr);
     }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());

@@ -313,7 +313,10 @@ int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out);
 
 /* ---- instrumentation (bench.py roofline leg) ------------------------------------------------------------- */
 /* Average device time (ms, HIP events on the context's stream) and launch count of a named kernel family since
- * the last me_timers_reset: "nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "voxel", "w2", "scs", "slab_filter", "halo_pack".  Enabled by me_timers_enable(1). */
+ * the last me_timers_reset: "nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "voxel", "w2", "scs", "slab_filter", "halo_pack".  Enabled by me_timers_enable(1).
+ * Counters (total_ms = 0, value in *launches): "nn_queries" / "nn_fallback_queries" (1-NN queries, and those that needed the
+ * octree pass), "nn1_opened" / "nn1_scans" / "nn1_points" / "nn1_max_opened" (octree walk: nodes opened, leaf cells and points
+ * scanned, the longest chain of one query). */
 int me_timers_enable(me_ctx *ctx, int on);
 int me_timers_reset(me_ctx *ctx);
 int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
