@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmapeval_hip.so")
+# MAPEVAL_HIP_LIB: another build of the same library (e.g. the -DME_MME_STATS one, profiles/README.md); still no fallback
+LIB_PATH = os.environ.get("MAPEVAL_HIP_LIB") or os.path.join(_HERE, "libmapeval_hip.so")
 
 ME_OK = 0
 ME_ERR_CAPACITY = -4

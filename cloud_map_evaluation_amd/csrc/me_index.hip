@@ -138,23 +138,72 @@ k_ingest(const double *__restrict__ in, long long n, int has_T, Mat4 T, double *
     }
 }
 
-__global__ void k_morton(const double *__restrict__ xyz, long long n, double ox, double oy, double oz, double fine_h,
-                         unsigned long long *__restrict__ codes, unsigned int *__restrict__ iota) {
-    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// Hilbert index of a cell (x, y, z), b bits per axis, as a 3b-bit key whose every 3-bit group is one level of the curve
+// (Skilling, "Programming the Hilbert curve", AIP Conf. Proc. 707, 2004: the transpose form, interleaved).  Like the Morton
+// code it is hierarchical — the top 3k bits depend on the top k bits of the coordinates only, so every aligned 2^j block of
+// cells is one contiguous run of the sorted array, which is all the cell tables and the octree ask of the order — but
+// consecutive cells along it are always face neighbours: 64 consecutive points never jump across the scene the way they
+// do at the seams of the Z curve.
+__device__ __forceinline__ unsigned long long hilbert_key(unsigned int x, unsigned int y, unsigned int z, int b) {
+    const unsigned int M = 1u << (b - 1);
+    for (unsigned int Q = M; Q > 1; Q >>= 1) {
+        const unsigned int P = Q - 1;
+        if (x & Q) x ^= P;
+        if (y & Q) {
+            x ^= P;
+        } else {
+            const unsigned int t = (x ^ y) & P;
+            x ^= t;
+            y ^= t;
+        }
+        if (z & Q) {
+            x ^= P;
+        } else {
+            const unsigned int t = (x ^ z) & P;
+            x ^= t;
+            z ^= t;
+        }
+    }
+    y ^= x;
+    z ^= y;
+    unsigned int t = 0;
+    for (unsigned int Q = M; Q > 1; Q >>= 1)
+        if (z & Q) t ^= Q - 1;
+    x ^= t;
+    y ^= t;
+    z ^= t;
+    return (spread21((unsigned long long) x) << 2) | (spread21((unsigned long long) y) << 1) | spread21((unsigned long long) z);
+}
+
+// fine-lattice coordinates of a point (the Morton code interleaves them)
+__device__ __forceinline__ void fine_cell(const double *__restrict__ xyz, long long i, double ox, double oy, double oz,
+                                          double fine_h, unsigned int &cx, unsigned int &cy, unsigned int &cz) {
     const double lim = 2097151.0;
     // division (not multiply-by-reciprocal): (p-o)/(h*2^-s) == ((p-o)/h)*2^s exactly, so the radius cell
     // floor((p-o)/h) is exactly the top bits of the fine coordinate.
-    const double fx = fmin(fmax(fine_coord(xyz[3 * i], ox, fine_h), 0.0), lim);
-    const double fy = fmin(fmax(fine_coord(xyz[3 * i + 1], oy, fine_h), 0.0), lim);
-    const double fz = fmin(fmax(fine_coord(xyz[3 * i + 2], oz, fine_h), 0.0), lim);
-    codes[i] = spread21((unsigned long long) fx) | (spread21((unsigned long long) fy) << 1) |
-               (spread21((unsigned long long) fz) << 2);
+    cx = (unsigned int) fmin(fmax(fine_coord(xyz[3 * i], ox, fine_h), 0.0), lim);
+    cy = (unsigned int) fmin(fmax(fine_coord(xyz[3 * i + 1], oy, fine_h), 0.0), lim);
+    cz = (unsigned int) fmin(fmax(fine_coord(xyz[3 * i + 2], oz, fine_h), 0.0), lim);
+}
+
+// sort keys: the Hilbert index of the point's cell at level `min_level` (the finest level the order matters at), placed at
+// bits [3 min_level, 63) — or the Morton code itself (hilbert == 0)
+__global__ void k_morton(const double *__restrict__ xyz, long long n, double ox, double oy, double oz, double fine_h,
+                         int min_level, int hilbert, unsigned long long *__restrict__ keys, unsigned int *__restrict__ iota) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned int cx, cy, cz;
+    fine_cell(xyz, i, ox, oy, oz, fine_h, cx, cy, cz);
+    if (hilbert)
+        keys[i] = hilbert_key(cx >> min_level, cy >> min_level, cz >> min_level, kMortonBits - min_level) << (3 * min_level);
+    else
+        keys[i] = spread21((unsigned long long) cx) | (spread21((unsigned long long) cy) << 1) | (spread21((unsigned long long) cz) << 2);
     iota[i] = (unsigned int) i;
 }
 
-__global__ void k_gather(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, long long n,
-                         SPoint *__restrict__ sp) {
+// sorted points, and their Morton codes (the cell keys of every level; recomputed here rather than carried through the sort)
+__global__ void k_gather(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, long long n, double ox,
+                         double oy, double oz, double fine_h, SPoint *__restrict__ sp, unsigned long long *__restrict__ codes) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned int s = perm[i];
@@ -164,6 +213,9 @@ __global__ void k_gather(const double *__restrict__ xyz, const unsigned int *__r
     p.z = xyz[3 * (long long) s + 2];
     p.idx = (long long) s;
     sp[i] = p;
+    unsigned int cx, cy, cz;
+    fine_cell(xyz, (long long) s, ox, oy, oz, fine_h, cx, cy, cz);
+    codes[i] = spread21((unsigned long long) cx) | (spread21((unsigned long long) cy) << 1) | (spread21((unsigned long long) cz) << 2);
 }
 
 // octree level 0: one node per occupied 1-NN-grid cell (a contiguous run of sorted points)
@@ -517,21 +569,25 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     ME_CHECK(ctx, perm.ensure((size_t) n * 4));
     ME_CHECK(ctx, c.codes.ensure((size_t) n * 8));
     ME_CHECK(ctx, c.sp.ensure((size_t) n * sizeof(SPoint)));
+    const int sort_min_level = std::max(0, c.shift - 5);
+    // ME_HILBERT=0: points sorted along the Z curve (the first version) for A/B measurements
+    static const int hilbert = std::getenv("ME_HILBERT") ? std::atoi(std::getenv("ME_HILBERT")) : 1;
     {
         TimerScope ts(ctx, "morton");
         hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, c.origin[0],
-                           c.origin[1], c.origin[2], c.fine_h, codes_in.as<unsigned long long>(), iota.as<unsigned int>());
+                           c.origin[1], c.origin[2], c.fine_h, sort_min_level, hilbert, codes_in.as<unsigned long long>(),
+                           iota.as<unsigned int>());
     }
     // Nothing below consumes the order inside a cell 32x finer than the search cell (the 1-NN grid and the octree leaves
     // sit at or above that level), so the radix sort skips those low bits: 6 passes instead of 8 on the bench scene.
     // The sort is stable, so the order inside such a cell is the input order: still deterministic.
-    const int sort_min_level = std::max(0, c.shift - 5);
     ME_TRY(sort_pairs_u64_u32(ctx, codes_in.as<unsigned long long>(), c.codes.as<unsigned long long>(),
                               iota.as<unsigned int>(), perm.as<unsigned int>(), n, 3 * sort_min_level, 63));
     {
         TimerScope ts(ctx, "gather");
         hipLaunchKernelGGL(k_gather, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
-                           perm.as<unsigned int>(), n, c.sp.as<SPoint>());
+                           perm.as<unsigned int>(), n, c.origin[0], c.origin[1], c.origin[2], c.fine_h, c.sp.as<SPoint>(),
+                           c.codes.as<unsigned long long>());
     }
     // --- occupied cells per Morton level -> pick the 1-NN grid level; build the cell tables ---
     {

@@ -512,13 +512,25 @@ __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, i
                                                  int lane, int2 *tab, GroupBox &box, int *n_keys_out = nullptr,
                                                  unsigned int *rows = nullptr, unsigned short *tcell = nullptr) {
     const unsigned long long pm = __ballot(pending);  // caller guarantees pm != 0
+#ifdef ME_LEADER_FIRST
     const int leader = __ffsll((long long) pm) - 1;
+#else
+    // The leader is the MIDDLE pending lane, not the first: the lanes hold Morton-consecutive points, the first pending lane
+    // sits at one end of the stretch of space they cover and its Chebyshev ball reaches half as far into it.
+    const int rank = __popcll(pm & ((1ULL << lane) - 1ULL));
+    const int leader = __ffsll((long long) __ballot(pending && rank == (__popcll(pm) >> 1))) - 1;
+#endif
     const int lx = readlane_i(cx, leader), ly = readlane_i(cy, leader), lz = readlane_i(cz, leader);
     const int ex = cx - lx, ey = cy - ly, ez = cz - lz;
     const bool in = pending && ex >= -kGroupR && ex <= kGroupR && ey >= -kGroupR && ey <= kGroupR && ez >= -kGroupR && ez <= kGroupR;
-    const int x0 = wave_min_i(in ? cx : lx) - H, x1 = wave_max_i(in ? cx : lx) + H;
-    const int y0 = wave_min_i(in ? cy : ly) - H, y1 = wave_max_i(in ? cy : ly) + H;
-    const int z0 = wave_min_i(in ? cz : lz) - H, z1 = wave_max_i(in ? cz : lz) + H;
+    // (readfirstlane: the butterfly leaves the same value in every lane, but only this tells the compiler so — without it the
+    // box, the table size and everything the callers derive from them live in vector registers and loops over them diverge)
+    const int x0 = __builtin_amdgcn_readfirstlane(wave_min_i(in ? cx : lx)) - H;
+    const int x1 = __builtin_amdgcn_readfirstlane(wave_max_i(in ? cx : lx)) + H;
+    const int y0 = __builtin_amdgcn_readfirstlane(wave_min_i(in ? cy : ly)) - H;
+    const int y1 = __builtin_amdgcn_readfirstlane(wave_max_i(in ? cy : ly)) + H;
+    const int z0 = __builtin_amdgcn_readfirstlane(wave_min_i(in ? cz : lz)) - H;
+    const int z1 = __builtin_amdgcn_readfirstlane(wave_max_i(in ? cz : lz)) + H;
     const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
     const int n_keys = nx * ny * nz;  // <= (2R+1+2H)^3
     if (n_keys_out) *n_keys_out = n_keys;

@@ -149,6 +149,16 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
     }
 }
 
+__device__ __forceinline__ double uniform_f64(double v) {  // a wave-uniform double, moved to a scalar register pair
+    const unsigned int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double((int) hi, (int) lo);
+}
+#ifdef ME_MME_STATS
+// build with -DME_MME_STATS (profiles/README.md): per launch, [0] wave rounds, [1] candidates streamed, [2] lanes served,
+// [3] accepted (query, candidate) pairs — printed to stderr by mme_run
+__device__ unsigned long long g_mme_stat[8];
+#endif
+
 // ------------------------------------------------------------------------------------------------------------
 // k_mme3 — the wave-shared candidate streams of k_mme with (a) an FP32 pre-test, (b) the per-run adjacency cull and
 // (c) candidates delivered through a wave-private LDS tile instead of scalar fetches.
@@ -226,8 +236,10 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
         const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
         const bool in = wave_group_table<1, true>(!done, cx, cy, cz, g, cell_lim, lane, tab, bx, &nk,
                                                   reinterpret_cast<unsigned int *>(tf));
-        const double ox = fr.ox + (double) bx.x0 * cell_h, oy = fr.oy + (double) bx.y0 * cell_h,
-                     oz = fr.oz + (double) bx.z0 * cell_h;  // wave-uniform
+        // wave-uniform, and kept in scalar registers (there is no scalar fp64 arithmetic: computed once per round on the
+        // vector unit, then moved over)
+        const double ox = uniform_f64(fr.ox + (double) bx.x0 * cell_h), oy = uniform_f64(fr.oy + (double) bx.y0 * cell_h),
+                     oz = uniform_f64(fr.oz + (double) bx.z0 * cell_h);
         const float ax = (float) (-2.0 * (qx - ox)), ay = (float) (-2.0 * (qy - oy)), az = (float) (-2.0 * (qz - oz));
         const float s = fmaf(az, az, fmaf(ay, ay, ax * ax));
         // (the group predicate rides on the thresholds: lanes outside the group accept nothing)
@@ -236,20 +248,24 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
         int k = 0;
         double s1x = 0, s1y = 0, s1z = 0;
         double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+#ifdef ME_MME_STATS
+        int st_cand = 0;
+#endif
         auto test = [&](const float4 &c, int j) {
             const float u = fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
             const bool hi = u < t_hi;
             const unsigned long long mh = __ballot(hi);
             if (mh) {  // some lane may hold this candidate inside its radius
                 bool acc = u < t_lo;
-                const double dx = tdx[j] - qx, dy = tdy[j] - qy, dz = tdz[j] - qz;
                 // (both compares land in scalar register pairs: the band test is scalar work, no VALU instruction)
                 if (__builtin_expect(mh != __ballot(acc), 0)) {  // a lane in the band: its exact test decides
                     asm volatile("; band: exact test" ::: "memory");     // (keeps the compiler from evaluating it always)
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    const double ex = tdx[j] - qx, ey = tdy[j] - qy, ez = tdz[j] - qz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
                     acc = acc || (hi && d2 < r2);                        // strict, nanoflann RadiusResultSet [upstream]
                 }
                 if (acc) {
+                    const double dx = tdx[j] - qx, dy = tdy[j] - qy, dz = tdz[j] - qz;
                     ++k;
                     s1x += dx;
                     s1y += dy;
@@ -266,6 +282,9 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
         if (dbg != 1) wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) {
             for (int base = cs; base < ce; base += TILE) {
                 const int n = min(TILE, ce - base);
+#ifdef ME_MME_STATS
+                st_cand += n;
+#endif
                 if (lane < n) {
                     const SPoint p = sp[base + lane];
                     const double px = p.x - ox, py = p.y - oy, pz = p.z - oz;
@@ -297,6 +316,19 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
             }
         });
+#ifdef ME_MME_STATS
+        {
+            int ka = in ? k - 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) ka += __shfl_xor(ka, o, 64);
+            const int served = __popcll(__ballot(in));
+            if (lane == 0) {
+                atomicAdd(&g_mme_stat[0], 1ULL);
+                atomicAdd(&g_mme_stat[1], (unsigned long long) st_cand);
+                atomicAdd(&g_mme_stat[2], (unsigned long long) served);
+                atomicAdd(&g_mme_stat[3], (unsigned long long) ka);
+            }
+        }
+#endif
         if (in) {
             done = true;
             const int kk = k - 1;  // drop the query itself (map_eval.cpp:1672-1673)
@@ -463,6 +495,17 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
+#ifdef ME_MME_STATS
+    {
+        unsigned long long st[8] = {0}, zero[8] = {0};
+        (void) hipMemcpyFromSymbol(st, HIP_SYMBOL(g_mme_stat), sizeof st);
+        (void) hipMemcpyToSymbol(HIP_SYMBOL(g_mme_stat), zero, sizeof zero);
+        if (st[0])
+            std::fprintf(stderr, "[mme stats] queries=%lld wave rounds=%llu (%.3f per 64 queries) candidates/round=%.1f lanes served/round=%.1f accepted/query=%.1f\n",
+                         (long long) (e - b), st[0], (double) st[0] * 64.0 / (double) (e - b), (double) st[1] / (double) st[0],
+                         (double) st[2] / (double) st[0], (double) st[3] / (double) (e - b));
+    }
+#endif
     c.mme_have = true;
     if (sum_H) *sum_H = hs;
     if (n_valid) *n_valid = hc;
