@@ -477,6 +477,10 @@ __device__ __forceinline__ bool wave_group_runs(bool pending, int cx, int cy, in
     return in;
 }
 
+__device__ __forceinline__ double uniform_f64(double v) {  // a wave-uniform double, moved to a scalar register pair
+    const unsigned int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double((int) hi, (int) lo);
+}
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));

@@ -149,10 +149,6 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
     }
 }
 
-__device__ __forceinline__ double uniform_f64(double v) {  // a wave-uniform double, moved to a scalar register pair
-    const unsigned int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double((int) hi, (int) lo);
-}
 #ifdef ME_MME_STATS
 // build with -DME_MME_STATS (profiles/README.md): per launch, [0] wave rounds, [1] candidates streamed, [2] lanes served,
 // [3] accepted (query, candidate) pairs — printed to stderr by mme_run

@@ -123,13 +123,17 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     // rank error: the cell box spans <= 7 cells per axis, so |p'| <= 12 h, |a| <= 24 h, every term of r is below ~150 h^2
     // and carries a few 2^-24 relative: E < 1.2e-4 h^2 in the worst case (typically 10x less); the check uses 2E with margin
     const float rank_tol = (float) (1e-3 * cell_h * cell_h);
+    // (b1 <= b2 <= b3 are the three smallest ranks seen: the new second is the median of {b1, b2, m}, the new third the
+    // median of {b2, b3, m} — one v_med3_f32 each; fminf/fmaxf chains cost three times as many instructions, most of them
+    // NaN canonicalisations of values that are never NaN)
     auto note = [&](float m, int j) {
         m += bias;
         const bool lt1 = m < b1, lt2 = m < b2;
-        b3 = fminf(b3, fmaxf(m, b2));
-        b2 = fminf(b2, fmaxf(m, b1));
-        j2 = lt1 ? j1 : (lt2 ? j : j2);
-        b1 = fminf(b1, m);
+        b3 = __builtin_amdgcn_fmed3f(b2, b3, m);
+        b2 = __builtin_amdgcn_fmed3f(b1, b2, m);
+        const int jn = lt2 ? j : j2;  // (two selects, no branch)
+        j2 = lt1 ? j1 : jn;
+        b1 = lt1 ? m : b1;
         j1 = lt1 ? j : j1;
     };
     // Candidate delivery.  A run (the points of one cell) is copied into a wave-private LDS tile with ONE coalesced vector
@@ -140,23 +144,32 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     __shared__ float4 s_tile[4][64];  // (doubles as the row masks of the adjacency cull while a round's table is built)
     float4 *tile = s_tile[threadIdx.x >> 6];
     double ox = 0, oy = 0, oz = 0;  // the round's local origin (wave-uniform)
+    // A run is padded to a multiple of four with records of rank +inf: no scalar tail loop (with 6-point cells most runs end
+    // in a partial group, and a lone candidate costs a whole note()).
+    // (Measured and rejected: candidates stored in pairs and ranked two at a time with v_pk_fma_f32 — 19 instead of 25
+    // instructions per group of four, yet 13.8 ms against 13.0: the packed FMA does not issue faster than two plain ones.)
     auto rank = [&](int j) {
         const float4 c = tile[j];
         return fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
     };
     auto stream_run = [&](int cs, int ce) {
         for (int base = cs; base < ce; base += 64) {
-            const int n = min(64, ce - base);
-            if (lane < n) {
-                const SPoint p = rsp[base + lane];
-                const double px = p.x - ox, py = p.y - oy, pz = p.z - oz;
-                tile[lane] = make_float4((float) px, (float) py, (float) pz, (float) fma(pz, pz, fma(py, py, px * px)));
+            const int n = min(64, ce - base), n4 = (n + 3) & ~3;
+            if (lane < n4) {
+                float4 rec = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
+                if (lane < n) {
+                    const SPoint p = rsp[base + lane];
+                    const double px = p.x - ox, py = p.y - oy, pz = p.z - oz;
+                    rec = make_float4((float) px, (float) py, (float) pz, (float) fma(pz, pz, fma(py, py, px * px)));
+                }
+                tile[lane] = rec;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            int j = 0;
-            for (; j + 4 <= n; j += 4) note(fminf(fminf(rank(j), rank(j + 1)), fminf(rank(j + 2), rank(j + 3))), base + j);
-            for (; j < n; ++j) note(rank(j), base + j);
+            // (ranks are never NaN: min3 / med3 rather than fminf, which canonicalises its operands first)
+            for (int j = 0; j < n4; j += 4)
+                note(__builtin_amdgcn_fmed3f(-INFINITY, rank(j), __builtin_amdgcn_fmed3f(-INFINITY, rank(j + 1), __builtin_amdgcn_fmed3f(-INFINITY, rank(j + 2), rank(j + 3)))),
+                     base + j);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
         }
@@ -170,9 +183,9 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         // (cull: a run adjacent to no lane of the group is in nobody's 3x3x3 block, so nobody's resolution test needs it)
         const bool in = wave_group_table<1, true>(!done, mcx, mcy, mcz, g, cell_lim, lane, tab, bx, &nk,
                                                   reinterpret_cast<unsigned int *>(tile));
-        ox = fr.ox + (double) bx.x0 * cell_h;
-        oy = fr.oy + (double) bx.y0 * cell_h;
-        oz = fr.oz + (double) bx.z0 * cell_h;
+        ox = uniform_f64(fr.ox + (double) bx.x0 * cell_h);  // (scalar registers: wave-uniform)
+        oy = uniform_f64(fr.oy + (double) bx.y0 * cell_h);
+        oz = uniform_f64(fr.oz + (double) bx.z0 * cell_h);
         if (in) {
             ax = (float) (-2.0 * (qx - ox));
             ay = (float) (-2.0 * (qy - oy));
