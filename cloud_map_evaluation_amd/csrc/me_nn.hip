@@ -261,18 +261,10 @@ __device__ __forceinline__ double octet_min(double v) {
 }
 
 constexpr int kNn1Block = 128;  // 16 octets per block: 16 x 18 levels x (8 floats + 9 ints) = 19.6 KB of walk cache
-// Work distribution.  The 8 octets of a wavefront walk in lock step (one instruction stream), so a wavefront is busy until its
-// LONGEST walk ends, and the walks of this kernel are wildly uneven: 26 dependent steps per query on average on the bench
-// pair, 734 for the worst one.  With one query per octet and a grid sized for the list, the kernel ran as four
-// successive batches of resident blocks (the walk cache limits a CU to 8 blocks), each as long as ITS longest walk.  Now the
-// grid is what the device holds at once, and an octet that has finished its query takes the next one — from a small
-// reservation its wavefront draws from one device-wide counter (`cursor`, zeroed by the host) — while its seven neighbours
-// go on walking: the kernel ends when the work runs out, about one longest walk after the start, not four.
 __global__ void __launch_bounds__(kNn1Block)
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
       OctView oct, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
-      const unsigned int *__restrict__ list_count, int use_bound, unsigned long long *__restrict__ dbg,
-      unsigned int *__restrict__ cursor) {
+      const unsigned int *__restrict__ list_count, int use_bound, unsigned long long *__restrict__ dbg) {
     __shared__ long long s_off[kMaxLevels];
     __shared__ float s_lb[kNn1Block / 8][kMaxLevels + 1][8];          // per octet, per level: the children's lower bounds
     __shared__ unsigned int s_beg[kNn1Block / 8][kMaxLevels + 1][9];  // ... and their [begin, end) on the level below
@@ -282,68 +274,152 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
     const ONode *__restrict__ nodes = oct.nodes;
     const long long n_items = list ? (long long) *list_count : (q_end - q_begin);
     const int sub = threadIdx.x & 7;
-    const int lane = threadIdx.x & 63;
-
-    // the query in hand (uniform over the octet)
-    bool walking = false;
-    long long i = 0;
-    double qx = 0, qy = 0, qz = 0;
-    double best = INFINITY;
-    long long best_i = 0x7fffffffffffffffLL;
-    unsigned int n_open = 0, n_scan = 0;  // nodes opened / leaf cells scanned for it (profiling counters, `dbg`)
-    unsigned long long n_pts = 0;
-    // scan of one run of sorted points [jb, je) (a leaf cell) by the octets flagged `go` (the shuffles run converged over
-    // the whole wave)
-    auto scan_points = [&](bool go, long long jb, long long je) {
-        if (!go) jb = je = 0;
-        n_scan += go ? 1u : 0u;
-        n_pts += (unsigned long long) (je - jb);
-        double lb = best;
-        long long li = best_i;
-        for (long long j = jb + sub; __ballot(j < je); j += 8) {
-            if (j < je) {
-                const SPoint p = rsp[j];
-                const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
-                if (d < lb || (d == lb && p.idx < li)) {  // ties -> smallest reference index (as the oracle)
-                    lb = d;
-                    li = p.idx;
-                }
-            }
-        }
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) {
-            const double od = __shfl_xor(lb, m, 64);
-            const long long oi = __shfl_xor(li, m, 64);
-            if (od < lb || (od == lb && oi < li)) {
-                lb = od;
-                li = oi;
-            }
-        }
-        if (go) {
-            best = lb;
-            best_i = li;
-        }
-    };
-    auto load_query = [&](long long t) {  // query number t of the list / of the range
-        i = q_begin + (list ? (long long) list[t] : t);
+    const long long octets_per_pass = (long long) gridDim.x * (blockDim.x >> 3);
+    for (long long t = (long long) blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);; t += octets_per_pass) {
+        const bool alive = t < n_items;
+        if (!__ballot(alive)) break;  // wave-uniform exit
+        const long long i = q_begin + (alive ? (list ? (long long) list[t] : t) : 0);
         const SPoint q = qsp[i];
-        qx = q.x;
-        qy = q.y;
-        qz = q.z;
-        best = INFINITY;
-        best_i = 0x7fffffffffffffffLL;
-        if (list) {  // the grid pass's best so far
+        const double qx = q.x, qy = q.y, qz = q.z;
+        unsigned int n_open = 0, n_scan = 0;  // nodes opened / leaf cells scanned by this octet (profiling counters, `dbg`)
+        unsigned long long n_pts = 0;
+        double best = INFINITY;
+        long long best_i = 0x7fffffffffffffffLL;
+        if (list && alive) {
             best = d2_out[i];
             const int bi = idx_out[i];
             if (bi >= 0) best_i = bi;
-        } else if (use_bound) {
+        } else if (use_bound && alive) {
             best = d2_out[i];  // caller's upper bound (me_nn_points_bounded): only closer points are of interest
         }
-        n_open = n_scan = 0;
-        n_pts = 0;
-    };
-    auto store_result = [&]() {
-        if (sub == 0) {
+        // scan of one run of sorted points [jb, je) (a leaf cell) by the octets flagged `go` (the shuffles run converged over
+        // the whole wave)
+        auto scan_points = [&](bool go, long long jb, long long je) {
+            if (!go) jb = je = 0;
+            n_scan += go ? 1u : 0u;
+            n_pts += (unsigned long long) (je - jb);
+            double lb = best;
+            long long li = best_i;
+            for (long long j = jb + sub; __ballot(j < je); j += 8) {
+                if (j < je) {
+                    const SPoint p = rsp[j];
+                    const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
+                    if (d < lb || (d == lb && p.idx < li)) {  // ties -> smallest reference index (as the oracle)
+                        lb = d;
+                        li = p.idx;
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {
+                const double od = __shfl_xor(lb, m, 64);
+                const long long oi = __shfl_xor(li, m, 64);
+                if (od < lb || (od == lb && oi < li)) {
+                    lb = od;
+                    li = oi;
+                }
+            }
+            if (go) {
+                best = lb;
+                best_i = li;
+            }
+        };
+        if (L == 0) {
+            scan_points(alive, 0, nr);  // the whole cloud is one cell
+        } else {
+            // Walk state: level l = the level of the node whose CHILDREN (level l-1) are being considered.  Lane `sub` owns
+            // child `sub`: after the one burst that fetches the <= 8 child records (+ the `begin` of the record after
+            // each, i.e. the child's end) it keeps, per level, the child's lower bound (a float rounded DOWN: still a
+            // lower bound) and its [begin, end) in a block-local LDS cache.  Returning to a parent therefore costs no memory
+            // round trip at all (the first version re-fetched the parent's header and its children and recomputed the
+            // bounds: three dependent round trips per node visited), and a descent costs one.  These few hundred far
+            // queries are pure pointer chasing: the kernel's time IS the longest chain of dependent fetches.
+            float *c_lb = s_lb[threadIdx.x >> 3][0];       // [level][8]
+            unsigned int *c_beg = s_beg[threadIdx.x >> 3][0];  // [level][9]: child begins + the end of the last one
+            unsigned long long taken_lo = 0, taken_hi = 0;  // "children already entered" per level: levels 1..8 / 9..16
+            double bound = best;  // pruning bound: min(best found, tightest box upper bound seen)
+            bool walking = alive;
+            int l = L;
+            // fetch the children [cb, ce) of a node onto level l's cache line; lane `sub` bounds child `sub`
+            auto open_node = [&](bool go, int lev, long long cb, long long ce) {
+                if (!go) {  // (an idle octet's cb / ce may be POINT indices of the leaf it has just scanned)
+                    cb = ce = 0;
+                    lev = 1;
+                }
+                const int cnt = (int) (ce - cb);
+                n_open += go ? 1u : 0u;
+                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(nodes + s_off[lev - 1] + cb + sub);
+                // (the buffer has 8 records of slack: short groups are masked, not skipped)
+                const float4 a = g[0], bb = g[1];
+                const unsigned int nxt = nodes[s_off[lev - 1] + cb + sub + 1].begin;
+                const float f[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
+                const bool mine = go && sub < cnt;
+                // every child box also yields an UPPER bound on the answer (some point lies inside it, no farther than
+                // its farthest corner): keeps the depth-first walk from sweeping a wide region on a loose `best`
+                const double ub = octet_min(mine ? box_upper_bound(f, qx, qy, qz) : INFINITY);
+                const double lbd = box_lower_bound(f, qx, qy, qz);
+                if (go) {
+                    bound = fmin(bound, ub);
+                    c_lb[lev * 8 + sub] = mine ? __double2float_rd(lbd) : INFINITY;
+                    c_beg[lev * 9 + sub] = __float_as_uint(bb.z);  // ONode::begin
+                    if (sub == 7 || sub == cnt - 1) c_beg[lev * 9 + sub + 1] = nxt;
+                }
+            };
+            {
+                const ONode *__restrict__ root = nodes + s_off[L];
+                open_node(walking, L, root[0].begin, root[1].begin);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            while (__ballot(walking)) {
+                const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
+                                                 : (unsigned int) (taken_hi >> (8 * (l - 9))) & 0xffu;
+                const double lbd = walking ? (double) c_lb[l * 8 + sub] : INFINITY;
+                const bool ok = walking && !((tk >> sub) & 1u) && lbd <= bound;  // <=: ties may hold a smaller index
+                double kd = ok ? lbd : INFINITY;
+                int kc = ok ? sub : 8;
+#pragma unroll
+                for (int m = 1; m < 8; m <<= 1) {
+                    const double od = __shfl_xor(kd, m, 64);
+                    const int oc = __shfl_xor(kc, m, 64);
+                    if (od < kd || (od == kd && oc < kc)) {
+                        kd = od;
+                        kc = oc;
+                    }
+                }
+                bool go_leaf = false, go_down = false;
+                long long cb = 0, ce = 0;
+                if (walking) {
+                    if (kc >= 8) {  // nothing left under this node: back to the parent's cache line
+                        if (l == L) walking = false;
+                        else ++l;
+                    } else {
+                        if (l <= 8) taken_lo |= 1ULL << (8 * (l - 1) + kc);
+                        else taken_hi |= 1ULL << (8 * (l - 9) + kc);
+                        cb = c_beg[l * 9 + kc];
+                        ce = c_beg[l * 9 + kc + 1];
+                        if (l == 1) {
+                            go_leaf = true;  // [cb, ce) are the points of a leaf cell
+                        } else {
+                            go_down = true;  // [cb, ce) are the chosen child's children, on level l - 2
+                            --l;
+                            if (l <= 8) taken_lo &= ~(0xffULL << (8 * (l - 1)));  // fresh node on the level below
+                            else taken_hi &= ~(0xffULL << (8 * (l - 9)));
+                        }
+                    }
+                }
+                if (__ballot(go_leaf)) {
+                    scan_points(go_leaf, cb, ce);
+                    bound = fmin(bound, best);
+                }
+                if (__ballot(go_down)) {
+                    open_node(go_down, go_down ? l : 1, cb, ce);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (alive && sub == 0) {
             d2_out[i] = best;
             idx_out[i] = (int) best_i;
             if (dbg) {  // (me_timer_get "nn1_opened" / "nn1_scans" / "nn1_points" / "nn1_max_opened"; only while timers are on)
@@ -353,148 +429,7 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                 atomicMax(&dbg[3], (unsigned long long) (n_open + n_scan));
             }
         }
-    };
-    if (L == 0) {  // the whole cloud is one cell: nothing to walk (static distribution)
-        const long long octets_per_pass = (long long) gridDim.x * (blockDim.x >> 3);
-        for (long long t = (long long) blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);; t += octets_per_pass) {
-            const bool alive = t < n_items;
-            if (!__ballot(alive)) break;
-            if (alive) load_query(t);
-            scan_points(alive, 0, nr);
-            if (alive) store_result();
-        }
-        return;
-    }
-
-    // Walk state: level l = the level of the node whose CHILDREN (level l-1) are being considered.  Lane `sub` owns
-    // child `sub`: after the one burst that fetches the <= 8 child records (+ the `begin` of the record after
-    // each, i.e. the child's end) it keeps, per level, the child's lower bound (a float rounded DOWN: still a
-    // lower bound) and its [begin, end) in a block-local LDS cache.  Returning to a parent therefore costs no memory
-    // round trip at all (the first version re-fetched the parent's header and its children and recomputed the
-    // bounds: three dependent round trips per node visited), and a descent costs one.
-    float *c_lb = s_lb[threadIdx.x >> 3][0];           // [level][8]
-    unsigned int *c_beg = s_beg[threadIdx.x >> 3][0];  // [level][9]: child begins + the end of the last one
-    unsigned long long taken_lo = 0, taken_hi = 0;     // "children already entered" per level: levels 1..8 / 9..16
-    double bound = INFINITY;  // pruning bound: min(best found, tightest box upper bound seen)
-    int l = L;
-    // fetch the children [cb, ce) of a node onto level l's cache line; lane `sub` bounds child `sub`
-    auto open_node = [&](bool go, int lev, long long cb, long long ce) {
-        if (!go) {  // (an idle octet's cb / ce may be POINT indices of the leaf it has just scanned)
-            cb = ce = 0;
-            lev = 1;
-        }
-        const int cnt = (int) (ce - cb);
-        n_open += go ? 1u : 0u;
-        const float4 *__restrict__ g = reinterpret_cast<const float4 *>(nodes + s_off[lev - 1] + cb + sub);
-        // (the buffer has 8 records of slack: short groups are masked, not skipped)
-        const float4 a = g[0], bb = g[1];
-        const unsigned int nxt = nodes[s_off[lev - 1] + cb + sub + 1].begin;
-        const float f[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
-        const bool mine = go && sub < cnt;
-        // every child box also yields an UPPER bound on the answer (some point lies inside it, no farther than
-        // its farthest corner): keeps the depth-first walk from sweeping a wide region on a loose `best`
-        const double ub = octet_min(mine ? box_upper_bound(f, qx, qy, qz) : INFINITY);
-        const double lbd = box_lower_bound(f, qx, qy, qz);
-        if (go) {
-            bound = fmin(bound, ub);
-            c_lb[lev * 8 + sub] = mine ? __double2float_rd(lbd) : INFINITY;
-            c_beg[lev * 9 + sub] = __float_as_uint(bb.z);  // ONode::begin
-            if (sub == 7 || sub == cnt - 1) c_beg[lev * 9 + sub + 1] = nxt;
-        }
-    };
-    const ONode *__restrict__ root = nodes + s_off[L];
-    const long long root_b = root[0].begin, root_e = root[1].begin;
-    // the wavefront's reservation [w_next, w_next + w_left) of the query numbers (wave-uniform)
-    const int chunk = n_items > (1LL << 20) ? 64 : 16;  // (bulk launches: fewer trips to the one counter)
-    long long w_next = 0;
-    int w_left = 0;
-    bool exhausted = false;
-    for (;;) {
-        // ---- idle octets take the next queries
-        const unsigned long long idle_m = __ballot(!walking && sub == 0);
-        if (idle_m && !exhausted) {
-            if (w_left == 0) {
-                unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(cursor, (unsigned int) chunk);
-                base = (unsigned int) __builtin_amdgcn_readfirstlane((int) base);
-                w_next = (long long) base;
-                const long long left = n_items - w_next;
-                w_left = (int) (left < 0 ? 0 : (left < chunk ? left : chunk));
-                if (w_left == 0) exhausted = true;
-            }
-            const int rank = __popcll(idle_m & ((1ULL << (lane & ~7)) - 1ULL));  // this octet among the idle ones
-            const bool start = !walking && rank < w_left;
-            if (start) load_query(w_next + rank);
-            const int given = min(__popcll(idle_m), w_left);
-            w_next += given;
-            w_left -= given;
-            if (__ballot(start)) {
-                if (start) {
-                    walking = true;
-                    l = L;
-                    taken_lo = taken_hi = 0;
-                    bound = best;
-                }
-                open_node(start, L, root_b, root_e);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (!__ballot(walking)) {
-            if (exhausted) break;
-            continue;
-        }
-        // ---- one step of every walking octet
-        const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
-                                         : (unsigned int) (taken_hi >> (8 * (l - 9))) & 0xffu;
-        const double lbd = walking ? (double) c_lb[l * 8 + sub] : INFINITY;
-        const bool ok = walking && !((tk >> sub) & 1u) && lbd <= bound;  // <=: ties may hold a smaller index
-        double kd = ok ? lbd : INFINITY;
-        int kc = ok ? sub : 8;
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) {
-            const double od = __shfl_xor(kd, m, 64);
-            const int oc = __shfl_xor(kc, m, 64);
-            if (od < kd || (od == kd && oc < kc)) {
-                kd = od;
-                kc = oc;
-            }
-        }
-        bool go_leaf = false, go_down = false, finished = false;
-        long long cb = 0, ce = 0;
-        if (walking) {
-            if (kc >= 8) {  // nothing left under this node: back to the parent's cache line
-                if (l == L) finished = true;
-                else ++l;
-            } else {
-                if (l <= 8) taken_lo |= 1ULL << (8 * (l - 1) + kc);
-                else taken_hi |= 1ULL << (8 * (l - 9) + kc);
-                cb = c_beg[l * 9 + kc];
-                ce = c_beg[l * 9 + kc + 1];
-                if (l == 1) {
-                    go_leaf = true;  // [cb, ce) are the points of a leaf cell
-                } else {
-                    go_down = true;  // [cb, ce) are the chosen child's children, on level l - 2
-                    --l;
-                    if (l <= 8) taken_lo &= ~(0xffULL << (8 * (l - 1)));  // fresh node on the level below
-                    else taken_hi &= ~(0xffULL << (8 * (l - 9)));
-                }
-            }
-        }
-        if (finished) {
-            store_result();
-            walking = false;
-        }
-        if (__ballot(go_leaf)) {
-            scan_points(go_leaf, cb, ce);
-            bound = fmin(bound, best);
-        }
-        if (__ballot(go_down)) {
-            open_node(go_down, go_down ? l : 1, cb, ce);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+    }  // grid-stride loop over octets
 }
 
 // ---- un-permute results to the caller's (original) query order ----
@@ -711,17 +646,6 @@ __global__ void k_nn_patch(const unsigned int *__restrict__ list, long long m, c
     d2[i] = fmin(d2[i], d2_new[t]);
 }
 
-// blocks of k_nn1 the device holds at once (19.6 KB of walk cache each: 8 per CU of 160 KB LDS); ME_NN1_BLOCKS overrides
-static long long nn1_resident_blocks() {
-    static const long long v = [] {
-        if (const char *e = std::getenv("ME_NN1_BLOCKS")) return (long long) std::atoll(e);
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return (long long) cus * 8;
-    }();
-    return v < 8 ? 8 : v;
-}
-
 int nn_search(me_ctx *ctx, int qslot, int rslot) {
     if (qslot < 0 || qslot > 1 || rslot < 0 || rslot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
     Cloud &q = ctx->cloud[qslot];
@@ -745,7 +669,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
     } else if (e > b) {
         const unsigned int nb = (unsigned int) (((e - b + 255) / 256 + 7) / 8 * 8);  // multiple of 8 (XCD chunking)
         ME_CHECK(ctx, q.nn_list.ensure((size_t) (e - b) * 4 + 64));
-        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));  // [0] unresolved-list length, [1] k_nn1's query cursor
+        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
         FrameView fr{r.origin[0], r.origin[1], r.origin[2], r.fine_h};
         {
             TimerScope ts(ctx, "nn_grid");
@@ -755,12 +679,11 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         }
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)
-            // (a resident grid: 8 blocks of walk cache per CU; the octets draw their queries from d_cnt[1])
-            const unsigned int nbf = (unsigned int) std::min<long long>(2LL * nb, nn1_resident_blocks());
+            const unsigned int nbf = (unsigned int) std::min<long long>(2LL * nb, 256 * 32);
             TimerScope ts(ctx, "nn1");
             hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
                                r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0,
-                               ctx->timers_on ? ctx->nn1_dbg() : nullptr, d_cnt + 1);
+                               ctx->timers_on ? ctx->nn1_dbg() : nullptr);
         }
         if (ctx->timers_on) {  // fallback share, for the bench report
             unsigned int h = 0;
@@ -812,14 +735,10 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
         ME_CHECK(ctx, qs.ensure((size_t) m * sizeof(SPoint)));
         ME_CHECK(ctx, qi.ensure((size_t) m * 4));
         hipLaunchKernelGGL(k_points_to_sp, dim3(nb), dim3(256), 0, ctx->stream, xyz_device, m, qs.as<SPoint>());
-        ME_CHECK(ctx, ctx->red.ensure(64));
-        unsigned int *d_cur = ctx->red.as<unsigned int>() + 1;
-        ME_CHECK(ctx, hipMemsetAsync(d_cur, 0, 4, ctx->stream));
         TimerScope ts(ctx, "nn1");
-        hipLaunchKernelGGL(k_nn1, dim3((unsigned int) std::min<long long>(2LL * nb, nn1_resident_blocks())), dim3(kNn1Block), 0,
-                           ctx->stream, qs.as<SPoint>(), 0LL, m, r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(),
-                           (const unsigned int *) nullptr, (const unsigned int *) nullptr, bounded ? 1 : 0,
-                           ctx->timers_on ? ctx->nn1_dbg() : nullptr, d_cur);
+        hipLaunchKernelGGL(k_nn1, dim3(std::min<unsigned int>(2 * nb, 256 * 32)), dim3(kNn1Block), 0, ctx->stream, qs.as<SPoint>(), 0LL, m,
+                           r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
+                           (const unsigned int *) nullptr, bounded ? 1 : 0, ctx->timers_on ? ctx->nn1_dbg() : nullptr);
     }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
