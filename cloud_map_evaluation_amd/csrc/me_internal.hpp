@@ -481,15 +481,43 @@ __device__ __forceinline__ double uniform_f64(double v) {  // a wave-uniform dou
     const unsigned int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double((int) hi, (int) lo);
 }
+// ---- cross-lane exchanges on the VALU (DPP) instead of the LDS pipe.  `__shfl_xor` compiles to ds_bpermute_b32: an LDS
+// round trip (~100 cycles) per 32 bits and butterfly stage, and the stages depend on each other.  The patterns below are
+// plain data-parallel-primitive modifiers of a v_mov: a few cycles each.
+// Partner of lane i inside its group of eight, stage 0: i^1 (quad_perm [1,0,3,2]), 1: i^2 (quad_perm [2,3,0,1]),
+// 2: 7-i (row_half_mirror: the other quad) — three stages leave a symmetric reduction's result in all eight lanes.
+template <int STAGE>
+__device__ __forceinline__ int octet_partner_i(int v) {
+    constexpr int ctrl = STAGE == 0 ? 0xB1 : (STAGE == 1 ? 0x4E : 0x141);
+    return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xF, 0xF, true);
+}
+template <int STAGE>
+__device__ __forceinline__ double octet_partner_d(double v) {
+    return __hiloint2double(octet_partner_i<STAGE>(__double2hiint(v)), octet_partner_i<STAGE>(__double2loint(v)));
+}
+template <int STAGE>
+__device__ __forceinline__ long long octet_partner_ll(long long v) {
+    const unsigned int lo = (unsigned int) octet_partner_i<STAGE>((int) (unsigned int) v);
+    const unsigned int hi = (unsigned int) octet_partner_i<STAGE>((int) (unsigned int) ((unsigned long long) v >> 32));
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
+// wave-wide min / max of an int, returned wave-uniform (scalar): four DPP stages reduce every row of 16 lanes (i^1, i^2,
+// 7-i, row_mirror 15-i), four readlanes and scalar min / max combine the rows
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -254,9 +254,10 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
 // one coalesced 256-byte burst per octet), a 3-step butterfly picks the nearest admissible child, and a leaf cell is
 // scanned eight points at a time.  The queries that reach this kernel are the rare far ones (0.1 % of the bench scene,
 // but each sweeps hundreds of nodes): with one lane per query the whole launch waited on a handful of serial walks.
-__device__ __forceinline__ double octet_min(double v) {
-#pragma unroll
-    for (int m = 1; m < 8; m <<= 1) v = fmin(v, __shfl_xor(v, m, 64));
+__device__ __forceinline__ double octet_min(double v) {  // (DPP exchanges, me_internal.hpp)
+    v = fmin(v, octet_partner_d<0>(v));
+    v = fmin(v, octet_partner_d<1>(v));
+    v = fmin(v, octet_partner_d<2>(v));
     return v;
 }
 
@@ -310,15 +311,15 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                     }
                 }
             }
-#pragma unroll
-            for (int m = 1; m < 8; m <<= 1) {
-                const double od = __shfl_xor(lb, m, 64);
-                const long long oi = __shfl_xor(li, m, 64);
+            auto stage = [&](double od, long long oi) {
                 if (od < lb || (od == lb && oi < li)) {
                     lb = od;
                     li = oi;
                 }
-            }
+            };
+            stage(octet_partner_d<0>(lb), octet_partner_ll<0>(li));
+            stage(octet_partner_d<1>(lb), octet_partner_ll<1>(li));
+            stage(octet_partner_d<2>(lb), octet_partner_ll<2>(li));
             if (go) {
                 best = lb;
                 best_i = li;
@@ -378,15 +379,15 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                 const bool ok = walking && !((tk >> sub) & 1u) && lbd <= bound;  // <=: ties may hold a smaller index
                 double kd = ok ? lbd : INFINITY;
                 int kc = ok ? sub : 8;
-#pragma unroll
-                for (int m = 1; m < 8; m <<= 1) {
-                    const double od = __shfl_xor(kd, m, 64);
-                    const int oc = __shfl_xor(kc, m, 64);
+                auto pick = [&](double od, int oc) {
                     if (od < kd || (od == kd && oc < kc)) {
                         kd = od;
                         kc = oc;
                     }
-                }
+                };
+                pick(octet_partner_d<0>(kd), octet_partner_i<0>(kc));
+                pick(octet_partner_d<1>(kd), octet_partner_i<1>(kc));
+                pick(octet_partner_d<2>(kd), octet_partner_i<2>(kc));
                 bool go_leaf = false, go_down = false;
                 long long cb = 0, ce = 0;
                 if (walking) {
