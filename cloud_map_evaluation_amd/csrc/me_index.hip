@@ -282,20 +282,15 @@ __global__ void k_oct_up(ONode *__restrict__ child, long long n_child, const uns
     parent[p] = nd;
 }
 
-__global__ void k_cell_flags(const unsigned long long *__restrict__ codes, long long n, int shift3,
-                             unsigned int *__restrict__ flags) {
+// the first point of every cell (code >> shift3 differs from the predecessor's) writes the cell's code and start; pos[i] =
+// cell starts before i (cell_start_ranks)
+__global__ void k_cell_scatter(const unsigned long long *__restrict__ codes, const unsigned int *__restrict__ pos, long long n,
+                               int shift3, unsigned long long *__restrict__ cell_code, unsigned int *__restrict__ cell_start) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    flags[i] = (i == 0 || (codes[i] >> shift3) != (codes[i - 1] >> shift3)) ? 1u : 0u;
-}
-
-__global__ void k_cell_scatter(const unsigned long long *__restrict__ codes, const unsigned int *__restrict__ flags,
-                               const unsigned int *__restrict__ pos, long long n, int shift3,
-                               unsigned long long *__restrict__ cell_code, unsigned int *__restrict__ cell_start) {
-    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flags[i]) {
-        cell_code[pos[i]] = codes[i] >> shift3;
+    const unsigned long long c = codes[i] >> shift3;
+    if (i == 0 || c != (codes[i - 1] >> shift3)) {
+        cell_code[pos[i]] = c;
         cell_start[pos[i]] = (unsigned int) i;
     }
 }
@@ -326,9 +321,22 @@ __global__ void __launch_bounds__(256) k_level_hist(const unsigned long long *__
     __shared__ unsigned int sh[32];
     if (threadIdx.x < 32) sh[threadIdx.x] = 0;
     __syncthreads();
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += (long long) gridDim.x * blockDim.x) {
-        const unsigned long long x = codes[i] ^ codes[i - 1];
-        if (x) atomicAdd(&sh[(63 - __clzll((long long) x)) / 3], 1u);
+    // (wave-aggregated: neighbours differ at two or three distinct levels per wavefront, almost all at the lowest ones — one
+    // LDS atomic per distinct level instead of 64 colliding on the same three counters)
+    for (long long i0 = (long long) blockIdx.x * blockDim.x + 1; i0 < n; i0 += (long long) gridDim.x * blockDim.x) {
+        const long long i = i0 + threadIdx.x;
+        int lv = -1;
+        if (i < n) {
+            const unsigned long long x = codes[i] ^ codes[i - 1];
+            if (x) lv = (63 - __clzll((long long) x)) / 3;
+        }
+        unsigned long long todo = __ballot(lv >= 0);
+        while (todo) {
+            const int l0 = __builtin_amdgcn_readlane(lv, __ffsll((long long) todo) - 1);
+            const unsigned long long same = __ballot(lv == l0);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&sh[l0], (unsigned int) __popcll(same));
+            todo &= ~same;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 32 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long) sh[threadIdx.x]);
@@ -340,18 +348,14 @@ static inline unsigned int grid_for(long long n, int block = 256) { return (unsi
 static int build_grid_table(me_ctx *ctx, Cloud &c, int shift, GridTable &t, GridView &g) {
     const long long n = c.n;
     const int shift3 = 3 * shift;
-    DevBuf &flags = ctx->tmp[0], &pos = ctx->tmp[1];
-    ME_CHECK(ctx, flags.ensure((size_t) n * 4));
+    DevBuf &pos = ctx->tmp[1];
     ME_CHECK(ctx, pos.ensure((size_t) n * 4));
-    hipLaunchKernelGGL(k_cell_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(), n, shift3,
-                       flags.as<unsigned int>());
-    ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), n));
+    ME_TRY(cell_start_ranks(ctx, c.codes.as<unsigned long long>(), n, shift3, pos.as<unsigned int>()));
     const long long n_cells = c.level_unique[shift];
     ME_CHECK(ctx, t.cell_code.ensure((size_t) n_cells * 8));
     ME_CHECK(ctx, t.cell_start.ensure((size_t) (n_cells + 1) * 4));
     hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(),
-                       flags.as<unsigned int>(), pos.as<unsigned int>(), n, shift3, t.cell_code.as<unsigned long long>(),
-                       t.cell_start.as<unsigned int>());
+                       pos.as<unsigned int>(), n, shift3, t.cell_code.as<unsigned long long>(), t.cell_start.as<unsigned int>());
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, ctx->stream, t.cell_start.as<unsigned int>(), n_cells, (unsigned int) n);
     unsigned long long hsize = 64;
     while (hsize < 2ULL * (unsigned long long) n_cells) hsize <<= 1;
@@ -569,7 +573,9 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     ME_CHECK(ctx, perm.ensure((size_t) n * 4));
     ME_CHECK(ctx, c.codes.ensure((size_t) n * 8));
     ME_CHECK(ctx, c.sp.ensure((size_t) n * sizeof(SPoint)));
-    const int sort_min_level = std::max(0, c.shift - 5);
+    // ME_SORT_DEPTH: levels below the search cell that the order (and therefore the choice of the 1-NN grid) may use
+    static const int sort_depth = std::getenv("ME_SORT_DEPTH") ? std::atoi(std::getenv("ME_SORT_DEPTH")) : 2;
+    const int sort_min_level = std::max(0, c.shift - std::max(0, sort_depth));
     // ME_HILBERT=0: points sorted along the Z curve (the first version) for A/B measurements
     static const int hilbert = std::getenv("ME_HILBERT") ? std::atoi(std::getenv("ME_HILBERT")) : 1;
     {
@@ -578,8 +584,10 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
                            c.origin[1], c.origin[2], c.fine_h, sort_min_level, hilbert, codes_in.as<unsigned long long>(),
                            iota.as<unsigned int>());
     }
-    // Nothing below consumes the order inside a cell 32x finer than the search cell (the 1-NN grid and the octree leaves
-    // sit at or above that level), so the radix sort skips those low bits: 6 passes instead of 8 on the bench scene.
+    // Nothing below consumes the order inside a cell 4x finer than the search cell: the 1-NN grid (and the octree leaves) is
+    // chosen among the SORTED levels, and a quarter-cell that holds the 6 points it aims at means > 380 points in the search
+    // cell (38 000 pts/m^2 of surface at r = 0.1 m); denser clouds simply get more points per 1-NN cell.  So the radix sort
+    // skips the low bits: 5 passes instead of 8 on the bench scene (6 with the five levels sorted at first).
     // The sort is stable, so the order inside such a cell is the input order: still deterministic.
     ME_TRY(sort_pairs_u64_u32(ctx, codes_in.as<unsigned long long>(), c.codes.as<unsigned long long>(),
                               iota.as<unsigned int>(), perm.as<unsigned int>(), n, 3 * sort_min_level, 63));
@@ -641,19 +649,17 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
             hipLaunchKernelGGL(k_oct_leaves, dim3(grid_for(v.count[0] + 1)), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),
                                c.nn_grid.cell_start, v.count[0], n, nodes);
             // prefix codes of the current level (level 0: the cell codes of the 1-NN grid), ping-pong
-            DevBuf &ca = ctx->tmp[2], &cb = ctx->tmp[3], &flags = ctx->tmp[0], &pos = ctx->tmp[1], &begin = ctx->tmp[4];
+            DevBuf &ca = ctx->tmp[2], &cb = ctx->tmp[3], &pos = ctx->tmp[1], &begin = ctx->tmp[4];
             const unsigned long long *cur = c.nn_grid.cell_code;
             for (int l = 0; l + 1 < L; ++l) {
                 const long long nc = v.count[l], np = v.count[l + 1];
-                ME_CHECK(ctx, flags.ensure((size_t) nc * 4));
                 ME_CHECK(ctx, pos.ensure((size_t) nc * 4));
                 ME_CHECK(ctx, begin.ensure((size_t) (np + 1) * 4));
                 DevBuf &nxt = (l % 2 == 0) ? ca : cb;
                 ME_CHECK(ctx, nxt.ensure((size_t) np * 8));
-                hipLaunchKernelGGL(k_cell_flags, dim3(grid_for(nc)), dim3(256), 0, ctx->stream, cur, nc, 3, flags.as<unsigned int>());
-                ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), nc));
-                hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(nc)), dim3(256), 0, ctx->stream, cur, flags.as<unsigned int>(),
-                                   pos.as<unsigned int>(), nc, 3, nxt.as<unsigned long long>(), begin.as<unsigned int>());
+                ME_TRY(cell_start_ranks(ctx, cur, nc, 3, pos.as<unsigned int>()));
+                hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(nc)), dim3(256), 0, ctx->stream, cur, pos.as<unsigned int>(), nc, 3,
+                                   nxt.as<unsigned long long>(), begin.as<unsigned int>());
                 hipLaunchKernelGGL(k_oct_up, dim3(grid_for(np + 1)), dim3(256), 0, ctx->stream, nodes + v.off[l], nc,
                                    begin.as<unsigned int>(), np, nodes + v.off[l + 1]);
                 cur = nxt.as<unsigned long long>();

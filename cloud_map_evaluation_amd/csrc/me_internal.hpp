@@ -256,6 +256,7 @@ inline unsigned int xcd_chunk_setting() {
 int sort_pairs_u64_u32(me_ctx *ctx, const unsigned long long *k_in, unsigned long long *k_out,
                        const unsigned int *v_in, unsigned int *v_out, long long n, int begin_bit, int end_bit);
 int exclusive_scan_u32(me_ctx *ctx, const unsigned int *in, unsigned int *out, long long n);
+int cell_start_ranks(me_ctx *ctx, const unsigned long long *codes, long long n, int shift3, unsigned int *out);
 int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n);
 
 // ---- me_index.hip ----

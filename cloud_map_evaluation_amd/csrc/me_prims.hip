@@ -33,6 +33,27 @@ int exclusive_scan_u32(me_ctx *ctx, const unsigned int *in, unsigned int *out, l
     return ME_OK;
 }
 
+// out[i] = number of cell starts before i, where i starts a cell when (codes[i] >> shift3) differs from its predecessor's:
+// the flags are computed inside the scan (no flag array written and read back)
+struct CellStartFlag {
+    const unsigned long long *codes;
+    int shift3;
+    __device__ unsigned int operator()(size_t i) const {
+        return (i == 0 || (codes[i] >> shift3) != (codes[i - 1] >> shift3)) ? 1u : 0u;
+    }
+};
+
+int cell_start_ranks(me_ctx *ctx, const unsigned long long *codes, long long n, int shift3, unsigned int *out) {
+    if (n <= 0) return ME_OK;
+    auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0), CellStartFlag{codes, shift3});
+    size_t bytes = 0;
+    ME_CHECK(ctx, rocprim::exclusive_scan(nullptr, bytes, flags, out, 0u, (size_t) n, rocprim::plus<unsigned int>(), ctx->stream));
+    ME_CHECK(ctx, ctx->tmp[5].ensure(bytes));
+    ME_CHECK(ctx, rocprim::exclusive_scan(ctx->tmp[5].p, bytes, flags, out, 0u, (size_t) n, rocprim::plus<unsigned int>(),
+                                          ctx->stream));
+    return ME_OK;
+}
+
 int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n) {
     if (n <= 0) return ME_OK;
     size_t bytes = 0;
