@@ -2,7 +2,7 @@
 
 Sharding ("primary" variant): every rank holds both clouds and builds both indices (the
 reference cloud must be complete on every rank: CD's nearest neighbour is unbounded, map_eval.cpp:1398-1431);
-the per-point passes (1-NN both directions, MME) process only the rank's slab of the Morton-sorted query order
+the per-point passes (1-NN both directions, MME) process only the rank's slab of the sorted (space-filling-curve) query order
 (me_set_shard) and return raw partial sums (me_nn_partial / sum_H, n_valid).  The data path needs exactly two
 collectives per suite: one all-reduce (sum) of a 38-double vector of partials, and one all-reduce of the 2 x 5
 sigma numerators (the second pass of map_eval.cpp:1132-1138 needs the global means first).  The voxel / AWD / SCS

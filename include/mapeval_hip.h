@@ -82,7 +82,7 @@ int me_version(void);
 me_ctx *me_twin(me_ctx *ctx);
 
 /* Multi-GPU slab sharding (no reference counterpart; the reference is single-process).  After this call every
- * per-point pass (NN, MME) only processes the `rank`-th of `world` equal slabs of the Morton-sorted query order,
+ * per-point pass (NN, MME) only processes the `rank`-th of `world` equal slabs of the sorted (space-filling-curve) query order,
  * and the voxel passes only own voxels whose key index falls in the rank's slab; partial sums are returned for
  * the caller to all-reduce (RCCL).  Default (0,1) = whole job. */
 int me_set_shard(me_ctx *ctx, int rank, int world);
@@ -146,7 +146,7 @@ int me_voxel_merge_device(me_ctx *ctx, int slot, double voxel_size, const double
 /* ---- clouds ------------------------------------------------------------------------------------------------ */
 /* Replaces: *map_3d_ = map_3d_->Transform(initial_matrix) (map_eval.cpp:1206) + every KDTreeFlann::SetGeometry
  * (map_eval.cpp:1214,1227,1401-1402,1449,1551,1619): uploads the cloud, applies T (row-major 4x4, NULL = none;
- * homogeneous divide as Open3D), Morton-sorts it and builds the search index ONCE.
+ * homogeneous divide as Open3D), sorts it along a space-filling curve and builds the search index ONCE.
  * cell_size: edge of the radius-search grid cell (pass nn_radius; <= 0 = automatic, rebuilt lazily by me_mme). */
 int me_upload_cloud(me_ctx *ctx, int slot, const double *xyz_host, int64_t n, const double *T_rowmajor4x4,
                     double cell_size);
