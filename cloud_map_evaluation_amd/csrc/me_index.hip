@@ -549,7 +549,7 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     const double cell_h = cell_size * (1.0 + 0x1p-20);
     // origin snapped to the global cell lattice: two clouds built with the same cell size get ALIGNED grids, so the
     // points of one cell of the query cloud fall into one cell of the reference cloud (the 1-NN grid pass groups
-    // lanes by reference cell; with a common lattice a wave of Morton-consecutive queries touches few of them)
+    // lanes by reference cell; with a common lattice a wave of curve-consecutive queries touches few of them)
     for (int d = 0; d < 3; ++d) c.origin[d] = std::floor(c.bbox_lo[d] / cell_h) * cell_h;
     extent = 0;
     for (int d = 0; d < 3; ++d) extent = std::fmax(extent, c.bbox_hi[d] - c.origin[d]);
@@ -562,7 +562,7 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     c.cell_h = cell_h;
     c.fine_h = std::ldexp(cell_h, -c.shift);
     c.index_valid = false;
-    c.mme_have = false;  // (Morton order changes)
+    c.mme_have = false;  // (the sorted order changes)
     c.nn_ref_slot = -1;
     ctx->cloud[1 - slot].nn_ref_slot = -1;
 

@@ -68,7 +68,7 @@ struct OctView {
 };
 
 struct GridView {
-    const unsigned long long *cell_code;  // unique cell Morton codes, ascending [n_cells]
+    const unsigned long long *cell_code;  // unique cell Morton codes, in the order of the sorted points [n_cells]
     const unsigned int *cell_start;       // [n_cells + 1] offsets into the sorted points
     const unsigned long long *hkeys;      // open-addressing table, EMPTY = ~0ull
     const unsigned int *hvals;            // cell index
@@ -124,7 +124,7 @@ struct Cloud {
     double fine_h = 0;   // cell_h / 2^shift
     int shift = 0;
     bool index_valid = false;
-    DevBuf codes;  // uint64[n] sorted fine Morton codes
+    DevBuf codes;  // uint64[n] fine Morton code of every sorted point (the points are sorted along the Hilbert curve)
     DevBuf sp;     // SPoint[n] sorted
     // sparse octree (general 1-NN path)
     OctView oct{};
@@ -134,7 +134,7 @@ struct Cloud {
     GridTable grid_tab, nn_tab;
     GridView grid{}, nn_grid{};
     long long level_unique[kMortonBits + 1] = {0};  // occupied cells per Morton level
-    // last NN result with this cloud as the query (Morton-sorted query order)
+    // last NN result with this cloud as the query (sorted query order)
     DevBuf nn_d2, nn_idx, nn_list;
     int nn_ref_slot = -1;
     // voxel table (ascending key order)
@@ -142,7 +142,7 @@ struct Cloud {
     long long n_vox = 0;
     bool vox_valid = false, vox_raw = false;
     bool vox_merged = false;  // the table is the cross-rank merge of partials (me_voxel_merge_device): complete on every rank
-    DevBuf mme_ent, mme_val;  // last me_mme of this cloud, Morton order: entropy (0 where invalid), validity byte
+    DevBuf mme_ent, mme_val;  // last me_mme of this cloud, sorted order: entropy (0 where invalid), validity byte
     bool mme_have = false;
     DevBuf vox_tmp;    // build scratch (segment starts when they outgrow the shared scratch)
     DevBuf vox_key;    // uint64[V] packed key
@@ -526,7 +526,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // distance kGroupR of the leader's; the cell box of the group grown by one (<= 7x7x7 = 343 cells) is resolved with
 // one hash probe per (lane, slot) into a wave-private LDS table `tab` (>= kGroupTab entries of {start, count}).
 // Every group lane then reads the runs of its own 3x3x3 block from the table: tab[(x-x0) + nx*((y-y0) + ny*(z-z0))].
-// 64 Morton-consecutive points almost always form one group, so the whole wave walks its candidates together.
+// 64 curve-consecutive points almost always form one group, so the whole wave walks its candidates together.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kGroupR = 2;
 constexpr int kGroupTab = 343;                               // (2R+1+2H)^3 for halo H = 1
@@ -534,8 +534,8 @@ constexpr int kGroupTab2 = (2 * kGroupR + 5) * (2 * kGroupR + 5) * (2 * kGroupR 
 
 // H = halo in cells: 1 when the cell edge covers the search radius, 2 for half-radius cells (5x5x5 stencil).
 // CULL: a cell of the box is kept only when it lies within Chebyshev distance H of the cell of SOME group lane (the box is
-// the bounding box of the group's cells grown by H: when the cells of 64 Morton-consecutive queries do not fill their
-// bounding box — an L, a diagonal, the two sides of a Z-curve jump — whole runs of it are adjacent to nobody, and every
+// the bounding box of the group's cells grown by H: when the cells of 64 curve-consecutive queries do not fill their
+// bounding box — an L, a diagonal, a staircase — whole runs of it are adjacent to nobody, and every
 // candidate of such a run would be tested by 64 lanes for nothing).  Per (y,z) row of the box the group lanes OR their x
 // position into a bit mask (LDS atomics), a row's mask is then dilated over the 3x3 neighbouring rows and by one bit in x:
 // a few dozen LDS operations per round against 64 x (9..19) VALU operations per candidate saved.  `rows` = 2 x 49 ints.
@@ -548,7 +548,7 @@ __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, i
 #ifdef ME_LEADER_FIRST
     const int leader = __ffsll((long long) pm) - 1;
 #else
-    // The leader is the MIDDLE pending lane, not the first: the lanes hold Morton-consecutive points, the first pending lane
+    // The leader is the MIDDLE pending lane, not the first: the lanes hold curve-consecutive points, the first pending lane
     // sits at one end of the stretch of space they cover and its Chebyshev ball reaches half as far into it.
     const int rank = __popcll(pm & ((1ULL << lane) - 1ULL));
     const int leader = __ffsll((long long) __ballot(pending && rank == (__popcll(pm) >> 1))) - 1;
@@ -622,8 +622,8 @@ constexpr int kGroupRows = 128;  // LDS ints per wave for the CULL row masks (64
 
 // Calls f(begin, end, slot) once per non-empty run of the wave's table, with WAVE-UNIFORM arguments (so that a loop over
 // [begin, end) fetches candidates with scalar loads and all lanes test the same candidate); slot = its table index.
-// MERGE: consecutive table slots whose runs are contiguous in the sorted array (x and x + 1 with x even are neighbours in
-// Morton order) are handed over as ONE run — with 6-point cells the per-run set-up of the 1-NN grid kernel (staging a tile,
+// MERGE: consecutive table slots whose runs are contiguous in the sorted array (the curve visits cell x + 1 right after
+// cell x) are handed over as ONE run — with 6-point cells the per-run set-up of the 1-NN grid kernel (staging a tile,
 // two barriers, the tail of the group-of-four loop) costs more than ranking the run's candidates.
 template <bool MERGE = false, class F>
 __device__ __forceinline__ void wave_for_each_run(const int2 *tab, int n_keys, int lane, F &&f) {

@@ -151,7 +151,8 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
 
 #ifdef ME_MME_STATS
 // build with -DME_MME_STATS (profiles/README.md): per launch, [0] wave rounds, [1] candidates streamed, [2] lanes served,
-// [3] accepted (query, candidate) pairs — printed to stderr by mme_run
+// [3] accepted (query, candidate) pairs, [4..6] rounds / candidates / lanes served of the rounds after a wave's first —
+// printed to stderr by mme_run
 __device__ unsigned long long g_mme_stat[8];
 #endif
 
@@ -226,6 +227,9 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
     bool have_det = false;  // the query has at least min_k neighbours
     // A lane accumulates in exactly ONE round (the one whose group it belongs to), so the moments live inside the round:
     // nothing of them is alive while the next round's table is built.
+#ifdef ME_MME_STATS
+    int st_round = 0;
+#endif
     while (__ballot(!done)) {
         GroupBox bx;
         int nk = 0;
@@ -322,7 +326,13 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 atomicAdd(&g_mme_stat[1], (unsigned long long) st_cand);
                 atomicAdd(&g_mme_stat[2], (unsigned long long) served);
                 atomicAdd(&g_mme_stat[3], (unsigned long long) ka);
+                if (st_round > 0) {  // what the rounds after a wave's first one cost and serve
+                    atomicAdd(&g_mme_stat[4], 1ULL);
+                    atomicAdd(&g_mme_stat[5], (unsigned long long) st_cand);
+                    atomicAdd(&g_mme_stat[6], (unsigned long long) served);
+                }
             }
+            ++st_round;
         }
 #endif
         if (in) {
@@ -497,9 +507,10 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
         (void) hipMemcpyFromSymbol(st, HIP_SYMBOL(g_mme_stat), sizeof st);
         (void) hipMemcpyToSymbol(HIP_SYMBOL(g_mme_stat), zero, sizeof zero);
         if (st[0])
-            std::fprintf(stderr, "[mme stats] queries=%lld wave rounds=%llu (%.3f per 64 queries) candidates/round=%.1f lanes served/round=%.1f accepted/query=%.1f\n",
+            std::fprintf(stderr, "[mme stats] queries=%lld wave rounds=%llu (%.3f per 64 queries) candidates/round=%.1f lanes served/round=%.1f accepted/query=%.1f | rounds after a wave's first: %llu, candidates/round=%.1f lanes served/round=%.1f\n",
                          (long long) (e - b), st[0], (double) st[0] * 64.0 / (double) (e - b), (double) st[1] / (double) st[0],
-                         (double) st[2] / (double) st[0], (double) st[3] / (double) (e - b));
+                         (double) st[2] / (double) st[0], (double) st[3] / (double) (e - b), st[4],
+                         st[4] ? (double) st[5] / (double) st[4] : 0.0, st[4] ? (double) st[6] / (double) st[4] : 0.0);
     }
 #endif
     c.mme_have = true;

@@ -49,7 +49,7 @@ __device__ __forceinline__ double box_upper_bound(const float *__restrict__ b, d
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Fast path: uniform-grid 1-NN.  A wavefront owns 64 consecutive (Morton-ordered) queries.  The lanes whose
+// Fast path: uniform-grid 1-NN.  A wavefront owns 64 consecutive (curve-ordered) queries.  The lanes whose
 // reference-grid cell lies within Chebyshev distance 2 of the leader's form a group (normally the whole wave); the
 // group's cell box grown by one is resolved with one hash probe per (lane, slot) into a wave-private LDS table, and
 // every non-empty run is streamed ONCE through a wave-private LDS tile (one coalesced load per run, broadcast reads), every

@@ -207,7 +207,7 @@ constexpr int kKnnBlock = 128;
 constexpr int kKnnMax = 40;  // k * 128 lanes * 12 B of LDS <= 60 KB
 
 // ---- k nearest neighbours of every point of a cloud IN that cloud + the normal of their raw-moment covariance ----
-// One lane per query (Morton order, so a wave walks neighbouring paths); the k best so far live in LDS, sorted
+// One lane per query (sorted order, so a wave walks neighbouring paths); the k best so far live in LDS, sorted
 // ascending by (d2, original index), element j of lane t at [j * blockDim + t] (conflict-free).  The walk is the
 // stackless nearest-first one of k_nn1 with the k-th best as the bound (<=: a tie may hold a smaller index).
 __global__ void __launch_bounds__(kKnnBlock)

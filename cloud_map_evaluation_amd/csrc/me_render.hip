@@ -31,7 +31,7 @@ __device__ __forceinline__ void jet_color(double value, double *rgb) {
     rgb[2] = jet_base(value * 2.0 - 0.5);
 }
 
-// one thread per (Morton-ordered) query: colour + inlier flag scattered to the caller's cloud order
+// one thread per (curve-ordered) query: colour + inlier flag scattered to the caller's cloud order
 __global__ void k_render_distance(const SPoint *__restrict__ qsp, const double *__restrict__ d2s, long long n, double dis,
                                   double gate, int gate_strict, double *__restrict__ rgb, unsigned char *__restrict__ inlier) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,7 +73,7 @@ k_minmax_nonzero(const double *__restrict__ v, long long n, double *__restrict__
     }
 }
 
-// Morton order -> cloud order: entropy and validity flag (as a 32-bit flag for the scan)
+// sorted order -> cloud order: entropy and validity flag (as a 32-bit flag for the scan)
 __global__ void k_entropy_unpermute(const SPoint *__restrict__ sp, const double *__restrict__ ent_s,
                                     const unsigned char *__restrict__ val_s, long long n, double *__restrict__ ent_o,
                                     unsigned int *__restrict__ flag_o) {

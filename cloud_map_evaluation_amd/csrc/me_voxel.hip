@@ -46,7 +46,7 @@ __device__ __forceinline__ unsigned long long voxel_key_of(double x, double y, d
 }
 
 // ---- voxel statistics straight from the Morton-sorted cloud ----------------------------------------------------
-// A voxel is large next to the search cell, so Morton-consecutive points mostly share their voxel: every wavefront
+// A voxel is large next to the search cell, so curve-consecutive points mostly share their voxel: every wavefront
 // (64 consecutive sorted points) splits into a few RUNS of equal key.  Pass 1 reduces (n, sum p) per run with a
 // segmented butterfly and emits one record per run; the records (about n/60 of them, not n) are radix-sorted by key,
 // one wavefront per voxel adds its records up in that fixed order -> mean; pass 2 emits sum (p-mean)(p-mean)^T per run
@@ -724,7 +724,7 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
         hipLaunchKernelGGL(k_vox_pass1, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sp, n, voxel_size, c.slab, wave_off, rec_key,
                            iota, rec_n, rec_sum, d_err);
     }
-    // radix sort is stable: Morton order is preserved inside every voxel (fixed summation order)
+    // radix sort is stable: the sorted order is preserved inside every voxel (fixed summation order)
     ME_TRY(sort_pairs_u64_u32(ctx, rec_key, skey, iota, perm_r, R, 0, 63));
     hipLaunchKernelGGL(k_head_flags, dim3(grid_for(R)), dim3(256), 0, ctx->stream, skey, R, flags);
     ME_TRY(exclusive_scan_u32(ctx, flags, pos, R));
