@@ -220,7 +220,7 @@ __global__ void k_gather(const double *__restrict__ xyz, const unsigned int *__r
 
 // octree level 0: one node per occupied 1-NN-grid cell (a contiguous run of sorted points)
 __global__ void k_oct_leaves(const SPoint *__restrict__ sp, const unsigned int *__restrict__ cell_start, long long n_cells,
-                             long long n_points, ONode *__restrict__ nodes) {
+                             long long n_points, ONode *__restrict__ nodes, unsigned int *__restrict__ pbegin) {
     const long long c = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (c > n_cells) return;
     ONode nd;
@@ -229,6 +229,7 @@ __global__ void k_oct_leaves(const SPoint *__restrict__ sp, const unsigned int *
         nd.begin = (unsigned int) n_points;
         nd.parent = 0;
         nodes[c] = nd;
+        pbegin[c] = (unsigned int) n_points;
         return;
     }
     const long long b = cell_start[c], e = cell_start[c + 1];
@@ -247,11 +248,13 @@ __global__ void k_oct_leaves(const SPoint *__restrict__ sp, const unsigned int *
     nd.begin = (unsigned int) b;
     nd.parent = 0;
     nodes[c] = nd;
+    pbegin[c] = (unsigned int) b;
 }
 
 // octree level l+1 from level l: parent p owns the children [begin[p], begin[p+1]) (<= 8, contiguous)
 __global__ void k_oct_up(ONode *__restrict__ child, long long n_child, const unsigned int *__restrict__ begin,
-                         long long n_parent, ONode *__restrict__ parent) {
+                         long long n_parent, ONode *__restrict__ parent, const unsigned int *__restrict__ child_pbegin,
+                         unsigned int *__restrict__ parent_pbegin) {
     const long long p = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n_parent) return;
     ONode nd;
@@ -260,6 +263,7 @@ __global__ void k_oct_up(ONode *__restrict__ child, long long n_child, const uns
         nd.begin = (unsigned int) n_child;
         nd.parent = 0;
         parent[p] = nd;
+        parent_pbegin[p] = child_pbegin[n_child];  // (the child level's terminator: the point count)
         return;
     }
     const long long b = begin[p], e = (p + 1 < n_parent) ? (long long) begin[p + 1] : n_child;
@@ -280,6 +284,7 @@ __global__ void k_oct_up(ONode *__restrict__ child, long long n_child, const uns
     nd.begin = (unsigned int) b;
     nd.parent = 0;
     parent[p] = nd;
+    parent_pbegin[p] = child_pbegin[b];
 }
 
 // the first point of every cell (code >> shift3 differs from the predecessor's) writes the cell's code and start; pos[i] =
@@ -644,10 +649,14 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
             v.n_levels = L;
             ME_CHECK(ctx, c.oct_nodes.ensure((size_t) (off + kFan) * sizeof(ONode)));  // + slack for the 8-record burst
             ME_CHECK(ctx, hipMemsetAsync(c.oct_nodes.as<ONode>() + off, 0, kFan * sizeof(ONode), ctx->stream));
+            ME_CHECK(ctx, c.oct_pbegin.ensure((size_t) (off + kFan + 1) * 4));
+            ME_CHECK(ctx, hipMemsetAsync(c.oct_pbegin.as<unsigned int>() + off, 0, (kFan + 1) * 4, ctx->stream));
             v.nodes = c.oct_nodes.as<ONode>();
+            v.pbegin = c.oct_pbegin.as<unsigned int>();
             ONode *nodes = c.oct_nodes.as<ONode>();
+            unsigned int *pbeg = c.oct_pbegin.as<unsigned int>();
             hipLaunchKernelGGL(k_oct_leaves, dim3(grid_for(v.count[0] + 1)), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),
-                               c.nn_grid.cell_start, v.count[0], n, nodes);
+                               c.nn_grid.cell_start, v.count[0], n, nodes, pbeg);
             // prefix codes of the current level (level 0: the cell codes of the 1-NN grid), ping-pong
             DevBuf &ca = ctx->tmp[2], &cb = ctx->tmp[3], &pos = ctx->tmp[1], &begin = ctx->tmp[4];
             const unsigned long long *cur = c.nn_grid.cell_code;
@@ -661,7 +670,7 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
                 hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(nc)), dim3(256), 0, ctx->stream, cur, pos.as<unsigned int>(), nc, 3,
                                    nxt.as<unsigned long long>(), begin.as<unsigned int>());
                 hipLaunchKernelGGL(k_oct_up, dim3(grid_for(np + 1)), dim3(256), 0, ctx->stream, nodes + v.off[l], nc,
-                                   begin.as<unsigned int>(), np, nodes + v.off[l + 1]);
+                                   begin.as<unsigned int>(), np, nodes + v.off[l + 1], pbeg + v.off[l], pbeg + v.off[l + 1]);
                 cur = nxt.as<unsigned long long>();
             }
         }

@@ -62,6 +62,7 @@ struct alignas(32) ONode {
 };
 struct OctView {
     const ONode *nodes;
+    const unsigned int *pbegin;  // first sorted point below every node (indexed like `nodes`; a level's terminator holds n)
     int n_levels;  // level 0 = leaf cells ... level n_levels-1 = root (1 node)
     long long count[kMaxLevels];
     long long off[kMaxLevels];  // offset of each level inside `nodes` (each level stores count + 1 records)
@@ -129,6 +130,7 @@ struct Cloud {
     // sparse octree (general 1-NN path)
     OctView oct{};
     DevBuf oct_nodes;
+    DevBuf oct_pbegin;
     // cell tables: `grid` at the radius level (MME), `nn_grid` at the level whose occupied cells hold ~16 points
     // (1-NN fast path); they share storage when the two levels coincide
     GridTable grid_tab, nn_tab;
@@ -196,6 +198,7 @@ struct me_ctx {
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
     long long nn_fallback = 0, nn_queries = 0;  // counted only while timers are on
+    me::DevBuf nn_far;                           // queries whose octree walk k_nn1 handed over to k_nn_far
     me::DevBuf nn1_dbg_buf;                      // octree-walk counters (nodes opened, leaves scanned, points, max per query)
     unsigned long long *nn1_dbg() {
         if (!nn1_dbg_buf.p) {

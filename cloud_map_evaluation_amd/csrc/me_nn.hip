@@ -265,7 +265,11 @@ constexpr int kNn1Block = 128;  // 16 octets per block: 16 x 18 levels x (8 floa
 __global__ void __launch_bounds__(kNn1Block)
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
       OctView oct, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
-      const unsigned int *__restrict__ list_count, int use_bound, unsigned long long *__restrict__ dbg) {
+      const unsigned int *__restrict__ list_count, int use_bound, unsigned long long *__restrict__ dbg,
+      unsigned int *__restrict__ far_list, unsigned int *__restrict__ far_count, int far_cap) {
+    // far_list: a walk that has taken `far_cap` steps is ABANDONED here — its best so far is stored as usual, a valid upper
+    // bound — and its query appended to far_list for k_nn_far (a whole wavefront per query, big leaves scanned 64 points
+    // abreast): the longest chain of dependent steps in this kernel is far_cap, not the walk of the farthest outlier.
     __shared__ long long s_off[kMaxLevels];
     __shared__ float s_lb[kNn1Block / 8][kMaxLevels + 1][8];          // per octet, per level: the children's lower bounds
     __shared__ unsigned int s_beg[kNn1Block / 8][kMaxLevels + 1][9];  // ... and their [begin, end) on the level below
@@ -325,6 +329,7 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                 best_i = li;
             }
         };
+        bool far_flag = false;
         if (L == 0) {
             scan_points(alive, 0, nr);  // the whole cloud is one cell
         } else {
@@ -372,7 +377,12 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            bool far = false;
             while (__ballot(walking)) {
+                if (far_list && walking && n_open + n_scan >= (unsigned int) far_cap) {
+                    far = true;
+                    walking = false;
+                }
                 const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
                                                  : (unsigned int) (taken_hi >> (8 * (l - 9))) & 0xffu;
                 const double lbd = walking ? (double) c_lb[l * 8 + sub] : INFINITY;
@@ -419,6 +429,17 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+            far_flag = far;
+        }
+        {  // abandoned walks go to the far list (wave-aggregated append)
+            const unsigned long long fm = __ballot(far_flag && sub == 0);
+            if (fm) {
+                unsigned int base = 0;
+                if ((threadIdx.x & 63) == 0) base = atomicAdd(far_count, (unsigned int) __popcll(fm));
+                base = (unsigned int) __builtin_amdgcn_readfirstlane((int) base);
+                if (far_flag && sub == 0)
+                    far_list[base + (unsigned int) __popcll(fm & ((1ULL << (threadIdx.x & 63)) - 1ULL))] = (unsigned int) (i - q_begin);
+            }
         }
         if (alive && sub == 0) {
             d2_out[i] = best;
@@ -431,6 +452,145 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
             }
         }
     }  // grid-stride loop over octets
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_nn_far — the walks k_nn1 abandoned (far_list), ONE WAVEFRONT PER QUERY.
+// A query far from the reference surface (an outlier metres above the ground) must look into every leaf cell that its
+// current best distance reaches: a disc of hundreds of 6-point cells, one dependent step each in k_nn1 (734 steps for the
+// worst query of the bench pair, ~3 us per step: that ONE walk was the kernel's duration).  Here the walk stops descending
+// at a node that holds at most `far_leaf` points — a contiguous run of the sorted array, `pbegin` — and scans it with all 64
+// lanes, four independent loads per lane in flight: a handful of dependent steps and a few streaming scans per query.
+// Same pruning rule as k_nn1 (a child is entered while its lower bound is <= the bound; ties -> smallest reference
+// index), the walk restarts from the root with the abandoned walk's best as its bound: the result is the exact minimum.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__restrict__ rsp, OctView oct,
+         double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ far_list,
+         const unsigned int *__restrict__ far_count, int far_leaf, unsigned long long *__restrict__ dbg) {
+    __shared__ long long s_off[kMaxLevels];
+    __shared__ float s_lb[4][kMaxLevels + 1][8];
+    __shared__ unsigned int s_beg[4][kMaxLevels + 1][9], s_pb[4][kMaxLevels + 1][9];
+    if (threadIdx.x < kMaxLevels) s_off[threadIdx.x] = oct.off[threadIdx.x];
+    __syncthreads();
+    const int L = oct.n_levels - 1;
+    if (L == 0) return;  // (a one-cell cloud never abandons a walk)
+    const ONode *__restrict__ nodes = oct.nodes;
+    const unsigned int *__restrict__ pbegin = oct.pbegin;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *c_lb = s_lb[wv][0];
+    unsigned int *c_beg = s_beg[wv][0], *c_pb = s_pb[wv][0];
+    const unsigned int n_far = *far_count;
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&dbg[4], (unsigned long long) n_far);  // "nn1_far"
+    for (unsigned int t = blockIdx.x * 4u + (unsigned int) wv; t < n_far; t += gridDim.x * 4u) {
+        const long long i = q_begin + (long long) far_list[t];
+        const SPoint q = qsp[i];
+        const double qx = q.x, qy = q.y, qz = q.z;
+        double best = d2_out[i];
+        long long best_i = idx_out[i] >= 0 ? (long long) idx_out[i] : 0x7fffffffffffffffLL;
+        double bound = best;
+        unsigned long long taken_lo = 0, taken_hi = 0;  // wave-uniform
+        int l = L;
+        // children [cb, ce) of a node -> level lev's cache line (lanes 0..7 bound one child each)
+        auto open_node = [&](int lev, unsigned int cb, unsigned int ce) {
+            const int cnt = (int) (ce - cb);
+            double ub = INFINITY;
+            if (lane < 8) {
+                const long long at = s_off[lev - 1] + (long long) cb + lane;  // (8 records of slack behind the last level)
+                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(nodes + at);
+                const float4 a = g[0], bb = g[1];
+                const float f[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
+                const bool mine = lane < cnt;
+                if (mine) ub = box_upper_bound(f, qx, qy, qz);
+                c_lb[lev * 8 + lane] = mine ? __double2float_rd(box_lower_bound(f, qx, qy, qz)) : INFINITY;
+                c_beg[lev * 9 + lane] = __float_as_uint(bb.z);
+                c_pb[lev * 9 + lane] = pbegin[at];
+                if (lane == 7 || lane == cnt - 1) {
+                    c_beg[lev * 9 + lane + 1] = nodes[at + 1].begin;
+                    c_pb[lev * 9 + lane + 1] = pbegin[at + 1];
+                }
+            }
+            ub = octet_min(ub);  // (lanes 8..63 hold +inf: their octets reduce to +inf)
+            bound = fmin(bound, uniform_f64(ub));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        {
+            const ONode *__restrict__ root = nodes + s_off[L];
+            open_node(L, root[0].begin, root[1].begin);
+        }
+        for (;;) {
+            const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
+                                             : (unsigned int) (taken_hi >> (8 * (l - 9))) & 0xffu;
+            const double lbd = lane < 8 ? (double) c_lb[l * 8 + lane] : INFINITY;
+            const bool ok = lane < 8 && !((tk >> lane) & 1u) && lbd <= bound;  // <=: ties may hold a smaller index
+            double kd = ok ? lbd : INFINITY;
+            int kc = ok ? lane : 8;
+            auto pick = [&](double od, int oc) {
+                if (od < kd || (od == kd && oc < kc)) {
+                    kd = od;
+                    kc = oc;
+                }
+            };
+            pick(octet_partner_d<0>(kd), octet_partner_i<0>(kc));
+            pick(octet_partner_d<1>(kd), octet_partner_i<1>(kc));
+            pick(octet_partner_d<2>(kd), octet_partner_i<2>(kc));
+            kc = __builtin_amdgcn_readfirstlane(kc);
+            if (kc >= 8) {  // nothing left under this node
+                if (l == L) break;
+                ++l;
+                continue;
+            }
+            if (l <= 8) taken_lo |= 1ULL << (8 * (l - 1) + kc);
+            else taken_hi |= 1ULL << (8 * (l - 9) + kc);
+            const unsigned int cb = c_beg[l * 9 + kc], ce = c_beg[l * 9 + kc + 1];
+            const unsigned int pb = c_pb[l * 9 + kc], pe = c_pb[l * 9 + kc + 1];
+            if (l == 1 || pe - pb <= (unsigned int) far_leaf) {
+                // scan the node's points, 4 x 64 at a time (clamped addresses keep the four loads unconditional)
+                double lb = best;
+                long long li = best_i;
+                for (unsigned int j0 = pb; j0 < pe; j0 += 256u) {
+                    SPoint p[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned int j = j0 + 64u * u + (unsigned int) lane;
+                        p[u] = rsp[j < pe ? j : pe - 1u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned int j = j0 + 64u * u + (unsigned int) lane;
+                        const double d = dist2_exact(qx, qy, qz, p[u].x, p[u].y, p[u].z);
+                        if (j < pe && (d < lb || (d == lb && p[u].idx < li))) {
+                            lb = d;
+                            li = p[u].idx;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    const double od = __shfl_xor(lb, m, 64);
+                    const long long oi = __shfl_xor(li, m, 64);
+                    if (od < lb || (od == lb && oi < li)) {
+                        lb = od;
+                        li = oi;
+                    }
+                }
+                best = lb;
+                best_i = li;
+                bound = fmin(bound, best);
+            } else {  // [cb, ce) are the chosen child's children, on level l - 2
+                --l;
+                if (l <= 8) taken_lo &= ~(0xffULL << (8 * (l - 1)));
+                else taken_hi &= ~(0xffULL << (8 * (l - 9)));
+                open_node(l, cb, ce);
+            }
+        }
+        if (lane == 0) {
+            d2_out[i] = best;
+            idx_out[i] = (int) best_i;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---- un-permute results to the caller's (original) query order ----
@@ -647,6 +807,18 @@ __global__ void k_nn_patch(const unsigned int *__restrict__ list, long long m, c
     d2[i] = fmin(d2[i], d2_new[t]);
 }
 
+// steps after which k_nn1 hands a walk over to k_nn_far (ME_NN1_FAR_CAP; 0 = never: the first version's behaviour)
+static int nn1_far_cap() {
+    static const int v = std::getenv("ME_NN1_FAR_CAP") ? std::atoi(std::getenv("ME_NN1_FAR_CAP")) : 64;
+    return v <= 0 ? 0x7fffffff : v;
+}
+// points a node may hold for k_nn_far to scan it whole instead of descending further (ME_NN_FAR_LEAF)
+static int nn_far_leaf() {
+    static const int v = std::getenv("ME_NN_FAR_LEAF") ? std::atoi(std::getenv("ME_NN_FAR_LEAF")) : 1024;
+    return v < 1 ? 1 : v;
+}
+constexpr unsigned int kFarGrid = 2048;  // blocks of four wavefronts: what the device holds at once, striding over the far list
+
 int nn_search(me_ctx *ctx, int qslot, int rslot) {
     if (qslot < 0 || qslot > 1 || rslot < 0 || rslot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
     Cloud &q = ctx->cloud[qslot];
@@ -670,7 +842,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
     } else if (e > b) {
         const unsigned int nb = (unsigned int) (((e - b + 255) / 256 + 7) / 8 * 8);  // multiple of 8 (XCD chunking)
         ME_CHECK(ctx, q.nn_list.ensure((size_t) (e - b) * 4 + 64));
-        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));  // [0] unresolved-list length, [1] far-list length
         FrameView fr{r.origin[0], r.origin[1], r.origin[2], r.fine_h};
         {
             TimerScope ts(ctx, "nn_grid");
@@ -681,9 +853,14 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)
             const unsigned int nbf = (unsigned int) std::min<long long>(2LL * nb, 256 * 32);
+            // (the far list can hold every query of the list: sized like it)
+            ME_CHECK(ctx, ctx->nn_far.ensure((size_t) (e - b) * 4 + 64));
             TimerScope ts(ctx, "nn1");
             hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
                                r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0,
+                               ctx->timers_on ? ctx->nn1_dbg() : nullptr, ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap());
+            hipLaunchKernelGGL(k_nn_far, dim3(kFarGrid), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, r.sp.as<SPoint>(), r.oct,
+                               q.nn_d2.as<double>(), q.nn_idx.as<int>(), ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn_far_leaf(),
                                ctx->timers_on ? ctx->nn1_dbg() : nullptr);
         }
         if (ctx->timers_on) {  // fallback share, for the bench report
@@ -736,10 +913,13 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
         ME_CHECK(ctx, qs.ensure((size_t) m * sizeof(SPoint)));
         ME_CHECK(ctx, qi.ensure((size_t) m * 4));
         hipLaunchKernelGGL(k_points_to_sp, dim3(nb), dim3(256), 0, ctx->stream, xyz_device, m, qs.as<SPoint>());
+        // (caller-supplied points — the cross-rank step, bulk queries — keep the plain octet walk: the hand-over to k_nn_far
+        // is tuned and measured on the list the grid pass leaves behind)
         TimerScope ts(ctx, "nn1");
         hipLaunchKernelGGL(k_nn1, dim3(std::min<unsigned int>(2 * nb, 256 * 32)), dim3(kNn1Block), 0, ctx->stream, qs.as<SPoint>(), 0LL, m,
                            r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
-                           (const unsigned int *) nullptr, bounded ? 1 : 0, ctx->timers_on ? ctx->nn1_dbg() : nullptr);
+                           (const unsigned int *) nullptr, bounded ? 1 : 0, ctx->timers_on ? ctx->nn1_dbg() : nullptr,
+                           (unsigned int *) nullptr, (unsigned int *) nullptr, 0);
     }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());

@@ -316,7 +316,7 @@ int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out);
  * the last me_timers_reset: "nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "voxel", "w2", "scs", "slab_filter", "halo_pack".  Enabled by me_timers_enable(1).
  * Counters (total_ms = 0, value in *launches): "nn_queries" / "nn_fallback_queries" (1-NN queries, and those that needed the
  * octree pass), "nn1_opened" / "nn1_scans" / "nn1_points" / "nn1_max_opened" (octree walk: nodes opened, leaf cells and points
- * scanned, the longest chain of one query). */
+ * scanned, the longest chain of one query in the octet walk), "nn1_far" (walks handed over to the wave-per-query kernel). */
 int me_timers_enable(me_ctx *ctx, int on);
 int me_timers_reset(me_ctx *ctx);
 int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
