@@ -3,7 +3,7 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run,
 one rank per GPU over RCCL.  One "step" = one pass of the whole hot path over the synthetic pair, starting from the
-two clouds RESIDENT IN HBM (raw, unsorted fp64 AoS) and ending with every scalar on the host: Morton sort + index
+two clouds RESIDENT IN HBM (raw, unsorted fp64 AoS) and ending with every scalar on the host: space-filling-curve sort + index
 build, both 1-NN passes + AC/COM/CD statistics, est-MME (+ GT-MME), voxel Gaussians, AWD, CDF sort, SCS.
 `value` = (N_est + N_gt) / step time of that span.  SURVEY.md 8(d) defines the span from HOST memory; the same steps timed from
 pinned host buffers (PCIe included) are reported next to it as `h2d_inclusive` — never as `value`.
