@@ -49,7 +49,7 @@ WORKLOADS = {
                    what="scan_pair: GT campus scene, est = one independent scan (drift, noise, outliers, thinning)"),
     "c3_20m": dict(points=20_000_000, density=2500.0, radius=0.1, voxel=3.0, what="scan_pair at 20 M"),
     "c5_tunnel": dict(points=100_000_000, density=2500.0, radius=0.1, voxel=2.0,
-                      what="tunnel_pair: tunnel + flat field + staircase (degenerate voxel covariances), est = perturbed GT"),
+                      what="tunnel_pair: tunnel + flat field + staircase (degenerate voxel covariances), est = an independent scan, 100 M + 100 M"),
 }
 
 
@@ -87,7 +87,7 @@ def make_pair(args, device):
     if args.workload == "c4_multisession":
         return synth.multisession_pair(args.points, 3, density=args.density, seed=100, device=device)
     if args.workload == "c5_tunnel":
-        return synth.tunnel_pair(args.points, density=args.density, seed=300, device=device)
+        return synth.tunnel_pair(args.points, density=args.density, seed=300, device=device, equal_sizes=True)
     return synth.scan_pair(args.points, density=args.density, seed=100, device=device)
 
 

@@ -207,26 +207,45 @@ def multisession_pair(n: int, sessions: int = 3, density: float = 2500.0, seed: 
     return est, gt
 
 
-def tunnel_pair(n: int, density: float = 2500.0, seed: int = 300, device="cpu"):
-    """C5: tunnel (cylinder r = 3 m) + flat field + staircase: near-rank-1/2 voxel covariances."""
-    g = _gen(seed, device)
+def tunnel_scene(n: int, density: float = 2500.0, seed: int = 300, device="cpu", n_ref=None, sample_seed=None):
+    """Tunnel (cylinder r = 3 m) + flat field + staircase.  The extents follow from n_ref (default n) points at `density`;
+    n points are sampled on them (a different sample_seed = an independent scan of the same geometry)."""
+    n_ref = n if n_ref is None else n_ref
+    g = _gen(seed if sample_seed is None else sample_seed, device)
     n_t = n // 2
     n_f = n // 3
     n_s = n - n_t - n_f
-    Lt = n_t / density / (2 * math.pi * 3.0)
+    r_t, r_f = (n_ref // 2), (n_ref // 3)
+    r_s = n_ref - r_t - r_f
+    Lt = r_t / density / (2 * math.pi * 3.0)
     th = _rand(n_t, g, device, 0.0, 2 * math.pi)
     xt = _rand(n_t, g, device, 0.0, Lt)
     tun = torch.stack([xt, 3.0 * torch.cos(th), 3.0 + 3.0 * torch.sin(th)], dim=1)
-    Lf = math.sqrt(n_f / density)
+    Lf = math.sqrt(r_f / density)
     fld = torch.stack([_rand(n_f, g, device, 0.0, Lf), _rand(n_f, g, device, 10.0, 10.0 + Lf),
                        torch.zeros(n_f, dtype=F64, device=device)], dim=1)
     # staircase: steps 0.3 m deep, 0.17 m high, 2 m wide
-    Ls = n_s / density / 2.0
+    Ls = r_s / density / 2.0
     sx = _rand(n_s, g, device, 0.0, Ls)
     step = torch.floor(sx / 0.3)
     stairs = torch.stack([sx, _rand(n_s, g, device, -12.0, -10.0), step * 0.17], dim=1)
     gt = torch.cat([tun, fld, stairs], dim=0)
+    del tun, fld, stairs, th, xt, sx, step
     gt = gt + _randn(gt.shape, g, device, 1e-3)
-    gt = gt[torch.randperm(gt.shape[0], generator=g, device=device)].contiguous()
-    est = perturb(gt, seed + 1, noise_std=0.01, drift=0.03, outlier_ratio=0.0)
-    return est, gt
+    return gt[torch.randperm(gt.shape[0], generator=g, device=device)].contiguous()
+
+
+def tunnel_pair(n: int, density: float = 2500.0, seed: int = 300, device="cpu", equal_sizes: bool = False):
+    """C5: tunnel + flat field + staircase: near-rank-1/2 voxel covariances.  est = the perturbed ground truth (thinned to
+    ~85 %), or with equal_sizes (BASELINE.json: "100 M-pt dense map pair") an independent, oversampled scan of the same
+    geometry, perturbed and cut to exactly n points."""
+    gt = tunnel_scene(n, density, seed, device)
+    if not equal_sizes:
+        return perturb(gt, seed + 1, noise_std=0.01, drift=0.03, outlier_ratio=0.0), gt
+    n_raw = int(n * 1.25)
+    raw = tunnel_scene(n_raw, density, seed, device, n_ref=n, sample_seed=seed + 1000)
+    est = perturb(raw, seed + 1, noise_std=0.01, drift=0.03, outlier_ratio=0.0)
+    del raw
+    if est.shape[0] < n:
+        raise ValueError("oversampling factor too small for the requested point count")
+    return est[:n].contiguous(), gt

@@ -1,0 +1,353 @@
+"""The parity pin of SURVEY section 8(c): the oracle against `oracle/_ref` = the REFERENCE'S OWN map_eval.cpp and
+voxel_calculator.cpp, compiled unmodified from /root/reference over functional stand-in headers (oracle/ref_build/).
+
+What runs inside `_ref` is the reference's control flow and expressions; what is still the builder's is the stand-in
+matrix / KD-tree layer, which is itself checked here against numpy / brute force (second half of the file).
+
+Bars: counts bit-for-bit, floating-point results <= 1e-12 relative (only the summation order may differ).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import ref
+from cloud_map_evaluation_amd import synth
+
+pytestmark = pytest.mark.skipif(not ref.available(), reason="no oracle/_ref library and no /root/reference to build it from")
+
+TRUNC = np.array([0.2, 0.1, 0.08, 0.05, 0.01])
+ROWS = ("mean", "rmse", "fitness", "sigma", "number")
+
+
+@pytest.fixture(scope="module")
+def c1():
+    """100 k-point cube pair, all metrics."""
+    est, gt = synth.cube_pair(100_000, seed=42)
+    est, gt = est.numpy(), gt.numpy()
+    cfg = ref.config(trunc=TRUNC, icp_max_distance=1.0, nn_radius=0.1, vmd_voxel_size=0.5)
+    return est, gt, ref.suite_initial(est, gt, cfg)
+
+
+def assert_stats(got: dict, exp, fp_rtol=1e-12):
+    assert np.array_equal(got["number"], np.asarray(exp.number, float)), "inlier counts"
+    for k in ("mean", "rmse", "fitness", "sigma"):
+        np.testing.assert_allclose(got[k], getattr(exp, k), rtol=fp_rtol, atol=0, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the reference's process() body at C1
+# ------------------------------------------------------------------------------------------------------------------
+def test_c1_ac_com_est_to_gt(c1):
+    """calculateMetricsWithInitialMatrix + getDiffRegResultWithCorrespondence (map_eval.cpp:1204-1260, :1069-1145)."""
+    est, gt, r = c1
+    assert_stats(r["est_gt"], oracle.reg_stats(est, gt, 1.0, 0, TRUNC))
+    assert np.array_equal(r["est_transformed"], est)  # identity initial_matrix leaves the map bit-identical (:1206)
+
+
+def test_c1_gt_to_est_is_the_references_swapped_pairing(c1):
+    """SURVEY finding 4: the reference pushes (map_idx, gt_idx) (:1233) but reads source = gt[pair0], target = map[pair1]
+    (:1241, :1093-1094).  `_ref` does what the reference does; restating THAT with numpy reproduces it, and the intended
+    pairing — what the oracle and the engine compute — is a different number."""
+    est, gt, r = c1
+    idx, _ = oracle.nn1(est, gt)                  # nearest map point of every gt point
+    keep = oracle.nn1(est, gt)[1] <= 1.0
+    pairs = np.stack([idx[keep], np.nonzero(keep)[0]], 1)          # (map index, gt index) as pushed at :1233
+    d = np.linalg.norm(gt[pairs[:, 0]] - est[pairs[:, 1]], axis=1)  # ... read as gt[pair0], map[pair1]
+    number = np.array([(d <= t).sum() for t in TRUNC], float)
+    assert np.array_equal(r["gt_est"]["number"], number)
+    np.testing.assert_allclose(r["gt_est"]["rmse"], [np.sqrt((d[d <= t] ** 2).sum() / len(d)) for t in TRUNC], rtol=1e-12)
+    intended = oracle.reg_stats(gt, est, 1.0, 0, TRUNC)
+    assert not np.array_equal(intended.number, number)
+    # the same reference function on the INTENDED pairs (gt_i, nn_in_map) is what the oracle reports
+    got = ref.diff_reg_result(0, gt, est, np.stack([np.nonzero(keep)[0], idx[keep]], 1), TRUNC)
+    assert_stats(got, intended)
+
+
+def test_c1_cd_f1_iou_vectors(c1):
+    est, gt, r = c1
+    eg = oracle.reg_stats(est, gt, 1.0, 0, TRUNC)
+    np.testing.assert_allclose(r["cd_vec"], r["est_gt"]["rmse"] + r["gt_est"]["rmse"], rtol=0)         # :1245
+    np.testing.assert_allclose(r["f1_vec"], 2 * eg.fitness * eg.rmse / (eg.fitness + eg.rmse), rtol=1e-12)  # :1249
+    np.testing.assert_allclose(r["iou_vec"], eg.number.astype(int) / (len(est) + len(gt) - eg.number.astype(int)), rtol=1e-15)
+    assert r["full_chamfer_dist"] == 0.0  # the initial-matrix path never calls computeChamferDistance
+
+
+def test_c1_mme_dispatcher(c1):
+    """computeMME (map_eval.cpp:149-189): TBB loop on the map (k >= 10), serial loop on the ground truth (k >= 5)."""
+    est, gt, r = c1
+    me, ee, ev, en, _ = oracle.mme(est, 0.1, 10)
+    mg, ge, gv, gn, _ = oracle.mme(gt, 0.1, 5, mode=0)
+    np.testing.assert_allclose(r["mme_est"], me, rtol=1e-12)
+    np.testing.assert_allclose(r["mme_gt"], mg, rtol=1e-12)
+    np.testing.assert_allclose(r["est_entropies"], ee, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(r["gt_entropies"], ge, rtol=1e-12, atol=0)
+    assert np.array_equal(r["est_entropies"] != 0, ev.astype(bool)) and np.array_equal(r["gt_entropies"] != 0, gv.astype(bool))
+    assert en > 0.9 * len(est) and gn > 0.9 * len(gt)
+
+
+def test_c1_vmd_scs_and_the_files_it_writes(c1):
+    """calculateVMD (map_eval.cpp:240-390): AWD, CDF, SCS; voxel_errors.txt rows against the oracle's (ascending key order
+    there, hash order in the file; 6 significant digits in the file)."""
+    est, gt, r = c1
+    o = oracle.awd_scs(oracle.VoxelMap(gt, 0.5), oracle.VoxelMap(est, 0.5))
+    np.testing.assert_allclose(r["vmd"], o["awd"], rtol=1e-12)
+    np.testing.assert_allclose(r["scs"], o["scs"], rtol=1e-12)
+    rows = r["files"]["voxel_errors.txt"]
+    assert rows.shape == o["rows"].shape
+    order = np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0]))
+    np.testing.assert_allclose(rows[order], o["rows"], rtol=2e-5, atol=1e-12)
+    assert np.array_equal(rows[order][:, 10:12], o["rows"][:, 10:12])  # populations
+    cdf = r["files"]["voxel_wasserstein_cdf.txt"]
+    np.testing.assert_allclose(cdf[:, 0], o["w_sorted"], rtol=2e-5)
+    np.testing.assert_allclose(cdf[:, 1], (np.arange(len(cdf)) + 1) / len(cdf), rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# single reference functions, other shapes
+# ------------------------------------------------------------------------------------------------------------------
+def _scene(n, seed=5, n_gt=None):
+    est, gt = synth.campus_pair(n, density=900.0, seed=seed)
+    est, gt = est.numpy(), gt.numpy()
+    return est, gt[: (n_gt or len(gt))]
+
+
+def test_initial_matrix_is_applied_as_open3d_transform():
+    est, gt = _scene(20_000, n_gt=17_000)
+    a = 0.01
+    T = np.array([[np.cos(a), -np.sin(a), 0, 0.03], [np.sin(a), np.cos(a), 0, -0.02], [0, 0, 1, 0.01], [0, 0, 0, 1.0]])
+    r = ref.suite_initial(est, gt, ref.config(T=T, evaluate_mme=False, vmd_voxel_size=2.0))
+    moved = oracle.transform(est, T)
+    assert np.array_equal(r["est_transformed"], moved)
+    assert_stats(r["est_gt"], oracle.reg_stats(moved, gt, 1.0, 0, TRUNC))
+
+
+@pytest.mark.parametrize("gate", [1.0, 0.004])
+def test_icp_path_statistics(gate):
+    """calculateMetrics (map_eval.cpp:1147-1202): 6-arg getDiffRegResult on the registration's correspondence set,
+    EvaluateRegistration(gt, map, max) + 4-arg getDiffRegResult, cd_vec, computeChamferDistance."""
+    est, gt = _scene(30_000, seed=9, n_gt=26_000)
+    r = ref.calculate_metrics(est, gt, ref.config(icp_max_distance=gate))
+    eg = oracle.reg_stats(est, gt, gate, 1, TRUNC)
+    ge = oracle.reg_stats(gt, est, gate, 1, TRUNC)
+    assert r["n_corr"] == eg.n_corr
+    assert_stats(r["est_gt"], eg)
+    assert set(r["gt_est"]) == {"mean", "rmse", "fitness", "sigma"}  # the 4-arg overload pushes no `number` (:893-896)
+    for k in ("mean", "rmse", "fitness", "sigma"):
+        np.testing.assert_allclose(r["gt_est"][k], getattr(ge, k), rtol=1e-12, err_msg=k)
+    np.testing.assert_allclose(r["cd_vec"], eg.rmse + ge.rmse, rtol=1e-12)
+    np.testing.assert_allclose(r["full_chamfer_dist"], oracle.chamfer(est, gt), rtol=1e-12)
+
+
+def test_empty_correspondence_set_gives_nan_like_the_reference():
+    src = np.array([[0.0, 0, 0], [1.0, 0, 0]])
+    tgt = np.array([[50.0, 0, 0]])
+    got = ref.diff_reg_result(0, src, tgt, np.zeros((0, 2), np.int32), TRUNC)
+    o = oracle.reg_stats(src, tgt, 1.0, 0, TRUNC)
+    assert np.all(np.isnan(got["mean"])) and np.all(np.isnan(o.mean))
+    assert np.all(np.isnan(got["rmse"])) and np.all(np.isnan(got["sigma"]))
+    assert np.array_equal(got["fitness"], np.zeros(5)) and np.array_equal(o.fitness, np.zeros(5))
+
+
+def test_chamfer_distance():
+    est, gt = _scene(25_000, seed=3, n_gt=21_000)
+    np.testing.assert_allclose(ref.chamfer(est, gt), oracle.chamfer(est, gt), rtol=1e-12)
+
+
+@pytest.mark.parametrize("variant,min_k,mode", [(0, 5, 0), (1, 10, 1), (2, 10, 2)])
+def test_mme_loops(variant, min_k, mode):
+    """ComputeMeanMapEntropy (:1438-1535, serial, k >= 5) / ...UsingNormal (:1538-1606) / ...UsingNormalTBB (:1608-1737)."""
+    est, _ = _scene(40_000, seed=11)
+    mean, ent, valid = ref.mme(variant, est, 0.12)
+    o_mean, o_ent, o_valid, o_n, _ = oracle.mme(est, 0.12, min_k, mode=mode)
+    assert np.array_equal(valid, o_valid.astype(bool)) and valid.sum() == o_n
+    assert 0.05 * len(est) < o_n < len(est)  # a density where the k threshold actually cuts
+    np.testing.assert_allclose(ent, o_ent, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(mean, o_mean, rtol=1e-12)
+
+
+def test_mme_no_valid_point_returns_zero():
+    p = np.random.default_rng(0).uniform(0, 100, (500, 3))
+    mean, ent, valid = ref.mme(2, p, 0.1)
+    assert mean == 0.0 and not valid.any() and not ent.any()
+    assert oracle.mme(p, 0.1, 10)[0] == 0.0
+
+
+def test_compute_entropy_formula():
+    c = np.array([[2.0, 0.3, 0.1], [0.3, 1.0, 0.2], [0.1, 0.2, 0.5]]) * 1e-3
+    assert ref.compute_entropy(c) == 0.5 * np.log(2 * np.pi * np.e * ref_det(c))
+
+
+def ref_det(m):
+    h = lambda a, b, c: m[0, a] * (m[1, b] * m[2, c] - m[1, c] * m[2, b])
+    return h(0, 1, 2) - h(1, 0, 2) + h(2, 0, 1)
+
+
+def test_voxel_map_tables_and_labels():
+    """buildVoxelMap + computeVoxelEntropy + getVoxelIndex + updateVoxelMap (voxel_calculator.cpp:21-56,97-113,142-172,241-245)."""
+    est, gt = _scene(60_000, seed=21, n_gt=50_000)
+    for cloud in (est, gt - np.array([400.0, 250.0, 3.0])):  # negative coordinates: floor, not truncation
+        rv, ov = ref.VoxelMap(cloud, 2.0), oracle.VoxelMap(cloud, 2.0)
+        e = rv.export()
+        keys, n, mu, sig, ent = ov.export()
+        assert np.array_equal(e["keys"], keys) and np.array_equal(e["npts"], n)
+        assert np.array_equal(e["mu"], mu)          # same streaming Welford, same cloud order: bit for bit
+        assert np.array_equal(e["sigma"].reshape(-1, 9), sig.reshape(-1, 9))
+        assert np.array_equal(e["entropy"], ent)
+        assert (n > 10).any() and (n <= 10).any()
+    re, rg = ref.VoxelMap(est, 2.0), ref.VoxelMap(gt, 2.0)
+    counts = re.update_from(rg)
+    o = oracle.awd_scs(oracle.VoxelMap(gt, 2.0), oracle.VoxelMap(est, 2.0))
+    assert tuple(counts) == tuple(o["counts"])
+
+
+def test_voxel_index_and_neighbours():
+    for p in ([-0.1, 0.1, -3.0], [-3.0001, 2.9999, 0.0], [0.0, -0.0, 5.999999], [1e-300, -1e-300, 3.0]):
+        assert np.array_equal(ref.voxel_index(p, 3.0), np.floor(np.array(p) / 3.0).astype(np.int32))
+    nb = ref.neighbor_indices([4, -2, 7], 5)
+    assert nb.shape == (1330, 3) and np.abs(nb - [4, -2, 7]).max() == 5 and not (nb == [4, -2, 7]).all(1).any()
+
+
+def test_w2_random_and_degenerate_pairs():
+    """computeWassersteinDistanceGaussian (voxel_calculator.cpp:115-140): the third division, the eigen-clamp, both Choleskys."""
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for i in range(400):
+        a = rng.normal(size=(3, 3)); b = rng.normal(size=(3, 3))
+        if i % 4 == 1:
+            a[:, 2] = 0                      # rank 2: a clamped eigenvalue
+        if i % 4 == 2:
+            a[:, 1:] = 0; b[:, 2] = 0        # rank 1 against rank 2
+        s1 = a @ a.T * 10.0 ** rng.uniform(-6, 4)
+        s2 = b @ b.T * 10.0 ** rng.uniform(-6, 4)
+        if i % 4 == 3:
+            s1 = s1 + rng.normal(size=(3, 3)) * 1e-9  # not symmetric: the (S + S^T)/2 line
+        n1, n2 = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+        mu1, mu2 = rng.normal(size=3), rng.normal(size=3)
+        w_ref = ref.w2_gaussian(mu1, s1, n1, mu2, s2, n2)
+        w_orc = oracle.w2_gaussian(mu1, s1, n1, mu2, s2, n2)
+        worst = max(worst, abs(w_ref - w_orc) / max(abs(w_ref), 1e-300))
+    assert worst < 1e-9, worst  # Jacobi (oracle) vs tridiagonal QR (stand-in Eigen) on clamped spectra
+
+
+def test_golden_rows_through_the_reference_function(golden):
+    """The reference's own run output (map_eval/scripts/voxel_errors.txt) through the reference's own function: W of every
+    row reproduced to the file's print precision, and oracle == _ref on the same inputs to 1e-12."""
+    rows = golden["rows"]
+    full = lambda r6: np.array([[r6[0], r6[1], r6[2]], [r6[1], r6[3], r6[4]], [r6[2], r6[4], r6[5]]])
+    rel_file, rel_orc = [], []
+    for r in rows[::3]:
+        args = (r[18:21], full(r[21:27]), int(r[10]), r[6:9], full(r[12:18]), int(r[11]))
+        w = ref.w2_gaussian(*args)
+        rel_file.append(abs(w - r[9]) / max(r[9], 1e-12))
+        rel_orc.append(abs(w - oracle.w2_gaussian(*args)) / max(w, 1e-12))
+    assert np.median(rel_file) < 2e-3 and np.quantile(rel_file, 0.99) < 5e-2
+    assert max(rel_orc) < 1e-12, max(rel_orc)
+
+
+def test_golden_scs_with_the_references_neighbourhood(golden):
+    """The reference's run (README screenshot `SCS: 0.78121`) recomputed from its own voxel_errors.txt with the reference's
+    getNeighborIndices (voxel_calculator.cpp:7-19) as the stencil and the arithmetic of map_eval.cpp:371-383; the oracle's
+    orc_scs gives the same number."""
+    rows = golden["rows"]
+    keys = np.rint(rows[:, 0:3] / float(golden["voxel_size"])).astype(np.int64)
+    w = rows[:, 9]
+    off = ref.neighbor_indices([0, 0, 0], 5).astype(np.int64)
+    assert off.shape == (1330, 3)
+    enc = lambda k: ((k[..., 0] + 4096) << 26) | ((k[..., 1] + 4096) << 13) | (k[..., 2] + 4096)
+    code = enc(keys)
+    order = np.argsort(code)
+    sc, sw = code[order], w[order]
+    nb = enc(keys[:, None, :] + off[None, :, :])                      # V x 1330
+    pos = np.clip(np.searchsorted(sc, nb), 0, len(sc) - 1)
+    hit = sc[pos] == nb
+    cnt = hit.sum(1)
+    wn = np.where(hit, sw[pos], 0.0)
+    mean = wn.sum(1) / np.maximum(cnt, 1)
+    var = (np.where(hit, (sw[pos] - mean[:, None]) ** 2, 0.0)).sum(1) / np.maximum(cnt, 1)
+    has = cnt > 0
+    scs = (np.sqrt(var[has]) / mean[has]).sum() / has.sum()
+    assert abs(scs - float(golden["screenshot_scs"])) < 5e-6
+    np.testing.assert_allclose(oracle.scs(keys.astype(np.int32), w, 5), scs, rtol=1e-12)
+
+
+def test_process_end_to_end_on_pcd_files(tmp_path):
+    """MapEval::process() itself (map_eval.cpp:4-104): PCD in, VoxelDownSample, MME, AC/COM, VMD, map_results.txt out."""
+    est, gt = synth.cube_pair(30_000, seed=6)
+    est, gt = est.numpy(), gt.numpy()
+
+    def write_pcd(path, p):
+        with open(path, "wb") as f:
+            f.write((f"# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 8 8 8\nTYPE F F F\nCOUNT 1 1 1\nWIDTH {len(p)}\nHEIGHT 1\n"
+                     f"VIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(p)}\nDATA binary\n").encode())
+            f.write(np.ascontiguousarray(p, np.float64).tobytes())
+
+    write_pcd(tmp_path / "global_pcd_lidar.pcd", est)
+    write_pcd(tmp_path / "gt.pcd", gt)
+    cfg = ref.config(nn_radius=0.2, vmd_voxel_size=0.5, downsample_size=0.05, save_immediate_result=True)
+    r = ref.process(cfg, tmp_path, tmp_path / "gt.pcd")
+    assert r["rc"] == 0
+    est_d, gt_d = oracle.voxel_downsample(est, 0.05), oracle.voxel_downsample(gt, 0.05)
+    assert (r["n_est"], r["n_gt"]) == (len(est_d), len(gt_d)) and len(est_d) < len(est)
+    assert_stats(r["est_gt"], oracle.reg_stats(est_d, gt_d, 1.0, 0, TRUNC))
+    np.testing.assert_allclose(r["mme_est"], oracle.mme(est_d, 0.2, 10)[0], rtol=1e-12)
+    np.testing.assert_allclose(r["mme_gt"], oracle.mme(gt_d, 0.2, 5, mode=0)[0], rtol=1e-12)
+    o = oracle.awd_scs(oracle.VoxelMap(gt_d, 0.5), oracle.VoxelMap(est_d, 0.5))
+    np.testing.assert_allclose([r["vmd"], r["scs"]], [o["awd"], o["scs"]], rtol=1e-12)
+    txt = r["files"]["map_results.txt"]
+    for key in ("RMSE/AC:", "Comp:", "FULL CD:", "VMD:", "SCS:", "MME:"):
+        assert key in txt
+    for name in ("map_entropy.pcd", "gt_entropy.pcd", "raw_rendered_dis_map.pcd", "inlier_rendered_dis_map.pcd"):
+        assert os.path.getsize(tmp_path / "map_results" / name) > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the stand-in layer on its own (the builder's arithmetic inside _ref)
+# ------------------------------------------------------------------------------------------------------------------
+def test_standin_kdtree_is_exact():
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(-5, 5, (3000, 3))
+    pts[100:130] = pts[7]                       # duplicates
+    q = np.concatenate([rng.uniform(-6, 6, (500, 3)), pts[:200]])
+    d2 = ((q[:, None, 0] - pts[None, :, 0]) ** 2 + (q[:, None, 1] - pts[None, :, 1]) ** 2) + (q[:, None, 2] - pts[None, :, 2]) ** 2
+    idx, got = ref.kdtree_nn1(pts, q)
+    assert np.array_equal(got, d2.min(1))                             # bit-exact squared distance
+    assert np.array_equal(d2[np.arange(len(q)), idx], d2.min(1))      # the index attains it
+    o_idx, o_d2 = oracle.nn1(pts, q)
+    assert np.array_equal(got, o_d2)
+    for r in (0.3, 0.7321):
+        assert np.array_equal(ref.kdtree_radius_count(pts, q, r), (d2 < r * r).sum(1))   # strict
+        assert np.array_equal(ref.kdtree_radius_count(pts, q, r), oracle.radius_count(pts, q, r))
+
+
+def test_standin_eigen_llt_through_w2_against_numpy():
+    """SelfAdjointEigenSolver + LLT of the stand-in Eigen, exercised through the reference's W function, against
+    numpy.linalg.eigh / cholesky."""
+    from tests.test_oracle_voxel import np_w2
+
+    rng = np.random.default_rng(3)
+    for i in range(300):
+        a, b = rng.normal(size=(3, 3)), rng.normal(size=(3, 3))
+        if i % 3 == 0:
+            a[:, 2] = a[:, 1]
+        s1, s2 = a @ a.T * 10.0 ** rng.uniform(-3, 3), b @ b.T * 10.0 ** rng.uniform(-3, 3)
+        n1, n2 = int(rng.integers(2, 400)), int(rng.integers(2, 400))
+        mu1, mu2 = rng.normal(size=3), rng.normal(size=3)
+        np.testing.assert_allclose(ref.w2_gaussian(mu1, s1, n1, mu2, s2, n2), np_w2(mu1, s1, n1, mu2, s2, n2), rtol=1e-9, atol=1e-12)
+
+
+def test_the_library_is_the_references_sources():
+    """SOURCES.sha256 (written by the recipe) names the files under /root/reference that were compiled, and no reference
+    source lives in this repository."""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    listing = open(os.path.join(here, "oracle", "_ref", "SOURCES.sha256")).read()
+    for name in ("src/map_eval.cpp", "src/voxel_calculator.cpp", "src/map_eval.h", "src/voxel_calculator.hpp"):
+        assert name in listing
+    for root, _, files in os.walk(os.path.join(here, "oracle")):
+        assert "voxel_calculator.cpp" not in files and "map_eval.cpp" not in files
+    if ref.have_sources():
+        import hashlib
+        for line in listing.strip().splitlines():
+            sha, path = line.split()
+            assert hashlib.sha256(open(path, "rb").read()).hexdigest() == sha
