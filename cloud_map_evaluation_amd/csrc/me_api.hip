@@ -469,7 +469,7 @@ int me_timers_reset(me_ctx *ctx) {
     ctx->timers_collect();
     ctx->timers.clear();
     ctx->nn_fallback = ctx->nn_queries = 0;
-    if (ctx->nn1_dbg_buf.p) (void) hipMemset(ctx->nn1_dbg_buf.p, 0, 64);
+    if (ctx->nn1_dbg_buf.p) (void) hipMemsetAsync(ctx->nn1_dbg_buf.p, 0, 64, ctx->stream);
     return ME_OK;
 }
 

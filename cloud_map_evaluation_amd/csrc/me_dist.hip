@@ -72,10 +72,23 @@ __global__ void k_split_segments(const unsigned int *__restrict__ off, const uns
     if (k == world) seg[world] = off[n_units * world - 1] + cnt[n_units * world - 1];
 }
 
+// 64-bit totals per destination (the segment offsets are 32-bit: a point is copied to every rank whose slab + halo holds it,
+// so the packed total can exceed 2^32 although n does not; the host checks these before it trusts the offsets)
+__global__ void __launch_bounds__(256)
+k_split_totals(const unsigned int *__restrict__ cnt, long long n_units, unsigned long long *__restrict__ totals) {
+    const int k = blockIdx.x;
+    unsigned long long s = 0;
+    for (long long u = threadIdx.x; u < n_units; u += 256) s += cnt[(long long) k * n_units + u];
+    __shared__ long long sm[4];
+    const long long t = block_sum_256_ll((long long) s, sm);
+    if (threadIdx.x == 0) totals[k] = (unsigned long long) t;
+}
+
 int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, const double *cuts_host, int world, double halo,
               double *out_device, long long capacity, long long *counts_host) {
     if ((n > 0 && !xyz_device) || n < 0 || axis < 0 || axis > 2 || !cuts_host || world < 1 || world > kMaxWorld || !(halo >= 0) || !counts_host)
         return ctx->fail(ME_ERR_ARG, "me_halo_pack_device: bad argument (1 <= world <= 64)");
+    if (n >= (1LL << 31)) return ctx->fail(ME_ERR_ARG, "me_halo_pack_device: more than 2^31 - 1 points in one call");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     Cuts c{};
     for (int k = 0; k < world; ++k) {
@@ -94,6 +107,12 @@ int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, cons
     TimerScope ts(ctx, "halo_pack");
     hipLaunchKernelGGL(k_halo_split<false>, grid, dim3(256), 0, ctx->stream, xyz_device, n, axis, c, world, n_units,
                        cnt.as<unsigned int>(), (const unsigned int *) nullptr, (double *) nullptr);
+    // the exact 64-bit totals first: 32-bit offsets are only meaningful when the packed total fits them
+    ME_CHECK(ctx, ctx->tmp[2].ensure((size_t) world * 8));
+    hipLaunchKernelGGL(k_split_totals, dim3((unsigned int) world), dim3(256), 0, ctx->stream, cnt.as<unsigned int>(), n_units,
+                       ctx->tmp[2].as<unsigned long long>());
+    std::vector<unsigned long long> tot64((size_t) world);
+    ME_CHECK(ctx, hipMemcpyAsync(tot64.data(), ctx->tmp[2].p, (size_t) world * 8, hipMemcpyDeviceToHost, ctx->stream));
     ME_TRY(exclusive_scan_u32(ctx, cnt.as<unsigned int>(), off.as<unsigned int>(), n_cnt));
     // destination k's segment starts at off[k * n_units]; the total is off[last] + cnt[last]: one small kernel collects the
     // world + 1 numbers, ONE copy brings them to the host (world separate 4-byte copies cost ~10 us each)
@@ -105,9 +124,16 @@ int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, cons
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     long long total = 0;
     for (int k = 0; k < world; ++k) {
-        counts_host[k] = (long long) seg[k + 1] - (long long) seg[k];
+        counts_host[k] = (long long) tot64[(size_t) k];
         total += counts_host[k];
     }
+    if (total > 0xffffffffLL) {
+        if (!out_device) return ME_OK;  // counts only: they are exact; packing needs 32-bit offsets
+        return ctx->fail(ME_ERR_CAPACITY, "me_halo_pack_device: the packed total exceeds 2^32 - 1 points (split the call)");
+    }
+    for (int k = 0; k < world; ++k)
+        if (counts_host[k] != (long long) seg[k + 1] - (long long) seg[k])
+            return ctx->fail(ME_ERR_STATE, "me_halo_pack_device: segment offsets disagree with the 64-bit totals");
     if (!out_device) return ME_OK;  // counts only
     if (capacity < total) return ctx->fail(ME_ERR_CAPACITY, "me_halo_pack_device: capacity too small (counts returned)");
     hipLaunchKernelGGL(k_halo_split<true>, grid, dim3(256), 0, ctx->stream, xyz_device, n, axis, c, world, n_units,

@@ -203,7 +203,7 @@ struct me_ctx {
     unsigned long long *nn1_dbg() {
         if (!nn1_dbg_buf.p) {
             if (nn1_dbg_buf.ensure(64) != hipSuccess) return nullptr;
-            (void) hipMemset(nn1_dbg_buf.p, 0, 64);
+            (void) hipMemsetAsync(nn1_dbg_buf.p, 0, 64, stream);  // ordered before the kernels that count into it
         }
         return nn1_dbg_buf.as<unsigned long long>();
     }
@@ -485,6 +485,27 @@ __device__ __forceinline__ double uniform_f64(double v) {  // a wave-uniform dou
     const unsigned int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double((int) hi, (int) lo);
 }
+// Sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48 all end with the total, bit-identical: the two
+// additions commute) with gfx950's half-exchange permutes — v_permlane16_swap trades the odd rows of one operand for the
+// even rows of the other, v_permlane32_swap the upper half for the lower half — one VALU instruction per 32 bits and
+// stage, no LDS round trip.
+__device__ __forceinline__ int rows4_sum_i(int v) {
+    auto a = __builtin_amdgcn_permlane16_swap((unsigned int) v, (unsigned int) v, false, false);
+    v = (int) a[0] + (int) a[1];
+    auto b = __builtin_amdgcn_permlane32_swap((unsigned int) v, (unsigned int) v, false, false);
+    return (int) b[0] + (int) b[1];
+}
+__device__ __forceinline__ double rows4_sum_d(double v) {
+    unsigned int lo = (unsigned int) __double2loint(v), hi = (unsigned int) __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int) b[0], (int) a[0]) + __hiloint2double((int) b[1], (int) a[1]);
+    lo = (unsigned int) __double2loint(v);
+    hi = (unsigned int) __double2hiint(v);
+    auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int) d[0], (int) c[0]) + __hiloint2double((int) d[1], (int) c[1]);
+}
 // ---- cross-lane exchanges on the VALU (DPP) instead of the LDS pipe.  `__shfl_xor` compiles to ds_bpermute_b32: an LDS
 // round trip (~100 cycles) per 32 bits and butterfly stage, and the stages depend on each other.  The patterns below are
 // plain data-parallel-primitive modifiers of a v_mov: a few cycles each.
@@ -543,7 +564,9 @@ constexpr int kGroupTab2 = (2 * kGroupR + 5) * (2 * kGroupR + 5) * (2 * kGroupR 
 // position into a bit mask (LDS atomics), a row's mask is then dilated over the 3x3 neighbouring rows and by one bit in x:
 // a few dozen LDS operations per round against 64 x (9..19) VALU operations per candidate saved.  `rows` = 2 x 49 ints.
 // `tcell` (optional) receives the box-relative cell coordinates of every table slot, packed x | y << 3 | z << 6.
-template <int H = 1, bool CULL = false>
+// R: Chebyshev radius (in cells) of a group around its leader — kGroupR for the 64-query kernels, 1 for the 16-query
+// passes of the MME kernel (a (2R+1+2H)^3 = 125-entry table).
+template <int H = 1, bool CULL = false, int R = kGroupR>
 __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, int cz, const GridView &g, int cell_lim,
                                                  int lane, int2 *tab, GroupBox &box, int *n_keys_out = nullptr,
                                                  unsigned int *rows = nullptr, unsigned short *tcell = nullptr) {
@@ -558,7 +581,7 @@ __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, i
 #endif
     const int lx = readlane_i(cx, leader), ly = readlane_i(cy, leader), lz = readlane_i(cz, leader);
     const int ex = cx - lx, ey = cy - ly, ez = cz - lz;
-    const bool in = pending && ex >= -kGroupR && ex <= kGroupR && ey >= -kGroupR && ey <= kGroupR && ez >= -kGroupR && ez <= kGroupR;
+    const bool in = pending && ex >= -R && ex <= R && ey >= -R && ey <= R && ez >= -R && ez <= R;
     // (readfirstlane: the butterfly leaves the same value in every lane, but only this tells the compiler so — without it the
     // box, the table size and everything the callers derive from them live in vector registers and loops over them diverge)
     const int x0 = __builtin_amdgcn_readfirstlane(wave_min_i(in ? cx : lx)) - H;

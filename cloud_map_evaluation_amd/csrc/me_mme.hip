@@ -32,6 +32,7 @@
 
 namespace me {
 
+#ifdef ME_AB  // round 1's kernel, for A/B measurements only (make EXTRA=-DME_AB; ME_MME_V=1 selects it)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
       GridView g, SlabView slab, double r2, int min_k, double *__restrict__ ent_s, unsigned char *__restrict__ valid_s,
@@ -148,6 +149,8 @@ k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ code
         part_cnt[blockIdx.x] = bc;
     }
 }
+
+#endif  // ME_AB
 
 #ifdef ME_MME_STATS
 // build with -DME_MME_STATS (profiles/README.md): per launch, [0] wave rounds, [1] candidates streamed, [2] lanes served,
@@ -381,6 +384,259 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
     }
 }
 
+#ifdef ME_AB
+// ------------------------------------------------------------------------------------------------------------
+// k_mme6 (round 3, MEASURED AND NOT ADOPTED: 33.8 ms per step against k_mme3's 26.1 on the 50 M + 50 M pair, results
+// identical; profiles/README.md "round 3" has the counters) — the radius test on the MATRIX pipe, 16 queries x 4
+// candidate slices per wavefront.
+//
+// u = |p'|^2 - 2 p'.q' over (candidates x queries) is a K = 4 contraction, (p'x, p'y, p'z, |p'|^2) . (ax, ay, az, 1):
+// one v_mfma_f32_16x16x4_f32 (32 cycles on the matrix pipe, exact FP32 = an fmaf chain) evaluates it for 16 candidates x
+// 16 queries, where the VALU version spent 4.5 instructions per candidate and 64 queries.  The output layout gives lane
+// (s = lane / 16, j = lane % 16) four candidates of query j; the candidates of a 16-block are dealt so that result
+// register r of slice s is candidate 4 r + s: an accumulation step (r) covers FOUR stream-consecutive candidates for the
+// 16 (curve-consecutive, i.e. spatially clustered) queries, and is skipped when none of the 64 pairs is accepted.
+// A wavefront owns 64 curve-consecutive points as before and serves them in four PASSES of 16 (every pass: all 64 lanes =
+// 16 queries x 4 slices, its own cell box and run table — the box of 16 queries holds about half the candidates of the box
+// of 64 —, candidate tiles packed ACROSS runs so that the MFMA blocks are full).  A slice accumulates k, sum(p - q),
+// sum((p - q)(p - q)^T) over its quarter of the candidates; two half-exchange permutes per value add the four slices.
+// The accepted set is exactly the fp64 test's (same exact band as k_mme3); the moments are the same fp64 sums in a different
+// order (valid flags and counts bit-identical, entropies to ~1e-14).
+// Error bound of the pre-test (h = cell edge; groups of Chebyshev radius 1: the box spans <= 5 cells, |p'|, |q'| <= 5h per
+// axis, |a| <= 10h), in units of 2^-24 h^2: rounding of p' and a: 600;  |p'|^2 <= 75 h^2: 75;  the MFMA's chain (four
+// roundings, partial sums <= 225 h^2): 900;  |a|^2 / 4 (<= 75 h^2, four roundings): 300;  T's rounding: 76;  r^2: 1.
+// Sum 1952 < 4096 = E.
+// ------------------------------------------------------------------------------------------------------------
+typedef float mme_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMme6Tab = 125;  // (2 R + 1 + 2 H)^3, R = H = 1
+
+template <int TILE, int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+k_mme6(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
+       GridView g, FrameView fr, SlabView slab, double r2, int min_k, double *__restrict__ ent_s,
+       unsigned char *__restrict__ valid_s, double *__restrict__ part_sum, long long *__restrict__ part_cnt,
+       unsigned int xcd_chunk, double cell_h, float thr_lo, float thr_hi) {
+    static_assert(TILE == 32 || TILE == 64, "tile = 2 or 4 MFMA blocks");
+    static_assert(TILE * 16 >= kGroupRows * 4, "the row masks of the cull alias the FP32 tile");
+    constexpr int NBLK = TILE / 16;
+    const unsigned int vb = xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);
+    const int lane = threadIdx.x & 63;
+    const int sl = lane >> 4, qj = lane & 15;  // slice, query of the pass
+    const unsigned int wbase = vb * blockDim.x + (threadIdx.x & ~63u);  // the wave's first point (relative to i_begin)
+    const int shift3 = 3 * g.shift;
+    const int cell_lim = 1 << (kMortonBits - g.shift);
+
+    __shared__ int2 s_tab[4][kMme6Tab + 3];
+    __shared__ float4 s_tf[4][TILE];     // FP32 records of the staged tile (the cull's row masks while the table is built)
+    __shared__ double s_td[4][3][TILE];  // its fp64 coordinates, one array per axis
+    const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    int2 *tab = s_tab[wv];
+    float4 *tf = s_tf[wv];
+    double *tdx = s_td[wv][0], *tdy = s_td[wv][1], *tdz = s_td[wv][2];
+    // A operand of block b: feature (lane / 16) of the candidate that MFMA row (lane % 16) stands for: row 4 s' + r' is
+    // candidate 4 r' + s' of the block (so that result register r' of slice s' is that candidate)
+    const float *tfa = reinterpret_cast<const float *>(tf) + (4 * (qj & 3) + (qj >> 2)) * 4 + sl;
+
+    double det_mine = 0.0;   // of point (wave's first + lane): set in the pass that serves it (pass == slice)
+    bool have_mine = false;
+#ifdef ME_MME_STATS
+    unsigned int st_rounds = 0, st_cand = 0, st_blocks = 0, st_slots = 0, st_pairs = 0, st_served = 0;
+#endif
+    for (int gp = 0; gp < 4; ++gp) {
+        const long long i = i_begin + (long long) (wbase + 16u * gp + qj);
+        bool act = i < i_end;
+        double qx = 0, qy = 0, qz = 0;
+        unsigned long long mycell = ~0ULL;
+        if (act) {
+            const SPoint q = sp[i];
+            qx = q.x;
+            qy = q.y;
+            qz = q.z;
+            mycell = codes[i] >> shift3;
+            if (!slab_owned(slab, qx, qy, qz)) act = false;  // slab mode: halo points are neighbours only, never queries
+        }
+        bool done = !act;
+        double det = 0.0;
+        bool have = false;
+        const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
+        while (__ballot(!done)) {
+            GroupBox bx;
+            int nk = 0;
+            const bool in = wave_group_table<1, true, 1>(!done, cx, cy, cz, g, cell_lim, lane, tab, bx, &nk,
+                                                         reinterpret_cast<unsigned int *>(tf));
+            const double ox = uniform_f64(fr.ox + (double) bx.x0 * cell_h), oy = uniform_f64(fr.oy + (double) bx.y0 * cell_h),
+                         oz = uniform_f64(fr.oz + (double) bx.z0 * cell_h);
+            const float ax = (float) (-2.0 * (qx - ox)), ay = (float) (-2.0 * (qy - oy)), az = (float) (-2.0 * (qz - oz));
+            const float s2 = fmaf(az, az, fmaf(ay, ay, ax * ax));
+            // (the group predicate rides on the thresholds: lanes outside the group accept nothing)
+            const float t_hi = in ? fmaf(-0.25f, s2, thr_hi) : -INFINITY;
+            const float t_lo = in ? fmaf(-0.25f, s2, thr_lo) : -INFINITY;
+            const float bq = sl == 0 ? ax : (sl == 1 ? ay : (sl == 2 ? az : 1.0f));  // B operand: row (lane / 16) of (a, 1)
+            int k = 0;
+            double s1x = 0, s1y = 0, s1z = 0;
+            double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+
+            // one accumulation step: result u of this lane's candidate `c` (tile slot) against its query
+            auto step = [&](float u, int c) {
+                const bool hi = u < t_hi;
+                const unsigned long long mh = __ballot(hi);
+                if (mh) {  // some (query, candidate) pair of the step may be inside the radius
+                    bool acc = u < t_lo;
+                    if (__builtin_expect(mh != __ballot(acc), 0)) {  // a lane in the band: its exact test decides
+                        asm volatile("; band: exact test" ::: "memory");
+                        const double ex = tdx[c] - qx, ey = tdy[c] - qy, ez = tdz[c] - qz;
+                        const double d2 = (ex * ex + ey * ey) + ez * ez;
+                        acc = acc || (hi && d2 < r2);  // strict, nanoflann RadiusResultSet [upstream]
+                    }
+#ifdef ME_MME_STATS
+                    ++st_slots;
+                    st_pairs += (unsigned int) __popcll(__ballot(acc));
+#endif
+                    if (acc) {
+                        const double dx = tdx[c] - qx, dy = tdy[c] - qy, dz = tdz[c] - qz;
+                        ++k;
+                        s1x += dx;
+                        s1y += dy;
+                        s1z += dz;
+                        sxx = fma(dx, dx, sxx);
+                        sxy = fma(dx, dy, sxy);
+                        sxz = fma(dx, dz, sxz);
+                        syy = fma(dy, dy, syy);
+                        syz = fma(dy, dz, syz);
+                        szz = fma(dz, dz, szz);
+                    }
+                }
+            };
+            // the first `nb` 16-blocks of the staged tile: all MFMAs first (independent), then their results
+            auto process = [&](int nb) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                mme_f32x4 d[NBLK];
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b)
+                    if (b < nb) {
+                        const mme_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        d[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(tfa[b * 64], bq, zero, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b)
+                    if (b < nb) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) step(d[b][r], 16 * b + 4 * r + sl);
+                    }
+#ifdef ME_MME_STATS
+                st_blocks += (unsigned int) nb;
+#endif
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next one
+            };
+            int filled = 0;  // wave-uniform: slots of the tile already staged (tiles are packed across runs)
+            wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) {
+                int pos = cs;
+                while (pos < ce) {
+                    const int m = min(TILE - filled, ce - pos);
+                    if (lane >= filled && lane < filled + m) {
+                        const SPoint p = sp[pos + (lane - filled)];
+                        const double px = p.x - ox, py = p.y - oy, pz = p.z - oz;
+                        const float fx = (float) px, fy = (float) py, fz = (float) pz;
+                        // |p'|^2 of the ROUNDED coordinates (the error bound is stated for them), rounded once
+                        const double w = ((double) fx * (double) fx + (double) fy * (double) fy) + (double) fz * (double) fz;
+                        tf[lane] = make_float4(fx, fy, fz, (float) w);
+                        tdx[lane] = p.x;
+                        tdy[lane] = p.y;
+                        tdz[lane] = p.z;
+                    }
+                    filled += m;
+                    pos += m;
+#ifdef ME_MME_STATS
+                    st_cand += (unsigned int) m;
+#endif
+                    if (filled == TILE) {
+                        process(NBLK);
+                        filled = 0;
+                    }
+                }
+            });
+            if (filled) {  // the last, partial tile: pad its last block with records no query accepts (u = +inf)
+                const int up = (filled + 15) & ~15;
+                if (lane >= filled && lane < up) tf[lane] = make_float4(0.f, 0.f, 0.f, INFINITY);
+                process(up >> 4);
+            }
+            // add the four slices (every lane takes part: lanes outside the group hold zeros)
+            k = rows4_sum_i(k);
+            s1x = rows4_sum_d(s1x);
+            s1y = rows4_sum_d(s1y);
+            s1z = rows4_sum_d(s1z);
+            sxx = rows4_sum_d(sxx);
+            sxy = rows4_sum_d(sxy);
+            sxz = rows4_sum_d(sxz);
+            syy = rows4_sum_d(syy);
+            syz = rows4_sum_d(syz);
+            szz = rows4_sum_d(szz);
+#ifdef ME_MME_STATS
+            ++st_rounds;
+            st_served += (unsigned int) (__popcll(__ballot(in)) >> 2);
+#endif
+            if (in) {
+                done = true;
+                const int kk = k - 1;  // drop the query itself (map_eval.cpp:1672-1673)
+                if (kk >= min_k) {     // (:1675 k >= 10, :1458 k >= 5)
+                    const double inv_k = 1.0 / (double) kk, inv_km1 = 1.0 / (double) (kk - 1);
+                    const double cxx = (sxx - s1x * s1x * inv_k) * inv_km1;
+                    const double cxy = (sxy - s1x * s1y * inv_k) * inv_km1;
+                    const double cxz = (sxz - s1x * s1z * inv_k) * inv_km1;
+                    const double cyy = (syy - s1y * s1y * inv_k) * inv_km1;
+                    const double cyz = (syz - s1y * s1z * inv_k) * inv_km1;
+                    const double czz = (szz - s1z * s1z * inv_k) * inv_km1;
+                    // Eigen 3x3 determinant (cofactor expansion along row 0)
+                    det = cxx * (cyy * czz - cyz * cyz) - cxy * (cxy * czz - cyz * cxz) + cxz * (cxy * cyz - cyy * cxz);
+                    have = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (sl == gp) {  // lane (s, j) of pass s is point 16 s + j = this lane's own point
+            det_mine = det;
+            have_mine = have;
+        }
+    }
+#ifdef ME_MME_STATS
+    if (lane == 0) {
+        atomicAdd(&g_mme_stat[0], (unsigned long long) st_rounds);
+        atomicAdd(&g_mme_stat[1], (unsigned long long) st_cand);
+        atomicAdd(&g_mme_stat[2], (unsigned long long) st_served);
+        atomicAdd(&g_mme_stat[3], (unsigned long long) st_pairs);
+        atomicAdd(&g_mme_stat[4], (unsigned long long) st_blocks);
+        atomicAdd(&g_mme_stat[5], (unsigned long long) st_slots);
+    }
+#endif
+    // (the logarithm stays outside the loops: inside, the compiler hoists its polynomial constants into VGPRs that live
+    // across the candidate loop)
+    double H = 0.0;
+    bool ok = false;
+    const long long i = i_begin + (long long) (wbase + (unsigned int) lane);
+    if (i < i_end) {
+        if (have_mine) {
+            const double h = 0.5 * log(2.0 * M_PI * M_E * det_mine);  // ComputeEntropy (:1656); NaN for det < 0
+            if (!isnan(h) && !isinf(h)) {                              // (:1692)
+                H = h;
+                ok = true;
+            }
+        }
+        ent_s[i] = H;  // 0.0 where invalid (:1614) and for the halo points of a slab
+        valid_s[i] = ok ? 1 : 0;
+    }
+    __shared__ double smd[4];
+    __shared__ long long smi[4];
+    const double bs = block_sum_256(H, smd);
+    const long long bc = block_sum_256_ll(ok ? 1LL : 0LL, smi);
+    if (threadIdx.x == 0) {
+        part_sum[blockIdx.x] = bs;
+        part_cnt[blockIdx.x] = bc;
+    }
+}
+#endif  // ME_AB
+
 __global__ void k_mme_unpermute(const SPoint *__restrict__ sp, long long i_begin, long long i_end,
                                 const double *__restrict__ ent_s, const unsigned char *__restrict__ valid_s,
                                 double *__restrict__ ent_o, unsigned char *__restrict__ valid_o) {
@@ -452,30 +708,41 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     long long *outc = reinterpret_cast<long long *>(outs + 1);
     const double r2 = radius * radius;  // Open3D SearchRadius -> nanoflann radiusSearch(q, r*r) [upstream]
     {
-        // ME_MME_V=1 runs the first version (exact fp64 test per candidate, no cull) for A/B measurements; ME_MME_WAVES
-        // picks the occupancy the kernel is compiled for (waves per SIMD)
-        static const int variant = std::getenv("ME_MME_V") ? std::atoi(std::getenv("ME_MME_V")) : 2;
-        static const int waves = std::getenv("ME_MME_WAVES") ? std::atoi(std::getenv("ME_MME_WAVES")) : 8;
-        static const int tile = std::getenv("ME_MME_TILE") ? std::atoi(std::getenv("ME_MME_TILE")) : 32;
         const FrameView fr{c.origin[0], c.origin[1], c.origin[2], c.fine_h};
-        static const int dbg = std::getenv("ME_MME_DBG") ? std::atoi(std::getenv("ME_MME_DBG")) : 0;
         const float band = (float) (0x1p-12 * c.cell_h * c.cell_h);  // E, see k_mme3
         const float thr_lo = (float) r2 - band, thr_hi = (float) r2 + band;
         TimerScope ts(ctx, "mme");
+#define ME_LAUNCH_MME3(T, W, DBG)                                                                                             \
+    hipLaunchKernelGGL((k_mme3<T, W>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),                                \
+                       c.codes.as<unsigned long long>(), b, e, c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(),             \
+                       val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), DBG, c.cell_h, thr_lo, thr_hi)
+#ifdef ME_AB
+        // A/B build only (make EXTRA=-DME_AB): ME_MME_V=1 runs round 1's kernel (exact fp64 test per candidate, no cull),
+        // 6 round 3's MFMA kernel; ME_MME_WAVES / ME_MME_TILE pick the compiled occupancy / tile, ME_MME_DBG the profiling cuts
+        static const int variant = std::getenv("ME_MME_V") ? std::atoi(std::getenv("ME_MME_V")) : 3;
+        static const int waves = std::getenv("ME_MME_WAVES") ? std::atoi(std::getenv("ME_MME_WAVES")) : 8;
+        static const int tile = std::getenv("ME_MME_TILE") ? std::atoi(std::getenv("ME_MME_TILE")) : 32;
+        static const int dbg = std::getenv("ME_MME_DBG") ? std::atoi(std::getenv("ME_MME_DBG")) : 0;
+#define ME_LAUNCH_MME6(T, W)                                                                                                  \
+    hipLaunchKernelGGL((k_mme6<T, W>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),                                \
+                       c.codes.as<unsigned long long>(), b, e, c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(),             \
+                       val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), c.cell_h, thr_lo, thr_hi)
         if (variant == 1) {
             hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
                                c.grid, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting());
-        } else {
-#define ME_LAUNCH_MME3(T, W)                                                                                                  \
-    hipLaunchKernelGGL((k_mme3<T, W>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),                                \
-                       c.codes.as<unsigned long long>(), b, e, c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(),             \
-                       val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), dbg, c.cell_h, thr_lo, thr_hi)
-            if (tile == 32 && waves >= 8) ME_LAUNCH_MME3(32, 8);
-            else if (tile == 32) ME_LAUNCH_MME3(32, 7);
-            else if (waves >= 7) ME_LAUNCH_MME3(64, 7);
-            else ME_LAUNCH_MME3(64, 6);
+        } else if (variant == 6) {
+            if (tile == 64) ME_LAUNCH_MME6(64, 6);
+            else if (waves < 8) ME_LAUNCH_MME6(32, 6);
+            else ME_LAUNCH_MME6(32, 8);
+        } else if (tile == 32 && waves >= 8) ME_LAUNCH_MME3(32, 8, dbg);
+        else if (tile == 32) ME_LAUNCH_MME3(32, 7, dbg);
+        else if (waves >= 7) ME_LAUNCH_MME3(64, 7, dbg);
+        else ME_LAUNCH_MME3(64, 6, dbg);
+#undef ME_LAUNCH_MME6
+#else
+        ME_LAUNCH_MME3(32, 8, 0);
+#endif
 #undef ME_LAUNCH_MME3
-        }
     }
     const long long chunk = ((long long) nb + kStage - 1) / kStage;
     hipLaunchKernelGGL(k_mme_final, dim3(kStage), dim3(256), 0, ctx->stream, ps, pc, (long long) nb, chunk, ps2, pc2);
@@ -507,10 +774,11 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
         (void) hipMemcpyFromSymbol(st, HIP_SYMBOL(g_mme_stat), sizeof st);
         (void) hipMemcpyToSymbol(HIP_SYMBOL(g_mme_stat), zero, sizeof zero);
         if (st[0])
-            std::fprintf(stderr, "[mme stats] queries=%lld wave rounds=%llu (%.3f per 64 queries) candidates/round=%.1f lanes served/round=%.1f accepted/query=%.1f | rounds after a wave's first: %llu, candidates/round=%.1f lanes served/round=%.1f\n",
-                         (long long) (e - b), st[0], (double) st[0] * 64.0 / (double) (e - b), (double) st[1] / (double) st[0],
-                         (double) st[2] / (double) st[0], (double) st[3] / (double) (e - b), st[4],
-                         st[4] ? (double) st[5] / (double) st[4] : 0.0, st[4] ? (double) st[6] / (double) st[4] : 0.0);
+            std::fprintf(stderr, "[mme stats] queries=%lld pass rounds=%llu (%.3f per 16 queries) candidates/round=%.1f queries served/round=%.1f accepted/query=%.1f | MFMA blocks/round=%.2f steps taken/round=%.2f (of %.2f) pairs/step=%.1f\n",
+                         (long long) (e - b), st[0], (double) st[0] * 16.0 / (double) (e - b), (double) st[1] / (double) st[0],
+                         (double) st[2] / (double) st[0], (double) st[3] / (double) (e - b) - 1.0, (double) st[4] / (double) st[0],
+                         (double) st[5] / (double) st[0], 4.0 * (double) st[4] / (double) st[0],
+                         st[5] ? (double) st[3] / (double) st[5] : 0.0);
     }
 #endif
     c.mme_have = true;

@@ -271,11 +271,14 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
     // bound — and its query appended to far_list for k_nn_far (a whole wavefront per query, big leaves scanned 64 points
     // abreast): the longest chain of dependent steps in this kernel is far_cap, not the walk of the farthest outlier.
     __shared__ long long s_off[kMaxLevels];
-    __shared__ float s_lb[kNn1Block / 8][kMaxLevels + 1][8];          // per octet, per level: the children's lower bounds
-    __shared__ unsigned int s_beg[kNn1Block / 8][kMaxLevels + 1][9];  // ... and their [begin, end) on the level below
+    // walk cache, sized by the octree's REAL depth at launch (dynamic LDS: nn1_cache_bytes): per octet and level the children's
+    // lower bounds [8] and their [begin, end) on the level below [9].  With the table's worst-case depth (18 levels, 20 KB per
+    // block) a CU held 7 blocks; a 50 M-point cloud has ~10 levels.
+    extern __shared__ unsigned int s_dyn[];
     if (threadIdx.x < kMaxLevels) s_off[threadIdx.x] = oct.off[threadIdx.x];
     __syncthreads();
     const int L = oct.n_levels - 1;  // root level
+    const int lv = oct.n_levels + 1;  // cache lines per octet
     const ONode *__restrict__ nodes = oct.nodes;
     const long long n_items = list ? (long long) *list_count : (q_end - q_begin);
     const int sub = threadIdx.x & 7;
@@ -340,8 +343,8 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
             // round trip at all (the first version re-fetched the parent's header and its children and recomputed the
             // bounds: three dependent round trips per node visited), and a descent costs one.  These few hundred far
             // queries are pure pointer chasing: the kernel's time IS the longest chain of dependent fetches.
-            float *c_lb = s_lb[threadIdx.x >> 3][0];       // [level][8]
-            unsigned int *c_beg = s_beg[threadIdx.x >> 3][0];  // [level][9]: child begins + the end of the last one
+            float *c_lb = reinterpret_cast<float *>(s_dyn) + (threadIdx.x >> 3) * lv * 8;  // [level][8]
+            unsigned int *c_beg = s_dyn + (kNn1Block / 8) * lv * 8 + (threadIdx.x >> 3) * lv * 9;  // [level][9]: child begins + the end of the last one
             unsigned long long taken_lo = 0, taken_hi = 0;  // "children already entered" per level: levels 1..8 / 9..16
             double bound = best;  // pruning bound: min(best found, tightest box upper bound seen)
             bool walking = alive;
@@ -471,6 +474,7 @@ k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__rest
     __shared__ long long s_off[kMaxLevels];
     __shared__ float s_lb[4][kMaxLevels + 1][8];
     __shared__ unsigned int s_beg[4][kMaxLevels + 1][9], s_pb[4][kMaxLevels + 1][9];
+    if (*far_count == 0) return;  // the common case (and every slab rank's): nothing was handed over
     if (threadIdx.x < kMaxLevels) s_off[threadIdx.x] = oct.off[threadIdx.x];
     __syncthreads();
     const int L = oct.n_levels - 1;
@@ -817,7 +821,8 @@ static int nn_far_leaf() {
     static const int v = std::getenv("ME_NN_FAR_LEAF") ? std::atoi(std::getenv("ME_NN_FAR_LEAF")) : 1024;
     return v < 1 ? 1 : v;
 }
-constexpr unsigned int kFarGrid = 2048;  // blocks of four wavefronts: what the device holds at once, striding over the far list
+constexpr unsigned int kFarGrid = 1024;  // blocks of four wavefronts striding over the far list (empty list: immediate return)
+static size_t nn1_cache_bytes(const OctView &oct) { return (size_t) (kNn1Block / 8) * (size_t) (oct.n_levels + 1) * (8 + 9) * 4; }
 
 int nn_search(me_ctx *ctx, int qslot, int rslot) {
     if (qslot < 0 || qslot > 1 || rslot < 0 || rslot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
@@ -856,7 +861,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
             // (the far list can hold every query of the list: sized like it)
             ME_CHECK(ctx, ctx->nn_far.ensure((size_t) (e - b) * 4 + 64));
             TimerScope ts(ctx, "nn1");
-            hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
+            hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
                                r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0,
                                ctx->timers_on ? ctx->nn1_dbg() : nullptr, ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap());
             hipLaunchKernelGGL(k_nn_far, dim3(kFarGrid), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, r.sp.as<SPoint>(), r.oct,
@@ -913,13 +918,19 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
         ME_CHECK(ctx, qs.ensure((size_t) m * sizeof(SPoint)));
         ME_CHECK(ctx, qi.ensure((size_t) m * 4));
         hipLaunchKernelGGL(k_points_to_sp, dim3(nb), dim3(256), 0, ctx->stream, xyz_device, m, qs.as<SPoint>());
-        // (caller-supplied points — the cross-rank step, bulk queries — keep the plain octet walk: the hand-over to k_nn_far
-        // is tuned and measured on the list the grid pass leaves behind)
+        // caller-supplied points (the cross-rank step, bulk queries): the same hand-over as me_nn1 — a walk that has taken
+        // far_cap steps stores its best so far and goes to k_nn_far (the far list holds indices into qs)
+        ME_CHECK(ctx, ctx->nn_far.ensure((size_t) m * 4 + 64));
+        ME_CHECK(ctx, ctx->red.ensure(64));
+        unsigned int *d_cnt = ctx->red.as<unsigned int>();
+        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
         TimerScope ts(ctx, "nn1");
-        hipLaunchKernelGGL(k_nn1, dim3(std::min<unsigned int>(2 * nb, 256 * 32)), dim3(kNn1Block), 0, ctx->stream, qs.as<SPoint>(), 0LL, m,
-                           r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
+        hipLaunchKernelGGL(k_nn1, dim3(std::min<unsigned int>(2 * nb, 256 * 32)), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream,
+                           qs.as<SPoint>(), 0LL, m, r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
                            (const unsigned int *) nullptr, bounded ? 1 : 0, ctx->timers_on ? ctx->nn1_dbg() : nullptr,
-                           (unsigned int *) nullptr, (unsigned int *) nullptr, 0);
+                           ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap());
+        hipLaunchKernelGGL(k_nn_far, dim3(kFarGrid), dim3(256), 0, ctx->stream, qs.as<SPoint>(), 0LL, r.sp.as<SPoint>(), r.oct, d2_device,
+                           qi.as<int>(), ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn_far_leaf(), ctx->timers_on ? ctx->nn1_dbg() : nullptr);
     }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
