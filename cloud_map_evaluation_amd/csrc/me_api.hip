@@ -189,8 +189,6 @@ int me_transform_cloud(me_ctx *ctx, int slot, const double *T) {
 
 int me_nn1(me_ctx *ctx, int query_slot, int ref_slot, int32_t *idx, double *d2) {
     if (!ctx) return ME_ERR_ARG;
-    if ((idx || d2) && query_slot >= 0 && query_slot <= 1 && ctx->cloud[query_slot].slab.axis >= 0)
-        return ctx->fail(ME_ERR_STATE, "me_nn1: per-point outputs are not available in slab mode (pass NULL)");
     ME_TRY(me::nn_search(ctx, query_slot, ref_slot));
     if (idx || d2) return me::nn_fetch(ctx, query_slot, idx, d2);
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -354,6 +352,30 @@ int me_nn_points(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m,
 int me_nn_points_bounded(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_inout_device) {
     if (!ctx) return ME_ERR_ARG;
     return me::nn_points(ctx, ref_slot, xyz_device, m, d2_inout_device, true);
+}
+
+int me_nn_fetch(me_ctx *ctx, int query_slot, int32_t *idx, double *d2) {
+    if (!ctx) return ME_ERR_ARG;
+    if (query_slot < 0 || query_slot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
+    return me::nn_fetch(ctx, query_slot, idx, d2);
+}
+
+int me_slab_points(me_ctx *ctx, int slot, int64_t *orig_index, uint8_t *owned, int64_t capacity, int64_t *count) {
+    if (!ctx) return ME_ERR_ARG;
+    long long c = 0;
+    const int rc = me::slab_points(ctx, slot, orig_index, owned, capacity, &c);
+    if (count) *count = c;
+    return rc;
+}
+
+int me_set_mme_result(me_ctx *ctx, int slot, const double *entropies, const uint8_t *valid) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::set_mme_result(ctx, slot, entropies, valid);
+}
+
+int me_set_nn_result(me_ctx *ctx, int query_slot, int ref_slot, const double *d2) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::set_nn_result(ctx, query_slot, ref_slot, d2);
 }
 
 int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t count) {

@@ -91,10 +91,11 @@ __global__ void k_slab_flags(const double *__restrict__ xyz, long long n, int ha
 }
 __global__ void k_slab_compact(const double *__restrict__ xyz, long long n, int has_T, Mat4 T,
                                const unsigned int *__restrict__ flags, const unsigned int *__restrict__ pos,
-                               double *__restrict__ out) {
+                               double *__restrict__ out, int *__restrict__ orig) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flags[i]) return;
     const long long o = pos[i];
+    orig[o] = (int) i;  // per-point outputs in slab mode are reported against the uploaded array (me_slab_points)
     double p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
     if (has_T) transform_point(T, p[0], p[1], p[2], p);
     out[3 * o] = p[0];
@@ -464,8 +465,10 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
         ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const long long kept = (long long) last_pos + last_flag;
         ME_CHECK(ctx, c.xyz.ensure((size_t) std::max<long long>(kept, 1) * 3 * sizeof(double)));
+        ME_CHECK(ctx, c.slab_orig.ensure((size_t) std::max<long long>(kept, 1) * 4));
+        c.slab_identity = false;
         hipLaunchKernelGGL(k_slab_compact, dim3(grid_for(n)), dim3(256), 0, ctx->stream, in, n, T ? 1 : 0, m,
-                           flags.as<unsigned int>(), pos.as<unsigned int>(), c.xyz.as<double>());
+                           flags.as<unsigned int>(), pos.as<unsigned int>(), c.xyz.as<double>(), c.slab_orig.as<int>());
         c.n = kept;
         if (kept == 0) {  // this rank's slab (+halo) holds nothing of this cloud: every pass returns empty partials
             c.uploaded = true;
@@ -677,6 +680,35 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     }
     ME_CHECK(ctx, hipGetLastError());
     c.index_valid = true;
+    return ME_OK;
+}
+
+__global__ void k_slab_points(const double *__restrict__ xyz, long long n, SlabView s, const int *__restrict__ orig,
+                              long long *__restrict__ orig_out, unsigned char *__restrict__ owned_out) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (orig_out) orig_out[i] = orig ? (long long) orig[i] : i;
+    if (owned_out) owned_out[i] = slab_owned(s, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]) ? 1 : 0;
+}
+
+// me_slab_points: which uploaded point each per-point output entry belongs to, and whether this rank owns it
+int slab_points(me_ctx *ctx, int slot, int64_t *orig_index, uint8_t *owned, long long capacity, long long *count) {
+    if (slot < 0 || slot > 1 || !count) return ctx->fail(ME_ERR_ARG, "me_slab_points: bad argument");
+    Cloud &c = ctx->cloud[slot];
+    if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "me_slab_points: cloud not uploaded");
+    *count = c.n;
+    if ((!orig_index && !owned) || c.n == 0) return ME_OK;
+    if (capacity < c.n) return ctx->fail(ME_ERR_CAPACITY, "me_slab_points: capacity too small (count returned)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    DevBuf &oi = ctx->tmp[0], &ow = ctx->tmp[1];
+    ME_CHECK(ctx, oi.ensure((size_t) c.n * 8));
+    ME_CHECK(ctx, ow.ensure((size_t) c.n));
+    hipLaunchKernelGGL(k_slab_points, dim3(grid_for(c.n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), c.n, c.slab,
+                       c.slab_identity ? (const int *) nullptr : c.slab_orig.as<int>(), orig_index ? oi.as<long long>() : nullptr,
+                       owned ? ow.as<unsigned char>() : nullptr);
+    if (orig_index) ME_CHECK(ctx, hipMemcpyAsync(orig_index, oi.p, (size_t) c.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (owned) ME_CHECK(ctx, hipMemcpyAsync(owned, ow.p, (size_t) c.n, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ME_OK;
 }
 

@@ -114,6 +114,8 @@ struct Cloud {
     long long n_total = 0;  // points the caller passed to the upload
     SlabView slab{-1, 0, 0, 0, 0};
     DevBuf nn_unres;        // slab mode: sorted positions of the not-yet-global 1-NN results
+    DevBuf slab_orig;       // slab mode, filtered upload: int32[n] position of every kept point in the uploaded array
+    bool slab_identity = true;  // ... or the identity (me_upload_slab_device, no filter pass)
     long long n_unres = 0;
     bool uploaded = false;
     DevBuf xyz;  // double[n][3] original order, after the optional transform
@@ -299,6 +301,9 @@ int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, cons
 int voxel_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, long long capacity, long long *n_rows);
 int voxel_merge(me_ctx *ctx, int slot, double voxel_size, const double *rows_device, long long m);
 int transform_points_device(me_ctx *ctx, double *xyz_device, long long n, const double *T);
+int set_mme_result(me_ctx *ctx, int slot, const double *entropies, const uint8_t *valid);
+int set_nn_result(me_ctx *ctx, int qslot, int rslot, const double *d2);
+int slab_points(me_ctx *ctx, int slot, int64_t *orig_index, uint8_t *owned, long long capacity, long long *count);
 
 // ---- me_render.hip ----
 int render_distance(me_ctx *ctx, int qslot, double dis, double gate, int gate_mode, double *rgb, uint8_t *inlier);

@@ -676,8 +676,6 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     if (min_k < 2) return ctx->fail(ME_ERR_ARG, "me_mme: min_k must be >= 2 (covariance divides by k-1)");
     Cloud &c = ctx->cloud[slot];
     if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "me_mme: cloud not uploaded");
-    if (c.slab.axis >= 0 && (entropies || valid))
-        return ctx->fail(ME_ERR_STATE, "me_mme: per-point outputs are not available in slab mode (pass NULL)");
     if (c.slab.axis >= 0 && c.slab.reg_lo > -INFINITY && c.slab.lo - c.slab.reg_lo < radius)
         return ctx->fail(ME_ERR_ARG, "me_mme: slab halo is smaller than the radius");
     if (c.n == 0) {  // empty slab

@@ -180,4 +180,57 @@ int render_entropy(me_ctx *ctx, int slot, double *xyz_out, double *rgb_out, long
     return ME_OK;
 }
 
+// ---- results computed elsewhere (the ranks of a distributed run) -> this context's sorted order ----
+__global__ void k_permute_in(const SPoint *__restrict__ sp, long long n, const double *__restrict__ ent_o,
+                             const unsigned char *__restrict__ val_o, double *__restrict__ ent_s, unsigned char *__restrict__ val_s,
+                             int *__restrict__ idx_s) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long o = sp[i].idx;
+    ent_s[i] = ent_o[o];
+    if (val_s) val_s[i] = val_o[o];
+    if (idx_s) idx_s[i] = -1;
+}
+
+int set_mme_result(me_ctx *ctx, int slot, const double *entropies, const uint8_t *valid) {
+    if (slot < 0 || slot > 1 || !entropies || !valid) return ctx->fail(ME_ERR_ARG, "me_set_mme_result: bad argument");
+    Cloud &c = ctx->cloud[slot];
+    if (!c.uploaded || !c.index_valid) return ctx->fail(ME_ERR_STATE, "me_set_mme_result: cloud not uploaded");
+    if (c.slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_set_mme_result: the context must hold the whole cloud (no slab)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    const long long n = c.n;
+    DevBuf &eo = ctx->tmp[2], &vo = ctx->tmp[3];
+    ME_CHECK(ctx, eo.ensure((size_t) n * 8));
+    ME_CHECK(ctx, vo.ensure((size_t) n));
+    ME_CHECK(ctx, c.mme_ent.ensure((size_t) n * 8));
+    ME_CHECK(ctx, c.mme_val.ensure((size_t) n));
+    ME_CHECK(ctx, hipMemcpyAsync(eo.p, entropies, (size_t) n * 8, hipMemcpyHostToDevice, ctx->stream));
+    ME_CHECK(ctx, hipMemcpyAsync(vo.p, valid, (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_permute_in, dim3((unsigned int) ((n + 255) / 256)), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), n,
+                       eo.as<double>(), vo.as<unsigned char>(), c.mme_ent.as<double>(), c.mme_val.as<unsigned char>(), (int *) nullptr);
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    c.mme_have = true;
+    return ME_OK;
+}
+
+int set_nn_result(me_ctx *ctx, int qslot, int rslot, const double *d2) {
+    if (qslot < 0 || qslot > 1 || rslot < 0 || rslot > 1 || !d2) return ctx->fail(ME_ERR_ARG, "me_set_nn_result: bad argument");
+    Cloud &q = ctx->cloud[qslot];
+    if (!q.uploaded || !q.index_valid) return ctx->fail(ME_ERR_STATE, "me_set_nn_result: cloud not uploaded");
+    if (q.slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_set_nn_result: the context must hold the whole cloud (no slab)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    const long long n = q.n;
+    DevBuf &eo = ctx->tmp[2];
+    ME_CHECK(ctx, eo.ensure((size_t) n * 8));
+    ME_CHECK(ctx, q.nn_d2.ensure((size_t) n * 8));
+    ME_CHECK(ctx, q.nn_idx.ensure((size_t) n * 4));
+    ME_CHECK(ctx, hipMemcpyAsync(eo.p, d2, (size_t) n * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_permute_in, dim3((unsigned int) ((n + 255) / 256)), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), n,
+                       eo.as<double>(), (const unsigned char *) nullptr, q.nn_d2.as<double>(), (unsigned char *) nullptr, q.nn_idx.as<int>());
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    q.nn_ref_slot = rslot;  // (the neighbour indices are not known here: -1; the renderers and the statistics use d2 only)
+    q.n_unres = 0;
+    return ME_OK;
+}
+
 }  // namespace me

@@ -405,6 +405,31 @@ class Engine:
         self._ck(fn(self._ctx, ref_slot, xyz.data_ptr(), int(xyz.shape[0]), d2.data_ptr()))
         return d2
 
+    def nn_fetch(self, query_slot: int):
+        """-> (idx, d2) of the last nn1(query_slot, ..) as it stands now (slab mode: after nn_patch; halo points d2 = -1)."""
+        n = self.size(query_slot)
+        idx, d2 = np.empty(n, np.int32), np.empty(n, np.float64)
+        self._ck(self._L.me_nn_fetch(self._ctx, query_slot, _addr(idx), _addr(d2)))
+        return idx, d2
+
+    def set_mme_result(self, slot: int, entropies, valid):
+        """Per-point MME results computed elsewhere (distributed run) -> ColorPointCloudByMME works on this context."""
+        e = np.ascontiguousarray(entropies, dtype=np.float64)
+        v = np.ascontiguousarray(valid, dtype=np.uint8)
+        self._ck(self._L.me_set_mme_result(self._ctx, slot, _addr(e), _addr(v)))
+
+    def set_nn_result(self, query_slot: int, ref_slot: int, d2):
+        d = np.ascontiguousarray(d2, dtype=np.float64)
+        self._ck(self._L.me_set_nn_result(self._ctx, query_slot, ref_slot, _addr(d)))
+
+    def slab_points(self, slot: int):
+        """Slab mode: (orig_index[n], owned[n]) of the points this context holds, in the order of its per-point outputs."""
+        n = self.size(slot)
+        orig, owned = np.empty(n, np.int64), np.empty(n, np.uint8)
+        cnt = C.c_int64(0)
+        self._ck(self._L.me_slab_points(self._ctx, slot, _addr(orig), _addr(owned), n, C.byref(cnt)))
+        return orig, owned.astype(bool)
+
     def nn_patch(self, query_slot: int, d2):
         import torch
 

@@ -129,6 +129,8 @@ Param loadParametersFromYAML(const std::string &yaml_file_path) {
     if (config.has("use_tbb_mme")) param.use_tbb_mme = config.as_bool("use_tbb_mme");
     if (config.has("gpu_device")) param.gpu_device = config.as_int("gpu_device");
     if (config.has("strict_reference")) param.strict_reference = config.as_bool("strict_reference");
+    if (config.has("num_gpus")) param.num_gpus = config.as_int("num_gpus");
+    if (param.num_gpus < 1 || param.num_gpus > 64) throw std::runtime_error("num_gpus must be in 1..64");
     return param;
 }
 
@@ -148,7 +150,8 @@ std::string paramToJson(const Param &p) {
       << "\", \"gt_map_path\": \"" << p.map_gt_path_ << "\", \"scene_name\": \"" << p.name_ << "\", \"pcd_file_name\": \""
       << p.pcd_file_name_ << "\", \"enable_debug\": " << b(p.enable_debug) << ", \"use_tbb_mme\": " << b(p.use_tbb_mme)
       << ", \"use_visualization\": " << b(p.use_visualization) << ", \"result_path\": \"" << p.result_path_
-      << "\", \"gpu_device\": " << p.gpu_device << ", \"strict_reference\": " << b(p.strict_reference) << "}";
+      << "\", \"gpu_device\": " << p.gpu_device << ", \"strict_reference\": " << b(p.strict_reference) << ", \"num_gpus\": " << p.num_gpus
+      << "}";
     return o.str();
 }
 
@@ -164,6 +167,7 @@ MapEval::MapEval(Param &param) : param_(param), map_3d_(new PointCloud), gt_3d_(
     std::error_code ec;
     if (!fs::exists(results_subfolder)) fs::create_directory(results_subfolder, ec);
     results_file_path = results_subfolder + "map_results.txt";
+    if (param_.dist_rank > 0) results_file_path = "/dev/null";  // multi-GPU: rank 0 alone writes the result files
     file_result.open(results_file_path, std::ios::app);  // append mode (:168)
     if (!file_result.is_open()) std::cerr << "ERROR: Failed to open results file at " << results_file_path << std::endl;
     const std::time_t now_c = std::chrono::system_clock::to_time_t(std::chrono::system_clock::now());
@@ -176,6 +180,7 @@ MapEval::MapEval(Param &param) : param_(param), map_3d_(new PointCloud), gt_3d_(
 }
 
 MapEval::~MapEval() {
+    if (render_ctx_) me_destroy(render_ctx_);
     if (ctx_) me_destroy(ctx_);
     file_result.close();
 }
@@ -240,6 +245,7 @@ int MapEval::process() {
     if (param_.enable_debug)
         std::cout << "INFO: Loaded point clouds: " << map_3d_->size() << " points (Map), " << gt_3d_->size()
                   << " points (Ground Truth)." << std::endl;
+    if (comm_) return processDist(tic_toc.toc());  // num_gpus > 1 (map_eval_dist.cpp)
     t1 = tic_toc.toc();
     // The reference computes MME on the map as loaded (:56) and transforms it afterwards, inside
     // calculateMetricsWithInitialMatrix (:1206): same order here (me_transform_cloud below), skipped for an identity matrix.
@@ -601,6 +607,14 @@ void MapEval::calculateMetricsWithInitialMatrix() {
         fail(me_last_error(ctx_));
         return;
     }
+    const double t_both = tt.toc() / 1000.0;
+    finishInitialMatrixMetrics(eg, ge, t_acc);
+    t_fcd += t_both - t_acc;  // the gt -> est search is what the full Chamfer distance adds (:1194)
+}
+
+void MapEval::finishInitialMatrixMetrics(const me_nn_stats_out &eg, const me_nn_stats_out &ge, double t_acc_s) {
+    TicToc tt;
+    t_acc = t_acc_s;
     push_results(est_gt_results, eg);
     push_results(gt_est_results, ge);
     for (int i = 0; i < 5; ++i) {
@@ -612,9 +626,9 @@ void MapEval::calculateMetricsWithInitialMatrix() {
         iou_vec[i] = (double) num_intersection / (double) num_union;  // (:1250-1252)
     }
     // FULL CD: the reference never computes it on this path (stays 0.0); it is free here (same two searches).
-    const double t0 = tt.toc();
     full_chamfer_dist = param_.strict_reference ? 0.0 : (eg.mean_nn_dist + ge.mean_nn_dist);  // (:1429)
-    t_fcd = (tt.toc() - t0) / 1000.0 + (tt.toc() / 1000.0 - t_acc);
+    t_fcd = tt.toc() / 1000.0;
+    if (param_.dist_rank > 0) return;
     std::cout << "INFO: Chamfer Distance: " << eigen_row(cd_vec, 6) << std::endl;
     std::cout << "INFO: F1 Score: " << eigen_row(f1_vec, 6) << std::endl;
     std::cout << "INFO: est-gt MME: " << mme_est << " " << mme_gt << std::endl;
@@ -627,10 +641,11 @@ double MapEval::computeChamferDistance() {
     return cd;
 }
 
-void MapEval::calculateVMD() {
+void MapEval::calculateVMD(bool tables_ready, bool write_files) {
     TicToc ticToc;
     int64_t nv = 0;
-    // buildVoxelMap(gt), buildVoxelMap(est), updateVoxelMap (:248-252)
+    // buildVoxelMap(gt), buildVoxelMap(est), updateVoxelMap (:248-252); tables_ready: the merged tables of a multi-GPU run
+    if (!tables_ready)
     if (me_voxel_gaussians(ctx_, ME_SLOT_GT, param_.vmd_voxel_size_, nullptr, nullptr, nullptr, nullptr, nullptr, &nv) != ME_OK ||
         me_voxel_gaussians(ctx_, ME_SLOT_EST, param_.vmd_voxel_size_, nullptr, nullptr, nullptr, nullptr, nullptr, &nv) != ME_OK) {
         fail(me_last_error(ctx_));
@@ -642,6 +657,7 @@ void MapEval::calculateVMD() {
         fail(me_last_error(ctx_));
         return;
     }
+    if (!write_files) return;  // (ranks > 0 of a multi-GPU run hold the same scalars and write nothing)
     std::cout << "Update active/old/new voxel num: " << counts[0] << " " << counts[1] << " " << counts[2] << std::endl;
     std::vector<double> rows((size_t) n_rows * 27), ws((size_t) n_rows);
     if (n_rows > 0) {

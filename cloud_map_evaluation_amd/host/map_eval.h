@@ -11,6 +11,10 @@
 
 #include "../../include/mapeval_hip.h"
 
+namespace medist {
+struct Comm;
+}
+
 using Vector5d = std::array<double, 5>;
 
 struct PointCloud {  // stands in for open3d::geometry::PointCloud on the hot path (points_ only)
@@ -47,6 +51,9 @@ struct Param {
     int gpu_device = 0;             // `gpu_device:` HIP device ordinal
     bool strict_reference = false;  // `strict_reference:` true = reproduce FULL CD = 0 on the initial-matrix path
                                     // (the reference never calls computeChamferDistance there, map_eval.cpp:1204-1260)
+    int num_gpus = 1;               // `num_gpus:` N > 1 = one process per GPU (devices gpu_device .. gpu_device + N - 1), the
+                                    // clouds cut into N slabs, collectives over RCCL (map_eval_dist.cpp)
+    int dist_rank = 0;              // (set by the launcher, not a YAML key)
     void printParam() const;
 };
 
@@ -61,13 +68,21 @@ public:
     int process();                                         // map_eval.cpp:4-102
     void computeMME(PointCloud &cloud, PointCloud &gt);    // map_eval.cpp:149-189
     void calculateMetricsWithInitialMatrix();              // map_eval.cpp:1204-1260
+    void finishInitialMatrixMetrics(const me_nn_stats_out &eg, const me_nn_stats_out &ge, double t_acc_s);  // its tail (:1238-1259)
     int performRegistration();                             // map_eval.cpp:191-237 (point-to-point ICP only)
     void calculateMetrics();                               // map_eval.cpp:1147-1202
     double computeChamferDistance();                       // map_eval.cpp:1398-1431
-    void calculateVMD();                                   // map_eval.cpp:240-390
+    void calculateVMD(bool tables_ready = false, bool write_files = true);  // map_eval.cpp:240-390
     bool renderEntropy(int slot, std::vector<double> &xyz, std::vector<double> &rgb, bool want_points);  // :686-735
     void saveMmeResults();                                 // map_eval.cpp:392-421
     void saveRegistrationResults();                        // map_eval.cpp:424-482 (text lines; renderers out of scope)
+
+    // multi-GPU (map_eval_dist.cpp): the communicator of this rank; forced = take the distributed path with one rank too
+    void setComm(medist::Comm *comm, bool forced) {
+        comm_ = comm;
+        dist_forced_ = forced;
+    }
+    int processDist(double t_loaded);
 
     Param param_;
     // results, same names as the reference (map_eval.h:328-353)
@@ -83,6 +98,12 @@ public:
 
 private:
     int fail(const std::string &msg);
+    int allReduceHost(std::vector<double> &v, bool min_op);
+    int gatherPerPoint(int slot, size_t n_global, const std::vector<double> *vals, const std::vector<uint8_t> *flags,
+                       std::vector<double> *vals_out, std::vector<uint8_t> *flags_out);
+    medist::Comm *comm_ = nullptr;
+    bool dist_forced_ = false;
+    me_ctx *render_ctx_ = nullptr;  // rank 0 of a multi-GPU run: the whole clouds, for the colour renderers
     std::shared_ptr<PointCloud> map_3d_, gt_3d_;
     me_ctx *ctx_ = nullptr;
     double t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t_fcd = 0, t_acc = 0;

@@ -3,11 +3,23 @@
 // essentials, runs MapEval::process().  Extra modes used by the tests (no GPU needed):
 //   map_eval --parse-config <yaml>   print the parsed Param as JSON
 //   map_eval --cloud-info <pcd|ply>  print point count and coordinate sums after NaN/inf removal
+//
+// Multi-GPU (`num_gpus: N` in the YAML; not a reference key): the process forks N - 1 children BEFORE anything touches HIP;
+// rank r drives device gpu_device + r (one process per GPU), the ranks meet in an RCCL communicator whose ncclUniqueId rank 0
+// publishes in a file next to the results (host/dist_comm.hpp), rank 0 writes every result file.  Test hooks:
+// MAPEVAL_FORCE_DIST=1 takes the distributed path with ONE rank (every collective goes through RCCL);
+// MAPEVAL_COMM=file + MAPEVAL_SINGLE_DEVICE=1 run N ranks on one GPU with file-based collectives (RCCL refuses two ranks on a
+// device).
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <cstdlib>
+#include <filesystem>
 #include <iomanip>
 #include <iostream>
 #include <thread>
 
+#include "dist_comm.hpp"
 #include "map_eval.h"
 #include "pcd_io.hpp"
 
@@ -53,11 +65,69 @@ int main(int argc, char **argv) {
     }
     std::cout << "MapEval (MI355X / HIP engine): A Unified Framework for Map Evaluation\n"
               << "CPU Cores: " << std::thread::hardware_concurrency() << "\n";
-    param.printParam();
+    // ---- multi-GPU launcher: one process per GPU ----
+    const bool forced = std::getenv("MAPEVAL_FORCE_DIST") && std::string(std::getenv("MAPEVAL_FORCE_DIST")) == "1";
+    const int world = param.num_gpus;
+    int rank = 0;
+    std::vector<pid_t> children;
+    const long launcher_pid = (long) getpid();
+    if (world > 1) {
+        std::cout.flush();
+        for (int r = 1; r < world; ++r) {
+            const pid_t pid = fork();
+            if (pid < 0) {
+                std::cerr << "[ERROR] fork failed" << std::endl;
+                return EXIT_FAILURE;
+            }
+            if (pid == 0) {
+                rank = r;
+                children.clear();
+                break;
+            }
+            children.push_back(pid);
+        }
+    }
+    const bool single_device = std::getenv("MAPEVAL_SINGLE_DEVICE") && std::string(std::getenv("MAPEVAL_SINGLE_DEVICE")) == "1";
+    param.dist_rank = rank;
+    if (!single_device) param.gpu_device += rank;
+    std::unique_ptr<medist::Comm> comm;
+    if (world > 1 || forced) {
+        std::error_code ec;
+        std::filesystem::create_directories(param.evaluation_map_pcd_path_ + "map_results", ec);
+        const std::string base = param.evaluation_map_pcd_path_ + "map_results/.mapeval_comm_" + std::to_string(launcher_pid);
+        if (std::getenv("MAPEVAL_COMM") && std::string(std::getenv("MAPEVAL_COMM")) == "file") {
+            std::filesystem::create_directories(base, ec);
+            auto c = std::make_unique<medist::FileComm>();
+            c->init(rank, world, base);
+            comm = std::move(c);
+        } else {
+            auto c = std::make_unique<medist::RcclComm>();
+            if (!c->init(rank, world, param.gpu_device, base + ".id")) {
+                std::cerr << "[ERROR] rank " << rank << ": RCCL bootstrap failed: " << c->err << std::endl;
+                return EXIT_FAILURE;
+            }
+            comm = std::move(c);
+        }
+    }
+    if (rank == 0) param.printParam();
     std::cout << "Starting evaluation...\n"
               << "================================================================================\n\n";
-    MapEval map_eval(param);
-    const int rc = map_eval.process();
+    int rc;
+    {
+        MapEval map_eval(param);
+        if (comm) map_eval.setComm(comm.get(), forced);
+        rc = map_eval.process();
+    }
+    comm.reset();
+    if (rank > 0) _exit(rc == 0 ? EXIT_SUCCESS : EXIT_FAILURE);
+    for (pid_t pid : children) {
+        int st = 0;
+        if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : -1;
+    }
+    if (world > 1 && std::getenv("MAPEVAL_COMM") && std::string(std::getenv("MAPEVAL_COMM")) == "file") {
+        std::error_code ec;
+        std::filesystem::remove_all(param.evaluation_map_pcd_path_ + "map_results/.mapeval_comm_" + std::to_string(launcher_pid), ec);
+    }
     std::cout << "\n================================================================================\n"
               << (rc == 0 ? "Evaluation completed successfully!\n" : "Evaluation FAILED.\n")
               << "================================================================================\n\n";

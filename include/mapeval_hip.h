@@ -93,7 +93,12 @@ int me_set_shard(me_ctx *ctx, int rank, int world);
  * visible as reference points / neighbours only.  Every rank therefore sorts and indexes ~1/world of each cloud.
  * MME is exact when halo >= nn_radius.  1-NN is exact for every query whose best distance is below its distance to
  * the slab's outer faces; the others are returned by me_nn_unresolved for the cross-rank step (me_nn_points on every
- * rank, min-reduce, me_nn_patch).  Per-point outputs (idx/d2/entropies arrays) are not available in slab mode.
+ * rank, min-reduce, me_nn_patch).
+ * Per-point outputs in slab mode (round 3; what the distributed host needs for map_entropy.pcd / raw_rendered_dis_map.pcd,
+ * map_eval.cpp:485-495, 686-736): the entropies / valid arrays of me_mme and the idx / d2 arrays of me_nn1 / me_nn_fetch have
+ * one entry per point this context HOLDS of the slot (me_cloud_size: owned + halo), in the order me_slab_points reports;
+ * halo points read entropy 0 / valid 0 / d2 -1 / idx -1; idx is an index into the points held of the reference slot and is
+ * the global neighbour only where the query did not go through the cross-rank step (d2 is global after me_nn_patch).
  * axis < 0 switches slab mode off.  Must be called before the uploads it applies to. */
 int me_set_slab(me_ctx *ctx, int axis, double lo, double hi, double halo);
 
@@ -112,6 +117,19 @@ int me_nn_points_bounded(me_ctx *ctx, int ref_slot, const double *xyz_device, in
 /* Overwrites the squared distances of the unresolved queries (same order as me_nn_unresolved returned them) with the
  * globally min-reduced values d2_device[count]. */
 int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t count);
+/* The per-point result of the last me_nn1(query_slot, ..) as it stands now (after me_nn_patch in slab mode): idx / d2 as
+ * me_nn1 returns them (either may be NULL). */
+int me_nn_fetch(me_ctx *ctx, int query_slot, int32_t *idx, double *d2);
+/* Slab mode: the points this context holds of `slot`, in the order of its per-point outputs: orig_index[i] = the point's
+ * position in the array that was uploaded (identity after me_upload_slab_device), owned[i] = 1 for the slab's own points,
+ * 0 for halo.  Either array may be NULL; *count = me_cloud_size.  ME_ERR_CAPACITY when capacity < count. */
+int me_slab_points(me_ctx *ctx, int slot, int64_t *orig_index, uint8_t *owned, int64_t capacity, int64_t *count);
+/* Hand a context per-point results that were computed elsewhere (by the ranks of a distributed run, put together with
+ * me_slab_points): afterwards me_render_entropy(slot) / me_render_distance(query_slot, ..) colour the WHOLE cloud held by
+ * this context exactly as after me_mme / me_nn1 (map_entropy.pcd, raw_rendered_dis_map.pcd; map_eval.cpp:485-495, 686-736).
+ * Arrays are host memory in cloud order, one entry per point of the slot. */
+int me_set_mme_result(me_ctx *ctx, int slot, const double *entropies, const uint8_t *valid);
+int me_set_nn_result(me_ctx *ctx, int query_slot, int ref_slot, const double *d2);
 
 /* Slab mode, voxel partials: Gaussians of the OWNED points only, RAW second moments (M2 = sum (p-mu)(p-mu)^T, no
  * division), ascending key order; partials of the same voxel from different ranks merge with Chan's formula. */

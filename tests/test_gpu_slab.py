@@ -182,3 +182,68 @@ def test_one_rank_step_through_rccl_matches_the_plain_step():
         for k in ("mean", "rmse", "sigma", "number", "fitness"):
             assert np.array_equal(np.asarray(r[d][k]), np.asarray(ref[d][k])), (d, k)
     assert r["n_w"] == ref["n_w"] and r["mme_valid"] == ref["mme_valid"]
+
+
+@pytest.mark.parametrize("prefiltered", [False, True])
+def test_per_point_outputs_in_slab_mode_cover_the_whole_cloud(prefiltered):
+    """Round 3: me_mme / me_nn1 return per-point arrays under a slab — one entry per point the context
+    holds, me_slab_points says which uploaded point each entry is and whether the rank owns it.  The owned entries of the
+    ranks, put together, are the single-context arrays: valid flags and squared distances bit for bit, entropies to 1e-12 (the
+    candidate streams are summed in a different order); what map_entropy.pcd / raw_rendered_dis_map.pcd need
+    (map_eval.cpp:485-495, 686-736)."""
+    import torch
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, gt = _scene(90_000)
+    world, halo = 3, 1.0
+    with Engine(0) as eng:
+        eng.upload(0, est, cell_size=0.1)
+        eng.upload(1, gt, cell_size=0.1)
+        _, ent_w, val_w, _, _ = eng.mme(0, 0.1, 10)
+        idx_w, d2_w = eng.nn1(0, 1)
+        ent = np.full(len(est), np.nan)
+        val = np.zeros(len(est), np.uint8)
+        d2 = np.full(len(est), np.nan)
+        nn_xyz = np.full((len(est), 3), np.nan)
+        seen = np.zeros(len(est), np.int32)
+        for rank in range(world):
+            axis, lo, hi = medist.slab_bounds(torch.from_numpy(gt), rank, world)
+            eng.set_slab(axis, lo, hi, halo)
+            if prefiltered:  # what the halo exchange delivers: exactly the slab + halo, uploaded without the filter pass
+                ke = np.nonzero((est[:, axis] >= lo - halo) & (est[:, axis] < hi + halo))[0]
+                kg = np.nonzero((gt[:, axis] >= lo - halo) & (gt[:, axis] < hi + halo))[0]
+                eng.upload_slab(0, torch.from_numpy(est[ke]).cuda(), cell_size=0.1)
+                eng.upload_slab(1, torch.from_numpy(gt[kg]).cuda(), cell_size=0.1)
+            else:
+                ke, kg = np.arange(len(est)), np.arange(len(gt))
+                eng.upload(0, est, cell_size=0.1)
+                eng.upload(1, gt, cell_size=0.1)
+            orig, owned = eng.slab_points(0)
+            orig_g, _ = eng.slab_points(1)
+            assert len(orig) == eng.size(0) and np.all(np.diff(orig) > 0)
+            coord = est[ke[orig], axis]
+            assert np.array_equal(owned, (coord >= lo) & (coord < hi))
+            _, e_r, v_r, nv, _ = eng.mme(0, 0.1, 10)
+            assert nv == int(v_r.sum()) and not v_r[~owned].any() and not e_r[~owned].any()
+            i_r, d_r = eng.nn1(0, 1)
+            assert np.all(d_r[~owned] == -1.0) and np.all(i_r[~owned] == -1)
+            open_q = eng.nn_unresolved(0)
+            if len(open_q):
+                with Engine(0) as full:
+                    full.upload(1, gt, cell_size=0.1)
+                    eng.nn_patch(0, full.nn_points(1, open_q))
+                i_r, d_r = eng.nn_fetch(0)
+            g = ke[orig[owned]]
+            seen[g] += 1
+            ent[g], val[g], d2[g] = e_r[owned], v_r[owned], d_r[owned]
+            nn_xyz[g] = gt[kg[orig_g[np.maximum(i_r[owned], 0)]]]
+        eng.set_slab(-1)
+    assert np.all(seen == 1), "every point is owned by exactly one rank"
+    assert np.array_equal(val, val_w) and np.array_equal(d2, d2_w)
+    np.testing.assert_allclose(ent, ent_w, rtol=1e-12, atol=0)
+    # the local neighbour index is the global one wherever the local search was final
+    dd = est - nn_xyz
+    local = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
+    assert (local == d2_w).mean() > 0.99 and np.all(local >= d2_w)
