@@ -339,7 +339,7 @@ def main():
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             # HBM bytes per launch from the rocprofv3 PMC passes (profiles/run_profile.sh, separate --pmc runs of this very
             # command): quoted only when they were collected at THIS kernel source and workload, otherwise null
-            traffic, traffic_src = None, None
+            traffic, traffic_x2, traffic_src = None, None, None
             sha = kernel_source_sha()
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
@@ -347,11 +347,14 @@ def main():
                     tj = json.load(open(tpath))
                     if tj.get("_kernel_source_sha") == sha and tj.get("_workload") == args.workload and tj.get("_points") == args.points:
                         traffic = tj.get(dom)
+                        traffic_x2 = tj.get(dom + "_fetch_x2")
                         traffic_src = {"file": "profiles/traffic.json", "kernel_source_sha": sha, "collected": tj.get("_tag")}
                 except Exception:
                     traffic = None
             line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_corrected": traffic_x2,
+                                "traffic_note": "bytes per launch: raw FETCH_SIZE + WRITE_SIZE, and with the guide's gfx950 FETCH x2 correction",
+                                "traffic_source": traffic_src,
                                 "avg_launch_ms": avg_ms, "units_per_launch": units, "algorithmic_bytes_per_launch": alg_bytes,
                                 "kernel_ms_per_step": {k: v[0] for k, v in fam.items()},
                                 "nn_fallback_fraction": (nn_fallback / nn_total) if nn_total else None,

@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence behind profiles/<tag>_*: run on the GPU box from the repo root,
 #   bash profiles/run_profile.sh r01
 # Counters are collected in their own passes (never together with --kernel-trace/--stats).
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"

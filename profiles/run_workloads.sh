@@ -1,7 +1,7 @@
 #!/bin/bash
 # The bench line of `python bench.py` and of the other --workloads, on the GPU box from the repo root:
 #   bash profiles/run_workloads.sh r02      -> gpurun_out/summary_<tag>/{bench_default.json, workloads.json}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/summary_$TAG
 mkdir -p "$OUT"
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"

@@ -78,6 +78,11 @@ def main(src, out, tag="r02"):
     # per-family figure bench.py reports as roofline.traffic (raw FETCH+WRITE per launch)
     fam = {{"me::k_mme3": "mme"}.get(k, k.replace("me::k_", "")): v["hbm_bytes_per_launch_raw"] for k, v in traffic.items()
            if k in ("me::k_nn_grid", "me::k_mme", "me::k_mme3", "me::k_nn1")}
+    # the same with the guide's gfx950 correction (FETCH_SIZE under-reports wide reads by 2x: k_morton streams 1.2 GB and reports
+    # 0.60 on this very profile) — bench.py quotes it as roofline.traffic_corrected
+    for k, v in traffic.items():
+        if k in ("me::k_nn_grid", "me::k_mme", "me::k_mme3", "me::k_nn1"):
+            fam[{"me::k_mme3": "mme"}.get(k, k.replace("me::k_", "")) + "_fetch_x2"] = v["hbm_bytes_per_launch_fetch_x2"]
     # provenance: bench.py quotes these figures only for the kernel sources and the workload they were collected with
     fam["_kernel_source_sha"] = kernel_source_sha()
     fam["_workload"], fam["_points"], fam["_tag"] = "c4_multisession", 50_000_000, tag
