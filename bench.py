@@ -193,6 +193,39 @@ def cpu_baseline_full(est, gt, P, evaluate_gt_mme, frac=0.01):
             "seconds": {k: round(v, 3) for k, v in t.items()}}
 
 
+def cpu_baseline_reference(args, P, evaluate_gt_mme, n=1_000_000):
+    """The REFERENCE'S OWN code (oracle/_ref: its map_eval.cpp + voxel_calculator.cpp compiled over stand-in headers, see
+    oracle/ref_build/) running the body of MapEval::process() — computeMME (TBB est loop, serial GT loop),
+    calculateMetricsWithInitialMatrix (two serial loops), calculateVMD — on a bounded pair of the same generator, wall clock on
+    this box's host cores.  The trees of a 1 M-point cloud are 5-6 levels shallower than the workload's: per-point cost is
+    UNDER-stated, the figure is an upper bound of what the reference would reach on the full pair."""
+    from oracle import ref
+    from cloud_map_evaluation_amd import synth
+
+    if not ref.available():
+        return None
+    est, gt = synth.scan_pair(n, density=args.density, seed=100)
+    est, gt = est.numpy(), gt.numpy()
+    cfg = ref.config(trunc=P.trunc_dist_, icp_max_distance=P.icp_max_distance_, nn_radius=P.nn_radius_, vmd_voxel_size=P.vmd_voxel_size_,
+                     evaluate_gt_mme=evaluate_gt_mme)
+    import contextlib
+
+    t0 = time.perf_counter()
+    with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
+        fd = os.dup(1)
+        os.dup2(dn.fileno(), 1)  # the reference prints its progress from C++
+        try:
+            r = ref.suite_initial(est, gt, cfg)
+        finally:
+            os.dup2(fd, 1)
+            os.close(fd)
+    dt = time.perf_counter() - t0
+    return {"value": 2 * n / 1e6 / dt, "unit": "Mpts/s", "cores": os.cpu_count() or 1, "kind": "reference",
+            "sample": f"oracle/_ref (the reference's own sources) on scan_pair {n} + {n} pts: computeMME + calculateMetricsWithInitialMatrix + "
+                      f"calculateVMD, {dt:.1f} s wall; serial loops as the reference has them, its TBB / OpenMP loops on all cores",
+            "mme_est": r["mme_est"], "vmd": r["vmd"]}
+
+
 def cpu_baseline_sample(args, P, evaluate_gt_mme, n=2_000_000):
     """Quick variant: the oracle end to end on a small pair of the same generator (trees are NOT full size)."""
     import oracle
@@ -385,6 +418,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline_full(est_h.numpy(), gt_h.numpy(), P, evaluate_gt_mme)
         else:
             line["cpu_baseline"] = cpu_baseline_sample(args, P, evaluate_gt_mme)
+        try:  # the reference's own code on a bounded sample, next to the port's full-size extrapolation
+            line["cpu_baseline"]["reference_run"] = cpu_baseline_reference(args, P, evaluate_gt_mme)
+        except Exception as e:  # (a checker, never the product: its absence or failure does not fail the bench)
+            line["cpu_baseline"]["reference_run"] = {"error": str(e)[:200]}
 
     eng.close()
     if world > 1:

@@ -247,8 +247,12 @@ int ref_mme(int variant, const double *xyz, int64_t n, double radius, const char
         else
             *mean = me.ComputeMeanMapEntropyUsingNormalTBB(pc, ent, radius);
         copy_doubles(ent, entropies);
+        // The parallel variants set bits of `valid_entropy_points` (a std::vector<bool>) from several threads: a data race on
+        // shared words that can lose an update (map_eval.cpp:1586, :1694).  A point is valid exactly when its entropy was
+        // stored (the same branch, :1692-1697; a stored entropy of exactly 0.0 would need det = 1 / (2 pi e) to the last bit),
+        // so the flag reported here is what a race-free run of the reference leaves.
         if (valid)
-            for (int64_t i = 0; i < n; ++i) valid[i] = me.valid_entropy_points[(size_t) i] ? 1 : 0;
+            for (int64_t i = 0; i < n; ++i) valid[i] = (me.valid_entropy_points[(size_t) i] || ent[(size_t) i] != 0.0) ? 1 : 0;
     });
 }
 
