@@ -511,6 +511,11 @@ int cloud_finish(me_ctx *ctx, int slot, bool bbox_ready) {
         c.bbox_lo[d] = lo;
         c.bbox_hi[d] = hi;
     }
+    // slab mode: whatever the upload path was (filter pass, or me_upload_slab_device which trusts the caller's exchange), every
+    // point held must lie inside [reg_lo, reg_hi) along the slab axis — otherwise the halo the per-point passes rely on is not the
+    // one me_set_slab declared (a caller whose cuts or halo differ from its exchange's would get silently incomplete neighbourhoods)
+    if (c.slab.axis >= 0 && (c.bbox_lo[c.slab.axis] < c.slab.reg_lo || !(c.bbox_hi[c.slab.axis] < c.slab.reg_hi)))
+        return ctx->fail(ME_ERR_ARG, "slab upload: points outside [lo - halo, hi + halo) of me_set_slab along the slab axis");
     c.uploaded = true;
     return cloud_build_index(ctx, slot, c.cell_size_req);
 }

@@ -247,3 +247,25 @@ def test_per_point_outputs_in_slab_mode_cover_the_whole_cloud(prefiltered):
     dd = est - nn_xyz
     local = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
     assert (local == d2_w).mean() > 0.99 and np.all(local >= d2_w)
+
+
+def test_slab_upload_rejects_points_outside_the_declared_region():
+    """me_upload_slab_device trusts that the exchange delivered exactly slab + halo; a caller whose cuts or halo differ from
+    me_set_slab's gets a loud error, not silently incomplete neighbourhoods near the faces."""
+    import torch
+
+    from cloud_map_evaluation_amd.engine import Engine, MapEvalError
+
+    est, _ = _scene(20_000)
+    axis = 0
+    lo, hi = np.quantile(est[:, axis], [0.3, 0.6])
+    with Engine(0) as eng:
+        eng.set_slab(axis, lo, hi, 0.5)
+        inside = est[(est[:, axis] >= lo - 0.5) & (est[:, axis] < hi + 0.5)]
+        eng.upload_slab(0, torch.from_numpy(inside).cuda(), cell_size=0.1)  # exactly the region: accepted
+        assert eng.size(0) == len(inside)
+        wider = est[(est[:, axis] >= lo - 0.8) & (est[:, axis] < hi + 0.5)]  # an exchange run with a wider halo
+        assert len(wider) > len(inside)
+        with pytest.raises(MapEvalError, match="outside"):
+            eng.upload_slab(0, torch.from_numpy(wider).cuda(), cell_size=0.1)
+        eng.set_slab(-1)
