@@ -293,6 +293,11 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
 
+    if world > 1:
+        # distributed step: the SECOND lane runs the long MME kernels, the main lane the latency-bound cross-rank step; giving the
+        # MME lane the dispatch priority shortens the step (emulated 8-rank step 11.5 -> 11.2 ms, profiles/README.md); one GPU: the
+        # library's default (main lane first)
+        os.environ.setdefault("ME_STREAM_PRIO", "twin")
     eng = Engine(local_rank)
 
     def sync():

@@ -463,6 +463,9 @@ def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, wor
         raise
 
 
+_CROSS_CAP = 4096  # open queries per direction and rank the folded all-gather carries (overflow: exact-size fallback)
+
+
 def _pad_rows(t, rows: int, width: int, device):
     import torch
 
@@ -504,29 +507,41 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         lane.wait_nn()
         cnt[1] = lane.unres_back
         tr.mark("wait_nn_back")
-    # --- collective 4: everybody learns everybody's open-query counts (and the global cloud sizes) ---
-    mine = torch.tensor([cnt[0], cnt[1], n_loc[0], n_loc[1]], dtype=torch.int64)
+    # --- collectives 4 + 5 folded (round 3): ONE fixed-capacity all-gather carries every rank's open-query counts, its cloud
+    #     sizes (row 0) AND the open queries of both directions with the bound to beat (rows 1 ..): no message is sized from a
+    #     previous one, one host read instead of two.  A rank with more than `cap` open queries in a direction (far beyond what
+    #     the 1 m halo leaves: outliers and non-overlapping regions) makes everybody fall back to a second, exactly sized gather. ---
+    cap = _CROSS_CAP
+    mineq = [eng.nn_unresolved(q, with_d2=True) if cnt[i] else None for i, (q, r) in enumerate(dirs)]
+    wdev = next((t.device for t in mineq if t is not None), comm_device)
+    head = torch.zeros((1, 4), dtype=torch.float64, device=comm_device)
+    head[0] = torch.tensor([cnt[0], cnt[1], n_loc[0], n_loc[1]], dtype=torch.float64)
     if single:
-        table = mine[None, :]
+        table = head.to(torch.int64).cpu()
+        allq = None
     else:
-        parts = [torch.empty(4, dtype=torch.int64, device=comm_device) for _ in range(world)]
-        dist.all_gather(parts, mine.to(comm_device))
-        table = torch.stack(parts).cpu()
+        msg = torch.cat([head] + [_pad_rows(mineq[i][:cap] if mineq[i] is not None else None, cap, 4, comm_device) for i in range(2)])
+        parts = [torch.empty_like(msg) for _ in range(world)]
+        dist.all_gather(parts, msg)
+        allq = torch.stack(parts)                                 # (world, 1 + 2 cap, 4)
+        table = allq[:, 0, :].to(torch.int64).cpu()               # the ONE host read of the cross-rank step
     n_e, n_g = int(table[:, 2].sum()), int(table[:, 3].sum())
     tr.mark("counts")
-    # --- collectives 5 + 6: open queries of both directions in one all-gather, their answers in one MIN-reduce ---
     n_cross = int(table[:, 0].sum() + table[:, 1].sum())
     if not single and n_cross > 0:
         cmax = [int(table[:, 0].max()), int(table[:, 1].max())]
-        mineq = [eng.nn_unresolved(q, with_d2=True) if cnt[i] else None for i, (q, r) in enumerate(dirs)]
-        wdev = next((t.device for t in mineq if t is not None), comm_device)
-        msg = torch.cat([_pad_rows(mineq[i], cmax[i], 4, comm_device) for i in range(2)])  # xyz + the bound to beat
-        parts = [torch.empty_like(msg) for _ in range(world)]
-        dist.all_gather(parts, msg)
-        allq = torch.stack(parts)                                 # (world, cmax_e + cmax_g, 4)
+        if max(cmax) > cap:  # overflow: the exact-size gather of round 2
+            msg = torch.cat([_pad_rows(mineq[i], cmax[i], 4, comm_device) for i in range(2)])
+            parts = [torch.empty_like(msg) for _ in range(world)]
+            dist.all_gather(parts, msg)
+            allq = torch.stack(parts)
+            offs = [0, cmax[0]]
+        else:
+            offs = [1, 1 + cap]
+            cmax = [cap, cap]
         d2 = torch.full(allq.shape[:2], float("inf"), dtype=torch.float64, device=comm_device)
-        base = 0
         for i, (q, r) in enumerate(dirs):
+            base = offs[i]
             sel = [(k, int(table[k, i])) for k in range(world) if k != rank and int(table[k, i]) > 0]
             if sel:
                 qs = torch.cat([allq[k, base:base + c] for k, c in sel])
@@ -537,13 +552,10 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
                     o += c
             if cnt[i]:
                 d2[rank, base:base + cnt[i]] = allq[rank, base:base + cnt[i], 3]  # the owner's own search is its answer
-            base += cmax[i]
         dist.all_reduce(d2, op=dist.ReduceOp.MIN)
-        base = 0
         for i, (q, r) in enumerate(dirs):
             if cnt[i]:
-                eng.nn_patch(q, d2[rank, base:base + cnt[i]].contiguous().to(wdev))
-            base += cmax[i]
+                eng.nn_patch(q, d2[rank, offs[i]:offs[i] + cnt[i]].contiguous().to(wdev))
     tr.mark("cross_rank_nn")
     parts = [eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_) for q, r in dirs]
     tr.mark("nn_sums")

@@ -526,6 +526,8 @@ def _dist_worker(rank, world, port, est, gt, T, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if os.environ.get("ME_TEST_CROSS_CAP"):  # force the overflow path of the folded cross-rank all-gather
+        medist._CROSS_CAP = int(os.environ["ME_TEST_CROSS_CAP"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=0.5, initial_matrix_=T)
@@ -543,11 +545,15 @@ def _dist_worker(rank, world, port, est, gt, T, q):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_input_suite_gloo_equals_single_process_oracle(world):
+@pytest.mark.parametrize("world,cap", [(2, 0), (3, 0), (2, 5)])
+def test_distributed_input_suite_gloo_equals_single_process_oracle(world, cap, monkeypatch):
     """1/world of each cloud per rank -> slab cuts from two collectives -> all-to-all halo exchange -> local passes ->
-    batched cross-rank resolve -> merged voxel tables: every rank ends with the single-process oracle's answer."""
+    batched cross-rank resolve (one fixed-capacity all-gather with the counts in-band; cap = 5 forces its overflow fallback)
+    -> merged voxel tables: every rank ends with the single-process oracle's answer."""
     import torch.multiprocessing as mp
+
+    if cap:
+        monkeypatch.setenv("ME_TEST_CROSS_CAP", str(cap))
 
     import oracle
     from cloud_map_evaluation_amd import synth
