@@ -528,6 +528,11 @@ int cloud_transform(me_ctx *ctx, int slot, const double *T) {
     if (c.slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_transform_cloud: not available in slab mode (pass T to the upload)");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     if (c.n == 0) return ME_OK;
+    {   // the identity moves nothing (Open3D's Transform would multiply by 1 and add 0: bit-identical): keep the index
+        bool identity = true;
+        for (int i = 0; i < 16; ++i) identity = identity && T[i] == ((i % 5 == 0) ? 1.0 : 0.0);
+        if (identity) return ME_OK;
+    }
     Mat4 m;
     std::memcpy(m.m, T, sizeof(m.m));
     hipLaunchKernelGGL(k_transform, dim3(grid_for(c.n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), c.n, m);

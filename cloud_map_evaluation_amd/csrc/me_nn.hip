@@ -750,6 +750,11 @@ k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__rest
         double best = d2_out[i];
         long long best_i = idx_out[i] >= 0 ? (long long) idx_out[i] : 0x7fffffffffffffffLL;
         double bound = best;
+        // per-lane running best over every scan of this query (round 3): the wave-wide (distance, index) butterfly — 24
+        // ds_bpermute round trips — is paid ONCE per query, not once per scanned node; between scans only the pruning bound is
+        // needed, an upper bound of the wave's minimum: the lanes' bests rounded UP to FP32 and min-reduced with DPP moves
+        double lb = best;
+        long long li = best_i;
         unsigned long long taken_lo = 0, taken_hi = 0;  // wave-uniform
         int l = L;
         // children [cb, ce) of a node -> level lev's cache line (lanes 0..7 bound one child each)
@@ -808,8 +813,6 @@ k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__rest
             const unsigned int pb = c_pb[l * 9 + kc], pe = c_pb[l * 9 + kc + 1];
             if (l == 1 || pe - pb <= (unsigned int) far_leaf) {
                 // scan the node's points, 4 x 64 at a time (clamped addresses keep the four loads unconditional)
-                double lb = best;
-                long long li = best_i;
                 for (unsigned int j0 = pb; j0 < pe; j0 += 256u) {
                     SPoint p[4];
 #pragma unroll
@@ -827,18 +830,9 @@ k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__rest
                         }
                     }
                 }
-#pragma unroll
-                for (int m = 1; m < 64; m <<= 1) {
-                    const double od = __shfl_xor(lb, m, 64);
-                    const long long oi = __shfl_xor(li, m, 64);
-                    if (od < lb || (od == lb && oi < li)) {
-                        lb = od;
-                        li = oi;
-                    }
-                }
-                best = lb;
-                best_i = li;
-                bound = fmin(bound, best);
+                // (squared distances are >= 0: their FP32 images order like their bit patterns)
+                const float wmin = __int_as_float(wave_min_i(__float_as_int(__double2float_ru(lb))));
+                bound = fmin(bound, (double) wmin);
             } else {  // [cb, ce) are the chosen child's children, on level l - 2
                 --l;
                 if (l <= 8) taken_lo &= ~(0xffULL << (8 * (l - 1)));
@@ -846,6 +840,17 @@ k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__rest
                 open_node(l, cb, ce);
             }
         }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {  // the query's answer: exact minimum, ties -> smallest reference index
+            const double od = __shfl_xor(lb, m, 64);
+            const long long oi = __shfl_xor(li, m, 64);
+            if (od < lb || (od == lb && oi < li)) {
+                lb = od;
+                li = oi;
+            }
+        }
+        best = lb;
+        best_i = li;
         if (lane == 0) {
             d2_out[i] = best;
             idx_out[i] = (int) best_i;
