@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 TRUNC = (0.2, 0.1, 0.08, 0.05, 0.01)
 RTOL = 1e-9
-SIGMA_TOL = 1e-9  # |dSigma| / max|Sigma| per voxel (measured: see profiles/README.md)
+from tests._tol import SIGMA_TOL  # |dSigma| / max|Sigma| per voxel
 
 
 def _gpu():

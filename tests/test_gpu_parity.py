@@ -193,8 +193,11 @@ def test_voxel_gaussians_parity(eng, campus):
     okeys, on, omu, osig, oent = oracle.VoxelMap(gt, 3.0).export()
     assert np.array_equal(keys, okeys) and np.array_equal(n, on)  # bit-exact voxel populations
     np.testing.assert_allclose(mu, omu, rtol=1e-13)
-    np.testing.assert_allclose(sig, osig, rtol=1e-7, atol=1e-18)
-    np.testing.assert_allclose(ent, oent, rtol=1e-8, atol=1e-10)
+    from tests._tol import assert_sigma_close
+
+    assert_sigma_close(sig, osig)  # 1e-9 of each matrix's scale (two-pass vs the reference's streaming Welford)
+    big = on > 10
+    np.testing.assert_allclose(ent[big], oent[big], rtol=0, atol=1e-8)  # 0.5 ln((2 pi e)^3 det): absolute
 
 
 @pytest.mark.parametrize("vs", [3.0, 0.5])
@@ -210,7 +213,9 @@ def test_awd_cdf_scs_parity(eng, campus, cube, vs):
     assert res["rows"].shape == ores["rows"].shape and len(res["rows"]) > 20
     assert np.array_equal(res["rows"][:, :6], ores["rows"][:, :6])        # same voxels, same order
     assert np.array_equal(res["rows"][:, 10:12], ores["rows"][:, 10:12])  # n_gt, n_est
-    np.testing.assert_allclose(res["rows"], ores["rows"], rtol=1e-6, atol=1e-15)
+    from tests._tol import assert_voxel_rows_close
+
+    assert_voxel_rows_close(res["rows"], ores["rows"], rtol=1e-8)
     np.testing.assert_allclose(res["rows"][:, 9], ores["rows"][:, 9], rtol=1e-8)  # W per voxel
     np.testing.assert_allclose(res["w_sorted"], ores["w_sorted"], rtol=1e-8)
     np.testing.assert_allclose(res["awd"], ores["awd"], rtol=RTOL)

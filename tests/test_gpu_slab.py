@@ -73,7 +73,9 @@ def test_slab_primitives_sum_to_whole():
     wk, wn, wmu, wsig, _ = whole_tab
     assert np.array_equal(keys, wk) and np.array_equal(n, wn)  # same voxels, same populations
     np.testing.assert_allclose(mu, wmu, rtol=1e-13)
-    np.testing.assert_allclose(sig, wsig, rtol=1e-7, atol=1e-18)
+    from tests._tol import assert_sigma_close
+
+    assert_sigma_close(sig, wsig)
 
 
 def _free_port():
