@@ -77,9 +77,24 @@ class RcclComm : public Comm {
         rank = rank_;
         world = world_;
         id_path_ = id_path;
-        if (hipSetDevice(device) != hipSuccess) {
-            err = "hipSetDevice failed";
-            return false;
+        // pre-flight over files, BEFORE the communicator: a rank whose device does not exist (num_gpus larger than the node) would
+        // otherwise leave the others blocked inside ncclCommInitRank
+        int n_dev = 0;
+        const bool dev_ok = hipGetDeviceCount(&n_dev) == hipSuccess && device >= 0 && device < n_dev && hipSetDevice(device) == hipSuccess;
+        const char mark = dev_ok ? '1' : '0';
+        write_file_atomic(id_path + ".ready" + std::to_string(rank), &mark, 1);
+        for (int k = 0; k < world; ++k) {
+            const std::string f = id_path + ".ready" + std::to_string(k);
+            if (!wait_for_file(f, 1, 120.0)) {
+                err = "rank " + std::to_string(k) + " did not start";
+                return false;
+            }
+            char m = '0';
+            std::ifstream(f, std::ios::binary).read(&m, 1);
+            if (m != '1') {
+                err = "rank " + std::to_string(k) + " has no GPU (device " + std::to_string(device - rank + k) + " of " + std::to_string(n_dev) + ")";
+                return false;
+            }
         }
         ncclUniqueId id;
         if (rank == 0) {
@@ -106,7 +121,10 @@ class RcclComm : public Comm {
     ~RcclComm() override {
         if (comm_) ncclCommDestroy(comm_);
         if (stream_) (void) hipStreamDestroy(stream_);
-        if (rank == 0 && !id_path_.empty()) std::remove(id_path_.c_str());
+        if (rank == 0 && !id_path_.empty()) {
+            std::remove(id_path_.c_str());
+            for (int k = 0; k < world; ++k) std::remove((id_path_ + ".ready" + std::to_string(k)).c_str());
+        }
     }
     bool all_reduce_sum_f64(double *dev, size_t n) override {
         return n == 0 || (ck(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, comm_, stream_), "ncclAllReduce(sum, f64)") && sync());

@@ -149,7 +149,7 @@ def test_host_run_with_voxel_downsample(tmp_path):
     np.testing.assert_allclose(res["MME"][0], oracle.mme(e_ds, 0.1, 10)[0], atol=6e-6)
 
 
-def _run_host(tmp_path, name, est, gt, T, num_gpus=1, env=None, downsample=0.0):
+def _run_host(tmp_path, name, est, gt, T, num_gpus=1, env=None, downsample=0.0, expect_failure=False):
     d = tmp_path / name
     d.mkdir()
     est_dir = d / "est"
@@ -161,6 +161,9 @@ def _run_host(tmp_path, name, est, gt, T, num_gpus=1, env=None, downsample=0.0):
     e = dict(os.environ)
     e.update(env or {})
     r = subprocess.run([EXE, str(cfg)], capture_output=True, text=True, timeout=900, env=e)
+    if expect_failure:
+        assert r.returncode != 0, r.stdout[-3000:]
+        return est_dir / "map_results", r.stdout + r.stderr
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return est_dir / "map_results", r.stdout
 
@@ -176,6 +179,21 @@ def _same_outputs(a, b):
         np.testing.assert_allclose(np.loadtxt(a / name), np.loadtxt(b / name), rtol=1e-5, atol=1e-12)
     for name in ("map_entropy.pcd", "gt_entropy.pcd", "raw_rendered_dis_map.pcd", "inlier_rendered_dis_map.pcd"):
         assert open(a / name, "rb").read() == open(b / name, "rb").read(), name  # same points, same colours, byte for byte
+
+
+def test_multi_gpu_host_with_more_ranks_than_gpus_fails_fast(tmp_path):
+    """`num_gpus` larger than the node: every rank stops at the file pre-flight of host/dist_comm.hpp with a message naming
+    the missing device, before any rank enters ncclCommInitRank (where the others would wait for the one that never comes)."""
+    import time
+    import torch
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.cube_pair(5_000, seed=3)
+    world = torch.cuda.device_count() + 1
+    t0 = time.time()
+    _, out = _run_host(tmp_path, "toomany", est.numpy(), gt.numpy(), np.eye(4), num_gpus=world, expect_failure=True)
+    assert "RCCL bootstrap failed" in out and "has no GPU" in out, out[-2000:]
+    assert time.time() - t0 < 60.0
 
 
 @pytest.mark.parametrize("identity", [True, False])
