@@ -293,11 +293,9 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
 
-    if world > 1:
-        # distributed step: the SECOND lane runs the long MME kernels, the main lane the latency-bound cross-rank step; giving the
-        # MME lane the dispatch priority shortens the step (emulated 8-rank step 11.5 -> 11.2 ms, profiles/README.md); one GPU: the
-        # library's default (main lane first)
-        os.environ.setdefault("ME_STREAM_PRIO", "twin")
+    # stream priorities: the library's default (main lane first) at every N — since the distributed step keeps its statistics and
+    # voxel collectives under the other lane's MME kernels, "MME lane first" no longer helps there (10.8 vs 10.8-11.2 ms emulated
+    # at 8 ranks, profiles/README.md)
     eng = Engine(local_rank)
 
     def sync():

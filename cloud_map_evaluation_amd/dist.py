@@ -12,6 +12,9 @@ stage is O(V) and replicated (no exchange).
 """
 from __future__ import annotations
 
+import os
+import threading
+
 import numpy as np
 
 ME_SLOT_EST, ME_SLOT_GT = 0, 1
@@ -297,15 +300,17 @@ def _slab_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
 #                      equal-count cuts (quantiles of the sorted sample), identical on every rank
 #   2. all-to-all      per-destination point counts (est, gt)              -> split sizes of (3)
 #   3. all-to-all      THE HALO EXCHANGE: [est | gt] points per destination (~2 x 24 B x N / world per rank + halo)
-#   4. all-gather      [open 1-NN queries est, gt; local cloud sizes] per rank
-#   5. all-gather + 6. all-reduce MIN   the open queries and their answers (only when some rank has any: outliers,
-#                      points whose ball crosses the slab's outer faces), both directions in one message
+#   4+5. all-gather    ONE fixed-capacity message per rank: [open-query counts est, gt; local cloud sizes] + the open 1-NN queries of
+#                      both directions with the bound to beat (overflow beyond the capacity: a second, exactly sized gather)
+#   6. all-reduce MIN  the answers (only when some rank has open queries: outliers, points whose ball crosses the slab's faces)
 #   7. all-reduce SUM  the 39 partial sums + the per-rank voxel row counts (one-hot);
 #   8. all-reduce SUM  the 2 x 5 sigma numerators (need the global means of (7))
 #   9. all-gather      voxel partial rows of both clouds (one padded message), merged on the device (Chan)
+#  10. all-reduce SUM  the four MME sums (two lanes only; with one lane they ride on (7))
 # Schedule on a rank: the main lane filters + indexes the map and searches map -> ground truth, the second lane does the same
-# for the ground truth and the opposite direction; then the second lane runs both MME passes and the voxel partials (the long,
-# VALU-bound part) WHILE the main lane goes through (4)-(6), whose octree pass and collectives are latency-bound.
+# for the ground truth and the opposite direction, builds the voxel partial rows and then runs both MME passes (the long,
+# VALU-bound part) WHILE the main lane goes through (4)-(9): an octree pass, small reductions and collectives, all latency-bound.
+# The lanes meet for (10) only.
 # ---------------------------------------------------------------------------------------------------------------
 class _Trace:
     """Wall-clock marks between the phases of a distributed step (ME_DIST_TRACE=1 prints them per step: where a rank's time goes
@@ -434,6 +439,22 @@ def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, wor
     split, e.g. a contiguous piece of the file).  Returns the same dict as suite_step on every rank."""
     import torch
 
+    two_lanes = overlap and hasattr(eng, "twin")
+    if two_lanes and est_part.is_cuda and _HP_TORCH_STREAM and not getattr(_tls, "in_hp", False):
+        # the small tensor ops between the engine calls (padding, slicing, the collectives' staging) go to a HIGH-priority
+        # torch stream: on the default stream they queue behind the other lane's MME workgroups (0.2 -> 1.8 ms for the
+        # open-query message at 8 ranks, profiles/README.md)
+        cur = torch.cuda.current_stream(est_part.device)
+        hp = _hp_stream(est_part.device)
+        hp.wait_stream(cur)
+        _tls.in_hp = True
+        try:
+            with torch.cuda.stream(hp):
+                res = suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank, world, evaluate_gt_mme, halo, overlap)
+        finally:
+            _tls.in_hp = False
+        cur.wait_stream(hp)
+        return res
     tr = _Trace()
     halo = max(float(halo), 1.0001 * float(P.nn_radius_))
     T = np.asarray(P.initial_matrix_, dtype=np.float64)
@@ -445,7 +466,7 @@ def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, wor
     tr.mark("halo_exchange")
     n_loc = (int(est_part.shape[0]), int(gt_part.shape[0]))
     eng.set_slab(axis, cuts[rank], cuts[rank + 1], halo)
-    lane = _DistLane(eng, gt_r, P, evaluate_gt_mme) if (overlap and hasattr(eng, "twin")) else None
+    lane = _DistLane(eng, gt_r, P, evaluate_gt_mme) if two_lanes else None
     try:
         _upload_received(eng, ME_SLOT_EST, est_r, P)
         if lane is None:
@@ -461,6 +482,20 @@ def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, wor
         if lane is not None:
             lane.abort()
         raise
+
+
+_HP_TORCH_STREAM = os.environ.get("ME_DIST_HP_STREAM", "1") != "0"
+_tls = threading.local()
+_hp_streams = {}
+
+
+def _hp_stream(device):
+    import torch
+
+    key = (device.type, device.index)
+    if key not in _hp_streams:
+        _hp_streams[key] = torch.cuda.Stream(device=device, priority=-1)
+    return _hp_streams[key]
 
 
 _CROSS_CAP = 4096  # open queries per direction and rank the folded all-gather carries (overflow: exact-size fallback)
@@ -559,14 +594,16 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     tr.mark("cross_rank_nn")
     parts = [eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_) for q, r in dirs]
     tr.mark("nn_sums")
-    # --- the other lane's products: MME sums and the voxel partial rows of the owned points ---
+    # --- everything below that does not need the MME sums runs BEFORE the other lane is joined (round 3): the voxel partial
+    #     rows of the owned points (they need the index only: the other lane builds them before its MME passes), the statistics
+    #     collectives and the voxel gather / merge / AWD are latency-bound host + small-kernel work, and they hide under the
+    #     other lane's MME kernels instead of forming a serial tail after them.  What is left after the join is one 4-double
+    #     all-reduce. ---
     if lane is not None:
-        lane.join()
-        m_e, m_g = lane.m_e, lane.m_g
-        rows = [lane.rows[ME_SLOT_EST], lane.rows[ME_SLOT_GT]]
+        rows = lane.wait_rows()  # built by the other lane before its MME passes
     else:
         rows = [eng.voxel_partial_rows(slot, P.vmd_voxel_size_) for slot in (ME_SLOT_EST, ME_SLOT_GT)]
-    tr.mark("join_lane")
+    tr.mark("voxel_rows")
     # --- collectives 7 + 8: partial sums, then the sigma numerators (second pass of map_eval.cpp:1132-1138); the per-rank
     #     voxel row counts ride on (7) as one-hot entries (exact in fp64), so the gather (9) needs no size exchange ---
     onehot = np.zeros(2 * world)
@@ -581,9 +618,6 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     sig = all_reduce_sum(np.concatenate(sig_local), dist, comm_device)
     s_eg = direction_stats(vec, 0, sig[:5], n_e)
     s_ge = direction_stats(vec, 1, sig[5:], n_g)
-    o = 2 * _DIR
-    mme_est = vec[o] / vec[o + 1] if vec[o + 1] > 0 else 0.0
-    mme_gt = vec[o + 2] / vec[o + 3] if vec[o + 3] > 0 else 0.0
     tr.mark("stats")
     # --- collective 9: voxel partial rows of both clouds in one padded all-gather, merged on the device ---
     if single:
@@ -591,25 +625,36 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     else:
         vmax = [max(int(vrows[:world].max()), 1), max(int(vrows[world:].max()), 1)]
         msg = torch.cat([_pad_rows(rows[0], vmax[0], 16, comm_device), _pad_rows(rows[1], vmax[1], 16, comm_device)])
-        parts = [torch.empty_like(msg) for _ in range(world)]
-        dist.all_gather(parts, msg)
-        allr = torch.stack(parts)
+        gparts = [torch.empty_like(msg) for _ in range(world)]
+        dist.all_gather(gparts, msg)
+        allr = torch.stack(gparts)
         gathered = [allr[:, :vmax[0]].reshape(-1, 16), allr[:, vmax[0]:].reshape(-1, 16)]
     for slot, g in zip((ME_SLOT_EST, ME_SLOT_GT), gathered):
         eng.voxel_merge(slot, P.vmd_voxel_size_, g.contiguous())
     tr.mark("voxel_gather_merge")
     v = eng.calculateVMD(P.vmd_voxel_size_, rows=False)
     tr.mark("awd_scs")
+    # --- the other lane's product: the MME sums (collective 10, two lanes only: with one lane they rode on collective 7) ---
+    o = 2 * _DIR
+    mm = vec[o:o + 4]
+    if lane is not None:
+        lane.join()
+        tr.mark("join_lane")
+        mm = all_reduce_sum(np.array([lane.m_e[0], lane.m_e[1], lane.m_g[0], lane.m_g[1]], dtype=np.float64), dist, comm_device)
+        tr.mark("mme_sums")
+    mme_est = mm[0] / mm[1] if mm[1] > 0 else 0.0
+    mme_gt = mm[2] / mm[3] if mm[3] > 0 else 0.0
     return dict(est_gt=s_eg, gt_est=s_ge, ac=s_eg["rmse"], com=s_eg["fitness"], cd=s_eg["mean_nn"] + s_ge["mean_nn"],
-                mme_est=mme_est, mme_gt=mme_gt, mme_valid=int(vec[o + 1]), awd=v["awd"], scs=v["scs"], n_w=v["n_rows"],
+                mme_est=mme_est, mme_gt=mme_gt, mme_valid=int(mm[1]), awd=v["awd"], scs=v["scs"], n_w=v["n_rows"],
                 n_est=n_e, n_gt=n_g, n_cross_rank_queries=n_cross, slab=slab)
 
 
 class _DistLane:
     """Second lane of the DISTRIBUTED step (a host thread on the engine's twin context).  It uploads (filters + indexes) the
-    ground truth, searches ground truth -> map, then runs BOTH MME passes and builds both voxel partial tables — the long,
-    VALU-bound part — while the main lane searches map -> ground truth and then sits in the cross-rank 1-NN step (collectives
-    and a latency-bound octree pass): the exchange hides under the MME kernels."""
+    ground truth, searches ground truth -> map, builds both voxel partial tables and then runs BOTH MME passes — the long,
+    VALU-bound part — while the main lane searches map -> ground truth and then goes through the cross-rank 1-NN step, the
+    statistics and the voxel merge (collectives, small reductions and a latency-bound octree pass): all of it hides under the
+    MME kernels."""
 
     def __init__(self, eng, gt, P, evaluate_gt_mme):
         import threading
@@ -619,32 +664,45 @@ class _DistLane:
         self.m_e = self.m_g = (0.0, 0)
         self.unres_back = 0
         self.gt_ready, self.est_ready, self.nn_done = threading.Event(), threading.Event(), threading.Event()
+        self.rows_done = threading.Event()
+        # `gt` was produced on the CALLER's current torch stream (the high-priority one of suite_step_dist); the thread has its
+        # own current stream, so it waits for this event before the engine reads the points
+        self._gt_written = None
+        if getattr(gt, "is_cuda", False):
+            import torch
+
+            self._gt_written = torch.cuda.Event()
+            self._gt_written.record(torch.cuda.current_stream(gt.device))
         self._t = threading.Thread(target=self._run, args=(eng.twin(), gt, P, evaluate_gt_mme), daemon=True)
         self._t.start()
 
     def _run(self, lane, gt, P, evaluate_gt_mme):
         try:
+            if self._gt_written is not None:
+                self._gt_written.synchronize()
             _upload_received(lane, ME_SLOT_GT, gt, P)
             self.gt_ready.set()
+            self.rows[ME_SLOT_GT] = lane.voxel_partial_rows(ME_SLOT_GT, P.vmd_voxel_size_)  # needs the index only
             self.est_ready.wait()
             if self.err is not None:
                 return
             lane.nn1(ME_SLOT_GT, ME_SLOT_EST, fetch=False)
             self.unres_back = lane.nn_unresolved_count(ME_SLOT_GT)
             self.nn_done.set()
+            self.rows[ME_SLOT_EST] = lane.voxel_partial_rows(ME_SLOT_EST, P.vmd_voxel_size_)
+            self.rows_done.set()
             if P.evaluate_mme_:
                 m = lane.mme(ME_SLOT_EST, P.nn_radius_, 10, per_point=False)
                 self.m_e = (m[4], m[3])
                 if evaluate_gt_mme:
                     m = lane.mme(ME_SLOT_GT, P.nn_radius_, 5, per_point=False)
                     self.m_g = (m[4], m[3])
-            for slot in (ME_SLOT_EST, ME_SLOT_GT):
-                self.rows[slot] = lane.voxel_partial_rows(slot, P.vmd_voxel_size_)
         except BaseException as e:  # re-raised by the waits
             self.err = e
         finally:
             self.gt_ready.set()
             self.nn_done.set()
+            self.rows_done.set()
 
     def _check(self):
         if self.err is not None:
@@ -657,6 +715,11 @@ class _DistLane:
     def wait_nn(self):
         self.nn_done.wait()
         self._check()
+
+    def wait_rows(self):
+        self.rows_done.wait()
+        self._check()
+        return [self.rows[ME_SLOT_EST], self.rows[ME_SLOT_GT]]
 
     def abort(self):
         self.err = self.err or RuntimeError("main lane failed")

@@ -4,7 +4,7 @@ run one after another with a stand-in process group whose collectives return wha
 delivers the points the other ranks would have sent — precomputed, untimed; all-reduces are identities; all-gathers repeat
 the rank's own message), so a rank's time is the compute + host work it would spend between collectives.  RCCL latency of
 the ~10 small collectives (~0.3-0.5 ms per step) and the halo payload (2 x 24 B x N / world^2 per link: < 0.3 ms at 8 ranks
-over xGMI) are NOT included.  usage: python profiles/emulate_scaling.py [points] [--workload campus|c4_multisession]"""
+over xGMI) are NOT included.  usage: python profiles/emulate_scaling.py [points] [--workload campus|c4_multisession] [--worlds 1,2,4,8]"""
 import json
 import sys
 import time
@@ -50,7 +50,7 @@ class FakeDist:
         pass
 
 
-def main(points, workload):
+def main(points, workload, worlds=(1, 2, 4, 8)):
     dev = torch.device("cuda", 0)
     if workload == "c4_multisession":
         est, gt = synth.multisession_pair(points, 3, density=2500.0, seed=100, device=dev)
@@ -60,7 +60,7 @@ def main(points, workload):
     eng = Engine(0)
     halo = 1.0
     out = {}
-    for world in (1, 2, 4, 8):
+    for world in worlds:
         pieces = [(est[slice(*medist.shard_range(est.shape[0], r, world))], gt[slice(*medist.shard_range(gt.shape[0], r, world))])
                   for r in range(world)]
         per_rank, detail = [], []
@@ -91,9 +91,9 @@ def main(points, workload):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 if world == 1:
-                    medist.suite_step(eng, None, dev, est, gt, P, True, overlap=True)
+                    medist.suite_step(eng, None, dev, est, gt, P, True, overlap=OVERLAP)
                 else:
-                    medist.suite_step_dist(eng, fd, dev, pieces[rank][0], pieces[rank][1], P, rank, world, True, halo=halo, overlap=True)
+                    medist.suite_step_dist(eng, fd, dev, pieces[rank][0], pieces[rank][1], P, rank, world, True, halo=halo, overlap=OVERLAP)
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
             best_t = {k: round(eng.timer(k)[0], 2) for k in ("mme", "nn_grid", "nn1", "sort", "morton", "gather", "cells", "voxel",
@@ -107,13 +107,14 @@ def main(points, workload):
         print(world, out[world], flush=True)
         if world > 1:
             del packs
-    base = out[1]["max_ms"]
+    base = out[1]["max_ms"] if 1 in out else float("nan")
     print(json.dumps({"points": points, "workload": workload, "driver": "suite_step_dist (distributed input, all-to-all halo)",
                       "per_world": out, "speedup_vs_1": {w: base / v["max_ms"] for w, v in out.items()}}))
 
 
 _orig_cuts = medist.dist_slab_cuts
 GLOBAL = {}
+OVERLAP = __import__("os").environ.get("ME_EMU_OVERLAP", "1") != "0"  # 0: one lane (what the phases cost without the other lane)
 
 
 def _patched_cuts(gt_part, d, cd, w, sample=16384):
@@ -129,4 +130,9 @@ if __name__ == "__main__":
     if "--workload" in sys.argv:
         wl = sys.argv[sys.argv.index("--workload") + 1]
         a = [x for x in a if x != wl]
-    main(int(a[0]) if a else 50_000_000, wl)
+    ws = (1, 2, 4, 8)
+    if "--worlds" in sys.argv:
+        w = sys.argv[sys.argv.index("--worlds") + 1]
+        ws = tuple(int(x) for x in w.split(","))
+        a = [x for x in a if x != w]
+    main(int(a[0]) if a else 50_000_000, wl, ws)
