@@ -119,12 +119,16 @@ class RcclComm : public Comm {
         return true;
     }
     ~RcclComm() override {
+        const bool was_up = comm_ != nullptr;
         if (comm_) ncclCommDestroy(comm_);
         if (stream_) (void) hipStreamDestroy(stream_);
-        if (rank == 0 && !id_path_.empty()) {
-            std::remove(id_path_.c_str());
-            for (int k = 0; k < world; ++k) std::remove((id_path_ + ".ready" + std::to_string(k)).c_str());
-        }
+        // only after a successful init (a barrier: every rank has read the files by then); after a failed one the launcher calls
+        // remove_bootstrap_files once its children are gone — a slower rank may still be looking for them
+        if (rank == 0 && was_up && !id_path_.empty()) remove_bootstrap_files(id_path_, world);
+    }
+    static void remove_bootstrap_files(const std::string &id_path, int world) {
+        std::remove(id_path.c_str());
+        for (int k = 0; k < world; ++k) std::remove((id_path + ".ready" + std::to_string(k)).c_str());
     }
     bool all_reduce_sum_f64(double *dev, size_t n) override {
         return n == 0 || (ck(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, comm_, stream_), "ncclAllReduce(sum, f64)") && sync());

@@ -104,6 +104,12 @@ int main(int argc, char **argv) {
             auto c = std::make_unique<medist::RcclComm>();
             if (!c->init(rank, world, param.gpu_device, base + ".id")) {
                 std::cerr << "[ERROR] rank " << rank << ": RCCL bootstrap failed: " << c->err << std::endl;
+                if (rank > 0) _exit(EXIT_FAILURE);
+                for (pid_t pid : children) {  // they fail on the same pre-flight; only then are the bootstrap files removed
+                    int st = 0;
+                    (void) waitpid(pid, &st, 0);
+                }
+                medist::RcclComm::remove_bootstrap_files(base + ".id", world);
                 return EXIT_FAILURE;
             }
             comm = std::move(c);
