@@ -167,6 +167,30 @@ def test_mme_loops(variant, min_k, mode):
     np.testing.assert_allclose(mean, o_mean, rtol=1e-12)
 
 
+@pytest.mark.parametrize("variant,min_k,mode", [(0, 5, 0), (1, 10, 1), (2, 10, 2)])
+def test_mme_on_exactly_degenerate_neighbourhoods(variant, min_k, mode):
+    """Coplanar lattice (z == 0 exactly), collinear points, a pile of duplicates and a tilted plane whose determinant is a rounding
+    residue of either sign: log(det) is -inf, nan or a large negative number and the reference's own gates decide (det > 0 in the
+    serial loop :1510, isfinite in the two normal loops :1583 / :1692).  The restatement has to take the SAME decision per point —
+    this is where an operation-order difference in the covariance or the determinant would show first."""
+    g = np.arange(40) * 0.02
+    plane = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+    plane = np.concatenate([plane, np.zeros((len(plane), 1))], 1)
+    line = np.stack([np.arange(400) * 0.005 + 5.0, np.full(400, 1.0), np.full(400, 2.0)], 1)
+    dup = np.tile(np.array([[9.0, 9.0, 9.0]]), (50, 1))
+    uv = np.random.default_rng(5).uniform(0, 0.8, (3000, 2))
+    tilted = np.stack([uv[:, 0] + 20.0, uv[:, 1] - 3.0, 0.37 * uv[:, 0] - 1.21 * uv[:, 1] + 7.0], 1)  # a plane up to rounding
+    cloud = np.concatenate([plane, line, dup, tilted]).astype(np.float64)
+    mean, ent, valid = ref.mme(variant, cloud, 0.1)
+    o_mean, o_ent, o_valid, o_n, _ = oracle.mme(cloud, 0.1, min_k, mode=mode)
+    assert np.array_equal(valid, o_valid.astype(bool)) and valid.sum() == o_n
+    assert np.array_equal(ent, o_ent)  # bit for bit, including which points stay at 0
+    if o_n:
+        assert mean == o_mean or abs(mean - o_mean) <= 1e-12 * abs(o_mean)
+    # the cases are really in there: some points rejected by the gate although they have enough neighbours
+    assert (~valid[:len(plane)]).any()
+
+
 def test_mme_no_valid_point_returns_zero():
     p = np.random.default_rng(0).uniform(0, 100, (500, 3))
     mean, ent, valid = ref.mme(2, p, 0.1)
