@@ -32,6 +32,10 @@ import os
 import sys
 import time
 
+# HIP runtime setting, before the runtime starts: kernel arguments in device memory.  The step is ~500 launches; this takes
+# 0.2-0.3 ms off it at 1 and at 8 ranks (profiles/README.md, measurement knobs).  An explicit HIP_FORCE_DEV_KERNARG=0 wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
