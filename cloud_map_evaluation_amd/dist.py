@@ -304,13 +304,12 @@ def _slab_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
 #                      both directions with the bound to beat (overflow beyond the capacity: a second, exactly sized gather)
 #   6. all-reduce MIN  the answers (only when some rank has open queries: outliers, points whose ball crosses the slab's faces)
 #   7. all-reduce SUM  the 39 partial sums + the per-rank voxel row counts (one-hot);
-#   8. all-reduce SUM  the 2 x 5 sigma numerators (need the global means of (7))
-#   9. all-gather      voxel partial rows of both clouds (one padded message), merged on the device (Chan)
-#  10. all-reduce SUM  the four MME sums (two lanes only; with one lane they ride on (7))
+#   8. all-gather      voxel partial rows of both clouds (one padded message), merged on the device (Chan)
+#   9. all-reduce SUM  the 2 x 5 sigma numerators (they need the global means of (7)) + the four MME sums of the other lane
 # Schedule on a rank: the main lane filters + indexes the map and searches map -> ground truth, the second lane does the same
 # for the ground truth and the opposite direction, builds the voxel partial rows and then runs both MME passes (the long,
-# VALU-bound part) WHILE the main lane goes through (4)-(9): an octree pass, small reductions and collectives, all latency-bound.
-# The lanes meet for (10) only.
+# VALU-bound part) WHILE the main lane goes through (4)-(8): an octree pass, small reductions and collectives, all latency-bound.
+# The lanes meet for (9) only.
 # ---------------------------------------------------------------------------------------------------------------
 class _Trace:
     """Wall-clock marks between the phases of a distributed step (ME_DIST_TRACE=1 prints them per step: where a rank's time goes
@@ -597,15 +596,15 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     # --- everything below that does not need the MME sums runs BEFORE the other lane is joined (round 3): the voxel partial
     #     rows of the owned points (they need the index only: the other lane builds them before its MME passes), the statistics
     #     collectives and the voxel gather / merge / AWD are latency-bound host + small-kernel work, and they hide under the
-    #     other lane's MME kernels instead of forming a serial tail after them.  What is left after the join is one 4-double
+    #     other lane's MME kernels instead of forming a serial tail after them.  What is left after the join is one 14-double
     #     all-reduce. ---
     if lane is not None:
         rows = lane.wait_rows()  # built by the other lane before its MME passes
     else:
         rows = [eng.voxel_partial_rows(slot, P.vmd_voxel_size_) for slot in (ME_SLOT_EST, ME_SLOT_GT)]
     tr.mark("voxel_rows")
-    # --- collectives 7 + 8: partial sums, then the sigma numerators (second pass of map_eval.cpp:1132-1138); the per-rank
-    #     voxel row counts ride on (7) as one-hot entries (exact in fp64), so the gather (9) needs no size exchange ---
+    # --- collective 7: the partial sums; the per-rank voxel row counts ride on it as one-hot entries (exact in fp64), so the
+    #     gather (8) needs no size exchange ---
     onehot = np.zeros(2 * world)
     onehot[rank], onehot[world + rank] = rows[0].shape[0], rows[1].shape[0]
     vec = all_reduce_sum(np.concatenate([pack_partials(parts, m_e, m_g), onehot]), dist, comm_device)
@@ -615,11 +614,8 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         C = vec[i * _DIR]
         mean = vec[i * _DIR + 6:i * _DIR + 11] / C if C > 0 else np.zeros(5)
         sig_local.append(eng.nn_sigma_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, mean))
-    sig = all_reduce_sum(np.concatenate(sig_local), dist, comm_device)
-    s_eg = direction_stats(vec, 0, sig[:5], n_e)
-    s_ge = direction_stats(vec, 1, sig[5:], n_g)
-    tr.mark("stats")
-    # --- collective 9: voxel partial rows of both clouds in one padded all-gather, merged on the device ---
+    tr.mark("stats")  # the sigma numerators stay local until the last collective
+    # --- collective 8: voxel partial rows of both clouds in one padded all-gather, merged on the device ---
     if single:
         gathered = rows
     else:
@@ -634,14 +630,19 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     tr.mark("voxel_gather_merge")
     v = eng.calculateVMD(P.vmd_voxel_size_, rows=False)
     tr.mark("awd_scs")
-    # --- the other lane's product: the MME sums (collective 10, two lanes only: with one lane they rode on collective 7) ---
+    # --- collective 9, the last one: the 2 x 5 sigma numerators (second pass of map_eval.cpp:1132-1138, they needed the global
+    #     means of (7)) together with the other lane's product, the four MME sums (with one lane those rode on (7)) ---
     o = 2 * _DIR
-    mm = vec[o:o + 4]
+    tail = [np.concatenate(sig_local)]
     if lane is not None:
         lane.join()
         tr.mark("join_lane")
-        mm = all_reduce_sum(np.array([lane.m_e[0], lane.m_e[1], lane.m_g[0], lane.m_g[1]], dtype=np.float64), dist, comm_device)
-        tr.mark("mme_sums")
+        tail.append(np.array([lane.m_e[0], lane.m_e[1], lane.m_g[0], lane.m_g[1]], dtype=np.float64))
+    tail = all_reduce_sum(np.concatenate(tail), dist, comm_device)
+    tr.mark("sigma_mme_sums")
+    s_eg = direction_stats(vec, 0, tail[:5], n_e)
+    s_ge = direction_stats(vec, 1, tail[5:10], n_g)
+    mm = tail[10:14] if lane is not None else vec[o:o + 4]
     mme_est = mm[0] / mm[1] if mm[1] > 0 else 0.0
     mme_gt = mm[2] / mm[3] if mm[3] > 0 else 0.0
     return dict(est_gt=s_eg, gt_est=s_ge, ac=s_eg["rmse"], com=s_eg["fitness"], cd=s_eg["mean_nn"] + s_ge["mean_nn"],
