@@ -393,6 +393,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
         e.n = e.n_total = 0;
         e.slab = ctx->slab;
         e.n_unres = 0;
+        e.slab_identity = true;
         e.uploaded = true;
         e.index_valid = false;
         e.nn_ref_slot = -1;
@@ -420,6 +421,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
     c.have_normals = c.have_cov = false;
     c.slab = ctx->slab;
     c.n_unres = 0;
+    c.slab_identity = true;  // (the filtered slab upload below clears it; a stale `false` would make me_slab_points read an old slab_orig)
     bool bbox_ready = false;
     // prefiltered: slab mode, but the caller guarantees that every point lies inside [reg_lo, reg_hi) (the halo exchange
     // delivered exactly those): the flag / scan / compact filter and its host round trip are skipped

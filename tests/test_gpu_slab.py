@@ -271,3 +271,32 @@ def test_slab_upload_rejects_points_outside_the_declared_region():
         with pytest.raises(MapEvalError, match="outside"):
             eng.upload_slab(0, torch.from_numpy(wider).cuda(), cell_size=0.1)
         eng.set_slab(-1)
+
+
+def test_filtered_upload_then_prefiltered_upload_on_the_same_slot_is_the_identity_again():
+    """ADVICE round 3: the filtered slab upload clears Cloud::slab_identity; a later me_upload_slab_device on the same
+    context and slot must set it back, or me_slab_points answers with the previous upload's (stale, possibly shorter)
+    orig-index table."""
+    import torch
+
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, _ = _scene(40_000)
+    axis = 0
+    lo, hi = np.quantile(est[:, axis], [0.2, 0.5])
+    halo = 0.5
+    with Engine(0) as eng:
+        eng.set_slab(axis, lo, hi, halo)
+        eng.upload(0, est, cell_size=0.1)  # filtered: keeps slab + halo of the whole cloud, orig != identity
+        orig_f, _ = eng.slab_points(0)
+        assert len(orig_f) < len(est) and not np.array_equal(orig_f, np.arange(len(orig_f)))
+        # a LARGER prefiltered piece on the same slot (the stale table would be read out of bounds)
+        lo2, hi2 = np.quantile(est[:, axis], [0.1, 0.9])
+        eng.set_slab(axis, lo2, hi2, halo)
+        inside = est[(est[:, axis] >= lo2 - halo) & (est[:, axis] < hi2 + halo)]
+        assert len(inside) > len(orig_f)
+        eng.upload_slab(0, torch.from_numpy(inside).cuda(), cell_size=0.1)
+        orig_p, owned_p = eng.slab_points(0)
+        assert np.array_equal(orig_p, np.arange(len(inside)))
+        assert np.array_equal(owned_p, (inside[:, axis] >= lo2) & (inside[:, axis] < hi2))
+        eng.set_slab(-1)
