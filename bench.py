@@ -354,7 +354,7 @@ def main():
         suite_step(eng, dist, world, est_d, gt_d, P, evaluate_gt_mme, comm_dev)
         OVERLAP = not args.no_overlap
         fam = {}
-        for name in ("nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "slab_filter", "voxel",
+        for name in ("nn_grid", "nn_grid2", "nn1", "nn_far", "mme", "sort", "morton", "gather", "cells", "nn_stats", "slab_filter", "voxel",
                      "w2", "scs", "halo_pack"):
             ms, cnt = eng.timer(name)
             if cnt:
@@ -398,7 +398,7 @@ def main():
                                 "avg_launch_ms": avg_ms, "units_per_launch": units, "algorithmic_bytes_per_launch": alg_bytes,
                                 "kernel_ms_per_step": {k: v[0] for k, v in fam.items()},
                                 "nn_fallback_fraction": (nn_fallback / nn_total) if nn_total else None,
-                                "queries_per_s": {"nn": (n_e + n_g) * shard / ((fam.get("nn1", (0, 0))[0] + fam.get("nn_grid", (0, 0))[0]) * 1e-3)
+                                "queries_per_s": {"nn": (n_e + n_g) * shard / ((fam.get("nn1", (0, 0))[0] + fam.get("nn_far", (0, 0))[0] + fam.get("nn_grid", (0, 0))[0] + fam.get("nn_grid2", (0, 0))[0]) * 1e-3)
                                                   if ("nn1" in fam or "nn_grid" in fam) else None,
                                                   "mme": (n_e + (n_g if evaluate_gt_mme else 0)) * shard / (fam["mme"][0] * 1e-3)
                                                   if "mme" in fam else None}}

@@ -519,8 +519,9 @@ int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launc
     if (std::strncmp(name, "nn1_", 4) == 0 && std::strlen(name) > 4) {
         // counters of the octree walk since the last reset (collected while timers are on): nodes opened, leaf cells scanned,
         // points scanned, the longest chain (opened + scanned) of one query
-        static const char *names[5] = {"nn1_opened", "nn1_scans", "nn1_points", "nn1_max_opened", "nn1_far"};
-        for (int k = 0; k < 5; ++k)
+        // ... and of k_nn_far: nodes opened, points scanned, the longest chain of one query
+        static const char *names[8] = {"nn1_opened", "nn1_scans", "nn1_points", "nn1_max_opened", "nn1_far", "nn1_far_opened", "nn1_far_points", "nn1_far_max"};
+        for (int k = 0; k < 8; ++k)
             if (std::strcmp(name, names[k]) == 0) {
                 unsigned long long v = 0;
                 if (ctx->nn1_dbg_buf.p) {

@@ -583,6 +583,7 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     c.fine_h = std::ldexp(cell_h, -c.shift);
     c.index_valid = false;
     c.mme_have = false;  // (the sorted order changes)
+    c.mme_feat_valid = false;
     c.nn_ref_slot = -1;
     ctx->cloud[1 - slot].nn_ref_slot = -1;
 

@@ -148,6 +148,13 @@ struct Cloud {
     bool vox_merged = false;  // the table is the cross-rank merge of partials (me_voxel_merge_device): complete on every rank
     DevBuf mme_ent, mme_val;  // last me_mme of this cloud, sorted order: entropy (0 where invalid), validity byte
     bool mme_have = false;
+    // matrix-pipe MME (me_mme7.hip): digit features of the sorted points, per radius-grid cell padded to 16-candidate chunks
+    DevBuf mme_feat;        // [n_chunks][80 columns][16 candidates] signed bytes
+    DevBuf mme_cell_chunk;  // uint32[n_cells + 1] first chunk of every cell
+    bool mme_feat_valid = false, mme_feat_usable = false;
+    double mme_feat_radius = 0;
+    long long mme_fx_origin[3] = {0, 0, 0};
+    int mme_fx_scale = 0;
     DevBuf vox_tmp;    // build scratch (segment starts when they outgrow the shared scratch)
     DevBuf vox_key;    // uint64[V] packed key
     DevBuf vox_n;      // int32[V]
@@ -201,6 +208,7 @@ struct me_ctx {
     std::vector<hipEvent_t> event_pool;
     long long nn_fallback = 0, nn_queries = 0;  // counted only while timers are on
     me::DevBuf nn_far;                           // queries whose octree walk k_nn1 handed over to k_nn_far
+    me::DevBuf nn_flags, nn_list_a;              // 1-NN cascade: unresolved flags of the fine-grid pass, their ordered list
     me::DevBuf nn1_dbg_buf;                      // octree-walk counters (nodes opened, leaves scanned, points, max per query)
     unsigned long long *nn1_dbg() {
         if (!nn1_dbg_buf.p) {
@@ -263,6 +271,7 @@ int sort_pairs_u64_u32(me_ctx *ctx, const unsigned long long *k_in, unsigned lon
 int exclusive_scan_u32(me_ctx *ctx, const unsigned int *in, unsigned int *out, long long n);
 int cell_start_ranks(me_ctx *ctx, const unsigned long long *codes, long long n, int shift3, unsigned int *out);
 int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n);
+int select_flagged_u32(me_ctx *ctx, const unsigned char *flags, long long n, unsigned int *out, unsigned int *count_device);
 
 // ---- me_index.hip ----
 int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, long long n, const double *T,
@@ -290,6 +299,11 @@ int gicp_covariances(me_ctx *ctx, int slot, double epsilon, double *cov_host);
 int get_covariances(me_ctx *ctx, int slot, double *cov_host);
 int rotate_attributes(me_ctx *ctx, int slot, const double *T);
 int icp_lsq_sums(me_ctx *ctx, int qslot, int mode, double max_distance, me_icp_lsq *out);
+
+// ---- me_mme7.hip (round 4's matrix-pipe MME kernel: measurement builds only, -DME_AB) ----
+int mme7_prepare(me_ctx *ctx, Cloud &c, double radius, bool *usable);
+int mme7_launch(me_ctx *ctx, Cloud &c, long long b, long long e, unsigned int nb, double radius, int min_k, double *ent_s,
+                unsigned char *valid_s, double *part_sum, long long *part_cnt);
 
 // ---- me_mme.hip ----
 int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, uint8_t *valid, double *sum_H,
@@ -571,10 +585,13 @@ constexpr int kGroupTab2 = (2 * kGroupR + 5) * (2 * kGroupR + 5) * (2 * kGroupR 
 // `tcell` (optional) receives the box-relative cell coordinates of every table slot, packed x | y << 3 | z << 6.
 // R: Chebyshev radius (in cells) of a group around its leader — kGroupR for the 64-query kernels, 1 for the 16-query
 // passes of the MME kernel (a (2R+1+2H)^3 = 125-entry table).
-template <int H = 1, bool CULL = false, int R = kGroupR>
+// `tabc` / `cell_aux` (optional, both or neither): tabc[slot] = cell_aux[cell index] for every non-empty slot — a second per-cell
+// array looked up with the same probe (the matrix-pipe MME kernel keeps the first feature chunk of every cell there).
+template <int H = 1, bool CULL = false, int R = kGroupR, bool MLP = false>
 __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, int cz, const GridView &g, int cell_lim,
                                                  int lane, int2 *tab, GroupBox &box, int *n_keys_out = nullptr,
-                                                 unsigned int *rows = nullptr, unsigned short *tcell = nullptr) {
+                                                 unsigned int *rows = nullptr, unsigned short *tcell = nullptr,
+                                                 unsigned int *tabc = nullptr, const unsigned int *cell_aux = nullptr) {
     const unsigned long long pm = __ballot(pending);  // caller guarantees pm != 0
 #ifdef ME_LEADER_FIRST
     const int leader = __ffsll((long long) pm) - 1;
@@ -627,10 +644,66 @@ __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, i
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    if (MLP) {
+        // Memory-level parallelism for kernels that run few waves per SIMD: the probes of ALL table slots of a lane are issued
+        // before any is waited for (the plain loop below is four dependent round trips per 64 slots, one batch after the other).
+        constexpr int NIT = ((2 * R + 1 + 2 * H) * (2 * R + 1 + 2 * H) * (2 * R + 1 + 2 * H) + 63) / 64;
+        unsigned long long key[NIT], got[NIT];
+        unsigned int slot[NIT];
+        bool want[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int t = lane + 64 * i;
+            const int tx = t % nx, ty = (t / nx) % ny, tz = t / (nx * ny);
+            const int ix = x0 + tx, iy = y0 + ty, iz = z0 + tz;
+            want[i] = t < n_keys && ix >= 0 && iy >= 0 && iz >= 0 && ix < cell_lim && iy < cell_lim && iz < cell_lim;
+            if (CULL) want[i] = want[i] && ((rows[64 + (t < n_keys ? ty + ny * tz : 0)] >> tx) & 1u);
+            key[i] = spread21((unsigned long long) ix) | (spread21((unsigned long long) iy) << 1) | (spread21((unsigned long long) iz) << 2);
+            slot[i] = (unsigned int) hash_u64(key[i]) & g.hmask;
+            got[i] = kEmptyKey;
+            if (tcell && t < n_keys) tcell[t] = (unsigned short) (tx | (ty << 3) | (tz << 6));
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            if (want[i]) got[i] = g.hkeys[slot[i]];
+        int ci[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            // (collisions: linear probing, rare)
+            while (want[i] && got[i] != key[i] && got[i] != kEmptyKey) {
+                slot[i] = (slot[i] + 1) & g.hmask;
+                got[i] = g.hkeys[slot[i]];
+            }
+            want[i] = want[i] && got[i] == key[i];
+            ci[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            if (want[i]) ci[i] = (int) g.hvals[slot[i]];
+        unsigned int cs0[NIT], cs1[NIT], ax[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            cs0[i] = cs1[i] = ax[i] = 0;
+            if (want[i]) {
+                cs0[i] = g.cell_start[ci[i]];
+                cs1[i] = g.cell_start[ci[i] + 1];
+                if (tabc) ax[i] = cell_aux[ci[i]];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int t = lane + 64 * i;
+            if (t < n_keys) {
+                tab[t] = make_int2((int) cs0[i], (int) (cs1[i] - cs0[i]));
+                if (tabc) tabc[t] = ax[i];
+            }
+        }
+    } else
     for (int t = lane; t < n_keys; t += 64) {
         const int tx = t % nx, ty = (t / nx) % ny, tz = t / (nx * ny);
         const int ix = x0 + tx, iy = y0 + ty, iz = z0 + tz;
         int2 run = make_int2(0, 0);
+        unsigned int aux = 0;
         bool want = ix >= 0 && iy >= 0 && iz >= 0 && ix < cell_lim && iy < cell_lim && iz < cell_lim;
         if (CULL) want = want && ((rows[64 + ty + ny * tz] >> tx) & 1u);
         if (want) {
@@ -640,9 +713,11 @@ __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, i
             if (ci >= 0) {
                 run.x = (int) g.cell_start[ci];
                 run.y = (int) g.cell_start[ci + 1] - run.x;
+                if (tabc) aux = cell_aux[ci];
             }
         }
         tab[t] = run;
+        if (tabc) tabc[t] = aux;
         if (tcell) tcell[t] = (unsigned short) (tx | (ty << 3) | (tz << 6));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

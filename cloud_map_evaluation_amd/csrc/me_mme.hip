@@ -219,11 +219,13 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
 
     __shared__ int2 s_tab[4][kGroupTab + 1];
     __shared__ float4 s_tf[4][TILE];     // FP32 records of the staged run (the cull's row masks while the table is built)
-    __shared__ double s_td[4][3][TILE];  // its fp64 coordinates, one array per axis
+    __shared__ double2 s_txy[4][TILE];   // its fp64 coordinates: (x, y) as one 16-byte record, z apart — two LDS reads per
+    __shared__ double s_tz[4][TILE];     // accepted candidate instead of three (a ds_read_b64 costs a SIMD 8.7 issue cycles)
     const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));  // scalar: the wave's LDS bases stay out of VGPRs
     int2 *tab = s_tab[wv];
     float4 *tf = s_tf[wv];
-    double *tdx = s_td[wv][0], *tdy = s_td[wv][1], *tdz = s_td[wv][2];
+    double2 *txy = s_txy[wv];
+    double *tdz = s_tz[wv];
     const int lane = threadIdx.x & 63;
 
     double det_keep = 0.0;  // determinant of the neighbourhood covariance (valid when have_det)
@@ -263,12 +265,14 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 // (both compares land in scalar register pairs: the band test is scalar work, no VALU instruction)
                 if (__builtin_expect(mh != __ballot(acc), 0)) {  // a lane in the band: its exact test decides
                     asm volatile("; band: exact test" ::: "memory");     // (keeps the compiler from evaluating it always)
-                    const double ex = tdx[j] - qx, ey = tdy[j] - qy, ez = tdz[j] - qz;
+                    const double2 exy = txy[j];
+                    const double ex = exy.x - qx, ey = exy.y - qy, ez = tdz[j] - qz;
                     const double d2 = (ex * ex + ey * ey) + ez * ez;
                     acc = acc || (hi && d2 < r2);                        // strict, nanoflann RadiusResultSet [upstream]
                 }
                 if (acc) {
-                    const double dx = tdx[j] - qx, dy = tdy[j] - qy, dz = tdz[j] - qz;
+                    const double2 pxy = txy[j];
+                    const double dx = pxy.x - qx, dy = pxy.y - qy, dz = tdz[j] - qz;
                     ++k;
                     s1x += dx;
                     s1y += dy;
@@ -295,8 +299,7 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                     // |p'|^2 of the ROUNDED coordinates (the error bound is stated for them), rounded once
                     const double w = ((double) fx * (double) fx + (double) fy * (double) fy) + (double) fz * (double) fz;
                     tf[lane] = make_float4(fx, fy, fz, (float) w);
-                    tdx[lane] = p.x;
-                    tdy[lane] = p.y;
+                    txy[lane] = make_double2(p.x, p.y);
                     tdz[lane] = p.z;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -691,6 +694,11 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     const long long n = c.n;
     long long b, e;
     ctx->shard_range(n, b, e);
+#ifdef ME_AB  // A/B build: ME_MME_V=7 runs round 4's matrix-pipe kernel (me_mme7.hip) where the cloud fits its fixed-point frame
+    bool use7 = false;
+    static const int force_v = std::getenv("ME_MME_V") ? std::atoi(std::getenv("ME_MME_V")) : 3;
+    if (force_v == 7) ME_TRY(mme7_prepare(ctx, c, radius, &use7));
+#endif
     DevBuf &ent_s = c.mme_ent, &val_s = c.mme_val;  // kept for me_render_entropy
     c.mme_have = false;
     ME_CHECK(ctx, ent_s.ensure((size_t) n * 8));
@@ -725,7 +733,9 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     hipLaunchKernelGGL((k_mme6<T, W>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),                                \
                        c.codes.as<unsigned long long>(), b, e, c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(),             \
                        val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), c.cell_h, thr_lo, thr_hi)
-        if (variant == 1) {
+        if (use7) {
+            ME_TRY(mme7_launch(ctx, c, b, e, nb, radius, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc));
+        } else if (variant == 1) {
             hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
                                c.grid, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting());
         } else if (variant == 6) {

@@ -63,18 +63,37 @@ __device__ __forceinline__ double box_upper_bound(const float *__restrict__ b, d
 // tests 4x fewer candidates but is bound by vector-L1 tag lookups (~11 distinct lines per load instruction) and
 // loses; Chebyshev-1 groups serialise a wave into ~5 rounds on a fine grid and lose as well.
 // ------------------------------------------------------------------------------------------------------------
+// FROM_LIST (round 4, the second pass of the cascade): the queries are q_begin + in_list[t], t < *in_count — what the first pass
+// on the fine grid could not settle, in curve order — and `g` is a COARSER level (the radius grid): a query whose neighbour is a few
+// fine cells away (drift, noise: 4.5 % of the queries at 10^4 pts/m^2, where the fine cells are 2.5 cm) is settled here, by the same
+// streamed ranking, instead of walking the octree (29 of 90 ms per step on that scene).  A fixed grid of waves strides over the list
+// (its length stays on the device).  First pass: unresolved queries are FLAGGED (flag_out), a stream compaction builds the ordered list.
+template <bool FROM_LIST>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
           GridView g,
           FrameView fr, SlabView slab, double *__restrict__ d2_out, int *__restrict__ idx_out,
-          unsigned int *__restrict__ list, unsigned int *__restrict__ list_count, unsigned int xcd_chunk) {
+          unsigned int *__restrict__ list, unsigned int *__restrict__ list_count, unsigned int xcd_chunk,
+          const unsigned int *__restrict__ in_list, const unsigned int *__restrict__ in_count, unsigned char *__restrict__ flag_out) {
     const int lane = threadIdx.x & 63;
-    const unsigned int vb = xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);  // gridDim.x is a multiple of 8
-    const long long i = q_begin + (long long) vb * blockDim.x + threadIdx.x;
-    bool active = i < q_end;
+    const unsigned int vb = FROM_LIST ? blockIdx.x : xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);  // gridDim.x is a multiple of 8
     const int cell_bits = kMortonBits - g.shift;
     const int cell_lim = 1 << cell_bits;
     const double cell_h = ldexp(fr.fine_h, g.shift);
+    __shared__ float4 s_tile[4][64];  // (doubles as the row masks of the adjacency cull while a round's table is built)
+    __shared__ int2 s_tab[4][kGroupTab + 1];
+    const long long n_in = FROM_LIST ? (long long) *in_count : 0;
+  for (long long pos = (long long) vb * blockDim.x + threadIdx.x;; pos += (long long) gridDim.x * blockDim.x) {
+    long long i;
+    bool active;
+    if (FROM_LIST) {
+        if (!__ballot(pos < n_in)) break;  // wave-uniform
+        active = pos < n_in;
+        i = q_begin + (active ? (long long) in_list[pos] : 0);
+    } else {
+        i = q_begin + pos;
+        active = i < q_end;
+    }
 
     double qx = 0, qy = 0, qz = 0;
     int mcx = 0, mcy = 0, mcz = 0;  // the query's cell in the REFERENCE cloud's grid
@@ -84,7 +103,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         qx = q.x;
         qy = q.y;
         qz = q.z;
-        if (!slab_owned(slab, qx, qy, qz)) {  // halo point: a reference for others, not a query of this rank
+        if (!FROM_LIST && !slab_owned(slab, qx, qy, qz)) {  // halo point: a reference for others, not a query of this rank
             d2_out[i] = -1.0;                 // skip marker for the statistics kernels
             idx_out[i] = -1;
             active = false;
@@ -141,7 +160,6 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     // version fetched the candidates with scalar loads (s_load, candidate in SGPRs): the scalar cache misses on this
     // stream (rocprofv3 SQC counters: 75 % of the requests), so every group of four paid an L2 round trip that 8 waves
     // per SIMD could not hide (68 % VALU issue).
-    __shared__ float4 s_tile[4][64];  // (doubles as the row masks of the adjacency cull while a round's table is built)
     float4 *tile = s_tile[threadIdx.x >> 6];
     double ox = 0, oy = 0, oz = 0;  // the round's local origin (wave-uniform)
     // A run is padded to a multiple of four with records of rank +inf: no scalar tail loop (with 6-point cells most runs end
@@ -175,7 +193,6 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         }
     };
     // (the candidate set of a round is a superset of the lane's own 3x3x3 block; extra candidates only help)
-    __shared__ int2 s_tab[4][kGroupTab + 1];
     int2 *tab = s_tab[threadIdx.x >> 6];
     while (__ballot(!done)) {
         GroupBox bx;
@@ -235,14 +252,22 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         d2_out[i] = best_x;  // final if resolved, initial bound otherwise
         idx_out[i] = (j1 >= 0) ? (int) best_i : -1;
     }
-    // wave-aggregated append of the unresolved lanes
-    const unsigned long long um = __ballot(unresolved);
-    if (um) {
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(list_count, (unsigned int) __popcll(um));
-        base = (unsigned int) readlane_i((int) base, 0);
-        if (unresolved) list[base + (unsigned int) __popcll(um & ((1ULL << lane) - 1ULL))] = (unsigned int) (i - q_begin);
+    if (!FROM_LIST && flag_out) {
+        // first pass of the cascade: flag the unresolved queries; the ordered list is built by a stream compaction
+        if (i < q_end) flag_out[i - q_begin] = unresolved ? 1 : 0;
+    } else {
+        // wave-aggregated append of the unresolved lanes
+        const unsigned long long um = __ballot(unresolved);
+        if (um) {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(list_count, (unsigned int) __popcll(um));
+            base = (unsigned int) readlane_i((int) base, 0);
+            if (unresolved) list[base + (unsigned int) __popcll(um & ((1ULL << lane) - 1ULL))] = (unsigned int) (i - q_begin);
+        }
     }
+    if (!FROM_LIST) break;
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 #ifdef ME_AB
@@ -347,7 +372,6 @@ k_nn_grid_mfma(const SPoint *__restrict__ qsp, long long q_begin, long long q_en
     // version fetched the candidates with scalar loads (s_load, candidate in SGPRs): the scalar cache misses on this
     // stream (rocprofv3 SQC counters: 75 % of the requests), so every group of four paid an L2 round trip that 8 waves
     // per SIMD could not hide (68 % VALU issue).
-    __shared__ float4 s_tile[4][64];  // (doubles as the row masks of the adjacency cull while a round's table is built)
     float4 *tile = s_tile[threadIdx.x >> 6];
     double ox = 0, oy = 0, oz = 0;  // the round's local origin (wave-uniform)
     // A run is padded to a multiple of four with records of rank +inf: no scalar tail loop (with 6-point cells most runs end
@@ -393,7 +417,6 @@ k_nn_grid_mfma(const SPoint *__restrict__ qsp, long long q_begin, long long q_en
         }
     };
     // (the candidate set of a round is a superset of the lane's own 3x3x3 block; extra candidates only help)
-    __shared__ int2 s_tab[4][kGroupTab + 1];
     int2 *tab = s_tab[threadIdx.x >> 6];
     while (__ballot(!done)) {
         GroupBox bx;
@@ -757,8 +780,11 @@ k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__rest
         long long li = best_i;
         unsigned long long taken_lo = 0, taken_hi = 0;  // wave-uniform
         int l = L;
+        unsigned int st_open = 0, st_scan = 0;  // (profiling counters, `dbg`)
+        unsigned long long st_pts = 0;
         // children [cb, ce) of a node -> level lev's cache line (lanes 0..7 bound one child each)
         auto open_node = [&](int lev, unsigned int cb, unsigned int ce) {
+            ++st_open;
             const int cnt = (int) (ce - cb);
             double ub = INFINITY;
             if (lane < 8) {
@@ -812,6 +838,8 @@ k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__rest
             const unsigned int cb = c_beg[l * 9 + kc], ce = c_beg[l * 9 + kc + 1];
             const unsigned int pb = c_pb[l * 9 + kc], pe = c_pb[l * 9 + kc + 1];
             if (l == 1 || pe - pb <= (unsigned int) far_leaf) {
+                ++st_scan;
+                st_pts += pe - pb;
                 // scan the node's points, 4 x 64 at a time (clamped addresses keep the four loads unconditional)
                 for (unsigned int j0 = pb; j0 < pe; j0 += 256u) {
                     SPoint p[4];
@@ -854,6 +882,11 @@ k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__rest
         if (lane == 0) {
             d2_out[i] = best;
             idx_out[i] = (int) best_i;
+            if (dbg) {  // (me_timer_get "nn1_far_opened" / "nn1_far_points" / "nn1_far_max"; only while timers are on)
+                atomicAdd(&dbg[5], (unsigned long long) st_open);
+                atomicAdd(&dbg[6], st_pts);
+                atomicMax(&dbg[7], (unsigned long long) (st_open + st_scan));
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1109,8 +1142,14 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
     } else if (e > b) {
         const unsigned int nb = (unsigned int) (((e - b + 255) / 256 + 7) / 8 * 8);  // multiple of 8 (XCD chunking)
         ME_CHECK(ctx, q.nn_list.ensure((size_t) (e - b) * 4 + 64));
-        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));  // [0] unresolved-list length, [1] far-list length
+        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));  // [0] unresolved-list length, [1] far-list length, [2] first-pass list
         FrameView fr{r.origin[0], r.origin[1], r.origin[2], r.fine_h};
+        // Cascade: fine grid -> (what it leaves) the radius grid, when that is a coarser level -> (what that leaves) the octree.
+        const bool two_pass = r.grid.cell_start && r.grid.shift > r.nn_grid.shift;
+        ME_CHECK(ctx, ctx->nn_flags.ensure((size_t) (e - b) + 64));
+        ME_CHECK(ctx, ctx->nn_list_a.ensure((size_t) (e - b) * 4 + 64));
+        unsigned int *list_a = two_pass ? ctx->nn_list_a.as<unsigned int>() : q.nn_list.as<unsigned int>();
+        unsigned int *cnt_a = two_pass ? d_cnt + 2 : d_cnt;
         {
             TimerScope ts(ctx, "nn_grid");
 #ifdef ME_AB  // A/B build: ME_NN_GRID_V=2 runs round 3's MFMA ranking, ME_NN_GRID_WAVES its occupancy
@@ -1126,22 +1165,37 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
                                    xcd_chunk_setting());
             else
 #endif
-            hipLaunchKernelGGL(k_nn_grid, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
-                               r.n, r.nn_grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt,
-                               xcd_chunk_setting());
+            {
+                hipLaunchKernelGGL((k_nn_grid<false>), dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
+                                   r.n, r.nn_grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt,
+                                   xcd_chunk_setting(), (const unsigned int *) nullptr, (const unsigned int *) nullptr,
+                                   ctx->nn_flags.as<unsigned char>());
+                ME_TRY(select_flagged_u32(ctx, ctx->nn_flags.as<unsigned char>(), e - b, list_a, cnt_a));
+            }
+        }
+        if (two_pass) {
+            TimerScope ts(ctx, "nn_grid2");
+            hipLaunchKernelGGL((k_nn_grid<true>), dim3(2048), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
+                               r.grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt,
+                               xcd_chunk_setting(), (const unsigned int *) list_a, (const unsigned int *) cnt_a, (unsigned char *) nullptr);
         }
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)
             const unsigned int nbf = (unsigned int) std::min<long long>(2LL * nb, 256 * 32);
             // (the far list can hold every query of the list: sized like it)
             ME_CHECK(ctx, ctx->nn_far.ensure((size_t) (e - b) * 4 + 64));
-            TimerScope ts(ctx, "nn1");
-            hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
-                               r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0,
-                               ctx->timers_on ? ctx->nn1_dbg() : nullptr, ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap());
-            hipLaunchKernelGGL(k_nn_far, dim3(kFarGrid), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, r.sp.as<SPoint>(), r.oct,
-                               q.nn_d2.as<double>(), q.nn_idx.as<int>(), ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn_far_leaf(),
-                               ctx->timers_on ? ctx->nn1_dbg() : nullptr);
+            {
+                TimerScope ts(ctx, "nn1");
+                hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
+                                   r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0,
+                                   ctx->timers_on ? ctx->nn1_dbg() : nullptr, ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap());
+            }
+            {
+                TimerScope ts(ctx, "nn_far");
+                hipLaunchKernelGGL(k_nn_far, dim3(kFarGrid), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, r.sp.as<SPoint>(), r.oct,
+                                   q.nn_d2.as<double>(), q.nn_idx.as<int>(), ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn_far_leaf(),
+                                   ctx->timers_on ? ctx->nn1_dbg() : nullptr);
+            }
         }
         if (ctx->timers_on) {  // fallback share, for the bench report
             unsigned int h = 0;

@@ -54,6 +54,17 @@ int cell_start_ranks(me_ctx *ctx, const unsigned long long *codes, long long n, 
     return ME_OK;
 }
 
+// out[0 .. *count) = the indices i < n with flags[i] != 0, ascending (a stream compaction; the count stays on the device)
+int select_flagged_u32(me_ctx *ctx, const unsigned char *flags, long long n, unsigned int *out, unsigned int *count_device) {
+    if (n <= 0) return ME_OK;
+    auto idx = rocprim::make_counting_iterator<unsigned int>(0u);
+    size_t bytes = 0;
+    ME_CHECK(ctx, rocprim::select(nullptr, bytes, idx, flags, out, count_device, (size_t) n, ctx->stream));
+    ME_CHECK(ctx, ctx->tmp[5].ensure(bytes));
+    ME_CHECK(ctx, rocprim::select(ctx->tmp[5].p, bytes, idx, flags, out, count_device, (size_t) n, ctx->stream));
+    return ME_OK;
+}
+
 int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n) {
     if (n <= 0) return ME_OK;
     size_t bytes = 0;
