@@ -22,6 +22,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "ref_build")
 _SO = os.path.join(_HERE, "_ref", "libmapeval_ref.so")
+_SO_PATCHED = os.path.join(_HERE, "_ref", "libmapeval_ref_patched.so")
 REFERENCE = os.environ.get("MAPEVAL_REFERENCE", "/root/reference/map_eval")
 
 
@@ -39,6 +40,44 @@ def build(force: bool = False) -> str | None:
 
 def available() -> bool:
     return os.path.exists(_SO) or have_sources()
+
+
+def build_patched(force: bool = False) -> str | None:
+    """The reference's own map_eval.cpp with the binding of INTEGRATION.md section B applied at build time
+    (oracle/ref_build/apply_binding.py; needs libmapeval_hip.so): oracle/_ref/libmapeval_ref_patched.so, or None."""
+    if have_sources():
+        subprocess.check_call(["make", "-C", _BUILD, "-s", f"REF={REFERENCE}", "patched"] + (["-B"] if force else []))
+    return _SO_PATCHED if os.path.exists(_SO_PATCHED) else None
+
+
+def patched_available() -> bool:
+    return os.path.exists(_SO_PATCHED) or have_sources()
+
+
+_lib_patched = None
+
+
+def process_patched(cfg: "Config", workdir, gt_path) -> dict:
+    """MapEval::process() of the PATCHED reference (its three hot-path calls go to libmapeval_hip.so) on the same files as
+    process().  rc = -1 when the library reports no GPU: the reference's own error path, no CPU fallback."""
+    global _lib_patched
+    if _lib_patched is None:
+        so = build_patched()
+        if so is None:
+            raise RuntimeError("oracle/_ref/libmapeval_ref_patched.so is missing and /root/reference is not here to build it")
+        L = C.CDLL(so)
+        L.ref_last_error.restype = C.c_char_p
+        L.ref_process.argtypes = [C.POINTER(Config), C.c_char_p, C.c_char_p, C.POINTER(Results), C.POINTER(C.c_int)]
+        _lib_patched = L
+    r = Results()
+    rc = C.c_int(0)
+    wd = str(workdir).rstrip("/") + "/"
+    if _lib_patched.ref_process(C.byref(cfg), wd.encode(), str(gt_path).encode(), C.byref(r), C.byref(rc)) != 0:
+        raise RuntimeError("reference (patched): " + _lib_patched.ref_last_error().decode())
+    out = _results(r)
+    out["rc"] = rc.value
+    out["files"] = _read_outputs(wd) if rc.value == 0 else {}
+    return out
 
 
 class Config(C.Structure):
