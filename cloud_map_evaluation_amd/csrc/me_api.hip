@@ -409,6 +409,17 @@ int me_halo_pack_device(me_ctx *ctx, const double *xyz_device, int64_t n, int ax
     return rc;
 }
 
+int me_halo_pack_tagged_device(me_ctx *ctx, const double *xyz_device, int64_t n, int axis, const double *cuts, int world, double halo,
+                               double *out_device, int64_t *tags_device, int64_t tag_base, int64_t capacity, int64_t *counts) {
+    if (!ctx) return ME_ERR_ARG;
+    long long c[64];
+    if (world < 1 || world > 64 || !counts) return ctx->fail(ME_ERR_ARG, "me_halo_pack_tagged_device: need 1 <= world <= 64 and counts");
+    const int rc = me::halo_pack(ctx, xyz_device, n, axis, cuts, world, halo, out_device, capacity, c,
+                                 reinterpret_cast<long long *>(tags_device), (long long) tag_base);
+    for (int k = 0; k < world; ++k) counts[k] = c[k];
+    return rc;
+}
+
 int me_voxel_partial_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, int64_t capacity, int64_t *n_rows) {
     if (!ctx) return ME_ERR_ARG;
     long long n = 0;

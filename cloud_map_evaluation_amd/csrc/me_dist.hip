@@ -29,7 +29,9 @@ template <bool SCATTER>
 __global__ void __launch_bounds__(256)
 k_halo_split(const double *__restrict__ xyz, long long n, int axis, Cuts cuts, int world, long long n_units,
              unsigned int *__restrict__ unit_counts /* [world][n_units] */, const unsigned int *__restrict__ unit_off,
-             double *__restrict__ out) {
+             double *__restrict__ out, long long *__restrict__ tag_out, long long tag_base) {
+    // tag_out (optional): tag_base + the point's input index travels with it — what the receiving rank needs to say WHICH point
+    // of the whole cloud an entry of its per-point outputs is (the distributed host's map_entropy.pcd / raw_rendered_dis_map.pcd)
     const int lane = threadIdx.x & 63;
     const long long u = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (u >= n_units) return;
@@ -57,6 +59,7 @@ k_halo_split(const double *__restrict__ xyz, long long n, int axis, Cuts cuts, i
                     out[3 * o] = p[0];
                     out[3 * o + 1] = p[1];
                     out[3 * o + 2] = p[2];
+                    if (tag_out) tag_out[o] = tag_base + i;
                 }
             }
             if (lane == k) mine += (unsigned int) __popcll(m);
@@ -85,7 +88,7 @@ k_split_totals(const unsigned int *__restrict__ cnt, long long n_units, unsigned
 }
 
 int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, const double *cuts_host, int world, double halo,
-              double *out_device, long long capacity, long long *counts_host) {
+              double *out_device, long long capacity, long long *counts_host, long long *tags_device, long long tag_base) {
     if ((n > 0 && !xyz_device) || n < 0 || axis < 0 || axis > 2 || !cuts_host || world < 1 || world > kMaxWorld || !(halo >= 0) || !counts_host)
         return ctx->fail(ME_ERR_ARG, "me_halo_pack_device: bad argument (1 <= world <= 64)");
     if (n >= (1LL << 31)) return ctx->fail(ME_ERR_ARG, "me_halo_pack_device: more than 2^31 - 1 points in one call");
@@ -106,7 +109,7 @@ int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, cons
     const dim3 grid((unsigned int) ((n_units + 3) / 4));
     TimerScope ts(ctx, "halo_pack");
     hipLaunchKernelGGL(k_halo_split<false>, grid, dim3(256), 0, ctx->stream, xyz_device, n, axis, c, world, n_units,
-                       cnt.as<unsigned int>(), (const unsigned int *) nullptr, (double *) nullptr);
+                       cnt.as<unsigned int>(), (const unsigned int *) nullptr, (double *) nullptr, (long long *) nullptr, 0LL);
     // the exact 64-bit totals first: 32-bit offsets are only meaningful when the packed total fits them
     ME_CHECK(ctx, ctx->tmp[2].ensure((size_t) world * 8));
     hipLaunchKernelGGL(k_split_totals, dim3((unsigned int) world), dim3(256), 0, ctx->stream, cnt.as<unsigned int>(), n_units,
@@ -137,7 +140,7 @@ int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, cons
     if (!out_device) return ME_OK;  // counts only
     if (capacity < total) return ctx->fail(ME_ERR_CAPACITY, "me_halo_pack_device: capacity too small (counts returned)");
     hipLaunchKernelGGL(k_halo_split<true>, grid, dim3(256), 0, ctx->stream, xyz_device, n, axis, c, world, n_units,
-                       (unsigned int *) nullptr, off.as<unsigned int>(), out_device);
+                       (unsigned int *) nullptr, off.as<unsigned int>(), out_device, tags_device, tag_base);
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
     return ME_OK;

@@ -311,7 +311,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
 
 // ---- me_dist.hip (multi-GPU pieces) ----
 int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, const double *cuts_host, int world, double halo,
-              double *out_device, long long capacity, long long *counts_host);
+              double *out_device, long long capacity, long long *counts_host, long long *tags_device = nullptr, long long tag_base = 0);
 int voxel_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, long long capacity, long long *n_rows);
 int voxel_merge(me_ctx *ctx, int slot, double voxel_size, const double *rows_device, long long m);
 int transform_points_device(me_ctx *ctx, double *xyz_device, long long n, const double *T);

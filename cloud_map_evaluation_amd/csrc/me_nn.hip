@@ -1404,7 +1404,10 @@ int icp_p2p_sums(me_ctx *ctx, int qslot, double max_distance, me_icp_sums *out) 
     if (q.slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_icp_p2p_sums: not available in slab mode");
     Cloud &r = ctx->cloud[q.nn_ref_slot];
     ME_CHECK(ctx, hipSetDevice(ctx->device));
-    const long long n = q.n;
+    // me_set_shard: this rank's share [b, e) of the sorted queries (the one me_nn1 searched); the caller all-reduces the sums
+    long long sb, se;
+    ctx->shard_range(q.n, sb, se);
+    const long long n = se - sb;
     const int nb = (int) std::max<long long>(1, std::min<long long>(1024, (n + 255) / 256));
     const size_t bytes_d = (size_t) (nb + 1) * kIcpD * 8;
     ME_CHECK(ctx, ctx->red.ensure(bytes_d + (size_t) (nb + 1) * 8));
@@ -1413,8 +1416,8 @@ int icp_p2p_sums(me_ctx *ctx, int qslot, double max_distance, me_icp_sums *out) 
     const double cx = r.origin[0], cy = r.origin[1], cz = r.origin[2];
     {
         TimerScope ts(ctx, "icp");
-        hipLaunchKernelGGL(k_icp_p2p, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), q.nn_d2.as<double>(), q.nn_idx.as<int>(),
-                           r.xyz.as<double>(), n, max_distance * max_distance, cx, cy, cz, pd, pc);
+        hipLaunchKernelGGL(k_icp_p2p, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>() + sb, q.nn_d2.as<double>() + sb,
+                           q.nn_idx.as<int>() + sb, r.xyz.as<double>(), n, max_distance * max_distance, cx, cy, cz, pd, pc);
         hipLaunchKernelGGL(k_final_sum_d, dim3(kIcpD), dim3(256), 0, ctx->stream, pd, nb, kIcpD, pd + (size_t) nb * kIcpD);
         hipLaunchKernelGGL(k_final_sum_i, dim3(1), dim3(256), 0, ctx->stream, pc, nb, 1, pc + nb);
     }
@@ -1424,7 +1427,7 @@ int icp_p2p_sums(me_ctx *ctx, int qslot, double max_distance, me_icp_sums *out) 
     ME_CHECK(ctx, hipMemcpyAsync(&hc, pc + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     out->n_corr = hc;
-    out->n_source = n;
+    out->n_source = q.n;  // (the whole source cloud, also under me_set_shard: fitness = all-reduced n_corr / n_source)
     for (int k = 0; k < 3; ++k) {
         out->sum_p[k] = hd[k];
         out->sum_q[k] = hd[3 + k];

@@ -612,7 +612,11 @@ int icp_lsq_sums(me_ctx *ctx, int qslot, int mode, double max_distance, me_icp_l
     if (mode == ME_ICP_GENERALIZED && (!r.have_cov || !q.have_cov))
         return ctx->fail(ME_ERR_STATE, "me_icp_lsq_sums: generalized ICP needs me_gicp_covariances on both clouds");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
-    const long long n = q.n;
+    // me_set_shard: this rank's share [b, e) of the sorted queries (the one me_nn1 searched); the sums are additive, the caller
+    // all-reduces them (host/map_eval_dist.cpp: the multi-GPU registration loop)
+    long long sb, se;
+    ctx->shard_range(q.n, sb, se);
+    const long long n = se - sb;
     const int nb = (int) std::max<long long>(1, std::min<long long>(1024, (n + 255) / 256));
     const size_t bytes_d = (size_t) (nb + 1) * kLsqD * 8;
     ME_CHECK(ctx, ctx->red.ensure(bytes_d + (size_t) (nb + 1) * 8));
@@ -621,12 +625,12 @@ int icp_lsq_sums(me_ctx *ctx, int qslot, int mode, double max_distance, me_icp_l
     {
         TimerScope ts(ctx, "icp");
         if (mode == ME_ICP_POINT_TO_PLANE)
-            hipLaunchKernelGGL(k_lsq_sums<1>, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), q.nn_d2.as<double>(),
-                               q.nn_idx.as<int>(), r.xyz.as<double>(), (const double *) nullptr, r.normals.as<double>(), n,
+            hipLaunchKernelGGL(k_lsq_sums<1>, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>() + sb, q.nn_d2.as<double>() + sb,
+                               q.nn_idx.as<int>() + sb, r.xyz.as<double>(), (const double *) nullptr, r.normals.as<double>(), n,
                                max_distance * max_distance, pd, pc);
         else
-            hipLaunchKernelGGL(k_lsq_sums<2>, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), q.nn_d2.as<double>(),
-                               q.nn_idx.as<int>(), r.xyz.as<double>(), q.cov.as<double>(), r.cov.as<double>(), n,
+            hipLaunchKernelGGL(k_lsq_sums<2>, dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>() + sb, q.nn_d2.as<double>() + sb,
+                               q.nn_idx.as<int>() + sb, r.xyz.as<double>(), q.cov.as<double>(), r.cov.as<double>(), n,
                                max_distance * max_distance, pd, pc);
         hipLaunchKernelGGL(k_lsq_final, dim3(kLsqD + 1), dim3(256), 0, ctx->stream, pd, pc, nb, pd + (size_t) nb * kLsqD, pc + nb);
     }
@@ -637,7 +641,7 @@ int icp_lsq_sums(me_ctx *ctx, int qslot, int mode, double max_distance, me_icp_l
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
     out->n_corr = hc;
-    out->n_source = n;
+    out->n_source = q.n;
     int t = 0;
     for (int a = 0; a < 6; ++a)
         for (int b = a; b < 6; ++b) {

@@ -33,6 +33,12 @@ struct Comm {
     virtual bool all_reduce_sum_u8(uint8_t *dev, size_t n) = 0;
     // recv_dev holds world x bytes, rank k's contribution at offset k * bytes
     virtual bool all_gather(const void *send_dev, void *recv_dev, size_t bytes) = 0;
+    // the halo exchange: send_bytes[k] bytes of send_dev (segments back to back, destination-major) go to rank k, recv_bytes[k]
+    // bytes arrive from rank k (back to back, source-major).  Device buffers; sizes known on both sides (exchanged beforehand).
+    virtual bool all_to_all_v(const void *send_dev, const size_t *send_bytes, void *recv_dev, const size_t *recv_bytes) = 0;
+    // true once any rank has called it with ok = false: the ranks agree on "carry on" before a phase that every rank must enter
+    // (a rank that failed locally says so here instead of leaving the others blocked in the next collective)
+    virtual bool all_ok(bool ok) = 0;
     virtual const char *name() const = 0;
 };
 
@@ -142,10 +148,33 @@ class RcclComm : public Comm {
     bool all_gather(const void *send_dev, void *recv_dev, size_t bytes) override {
         return bytes == 0 || (ck(ncclAllGather(send_dev, recv_dev, bytes, ncclUint8, comm_, stream_), "ncclAllGather") && sync());
     }
+    bool all_to_all_v(const void *send_dev, const size_t *send_bytes, void *recv_dev, const size_t *recv_bytes) override {
+        // one group of point-to-point transfers: xGMI is point-to-point, every pair of ranks uses its own link
+        if (!ck(ncclGroupStart(), "ncclGroupStart")) return false;
+        size_t so = 0, ro = 0;
+        bool ok = true;
+        for (int k = 0; k < world && ok; ++k) {
+            if (send_bytes[k]) ok = ck(ncclSend((const char *) send_dev + so, send_bytes[k], ncclUint8, k, comm_, stream_), "ncclSend");
+            if (ok && recv_bytes[k]) ok = ck(ncclRecv((char *) recv_dev + ro, recv_bytes[k], ncclUint8, k, comm_, stream_), "ncclRecv");
+            so += send_bytes[k];
+            ro += recv_bytes[k];
+        }
+        const bool ended = ck(ncclGroupEnd(), "ncclGroupEnd");
+        return ok && ended && sync();
+    }
+    bool all_ok(bool ok) override {
+        if (!flag_ && hipMalloc((void **) &flag_, 8) != hipSuccess) return false;
+        const double v = ok ? 1.0 : 0.0;
+        if (hipMemcpy(flag_, &v, 8, hipMemcpyHostToDevice) != hipSuccess) return false;
+        if (!all_reduce_min_f64(flag_, 1)) return false;
+        double r = 0;
+        return hipMemcpy(&r, flag_, 8, hipMemcpyDeviceToHost) == hipSuccess && r > 0.5;
+    }
     const char *name() const override { return "rccl"; }
 
   private:
     std::string id_path_;
+    double *flag_ = nullptr;
 };
 
 class FileComm : public Comm {  // tests only: see the header comment
@@ -208,6 +237,57 @@ class FileComm : public Comm {  // tests only: see the header comment
         if (!exchange(h.data(), bytes, all)) return false;
         for (int k = 0; k < world; ++k)
             if (hipMemcpy((char *) recv_dev + (size_t) k * bytes, all[(size_t) k].data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
+        return true;
+    }
+    bool all_to_all_v(const void *send_dev, const size_t *send_bytes, void *recv_dev, const size_t *recv_bytes) override {
+        // every rank publishes [world sizes | its whole send buffer]; a receiver cuts its segment out of every file
+        size_t total = 0;
+        for (int k = 0; k < world; ++k) total += send_bytes[k];
+        std::vector<char> h((size_t) world * 8 + total);
+        for (int k = 0; k < world; ++k) {
+            const unsigned long long b = send_bytes[k];
+            std::memcpy(h.data() + (size_t) k * 8, &b, 8);
+        }
+        if (total && hipMemcpy(h.data() + (size_t) world * 8, send_dev, total, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        const long s = seq_++;
+        if (!write_file_atomic(path(s, rank), h.data(), h.size())) {
+            err = "FileComm: cannot write into " + dir_;
+            return false;
+        }
+        size_t ro = 0;
+        for (int k = 0; k < world; ++k) {
+            if (!wait_for_file(path(s, k), (size_t) world * 8, 300.0)) {
+                err = "FileComm: timed out waiting for rank " + std::to_string(k);
+                return false;
+            }
+            std::ifstream f(path(s, k), std::ios::binary);
+            std::vector<unsigned long long> sz((size_t) world);
+            f.read((char *) sz.data(), (std::streamsize) world * 8);
+            size_t off = (size_t) world * 8;
+            for (int j = 0; j < rank; ++j) off += (size_t) sz[(size_t) j];
+            if ((size_t) sz[(size_t) rank] != recv_bytes[k]) {
+                err = "FileComm: all_to_all_v size mismatch";
+                return false;
+            }
+            if (recv_bytes[k]) {
+                std::vector<char> seg(recv_bytes[k]);
+                f.seekg((std::streamoff) off);
+                f.read(seg.data(), (std::streamsize) recv_bytes[k]);
+                if (!f || hipMemcpy((char *) recv_dev + ro, seg.data(), recv_bytes[k], hipMemcpyHostToDevice) != hipSuccess) return false;
+            }
+            ro += recv_bytes[k];
+        }
+        return true;
+    }
+    bool all_ok(bool ok) override {
+        double v = ok ? 1.0 : 0.0;
+        std::vector<std::vector<char>> all;
+        if (!exchange(&v, 8, all)) return false;
+        for (int k = 0; k < world; ++k) {
+            double r;
+            std::memcpy(&r, all[(size_t) k].data(), 8);
+            if (!(r > 0.5)) return false;
+        }
         return true;
     }
     const char *name() const override { return "file (tests only)"; }

@@ -423,10 +423,16 @@ void matmul4(const double A[16], const double B[16], double C[16]) {
 
 }  // namespace
 
-int MapEval::performRegistration() {
+int MapEval::performRegistration(bool metrics) {
     // RegistrationICP(*map_3d_, *gt_3d_, icp_max_distance_, initial_matrix_, PointToPoint, ICPConvergenceCriteria())
     // (map_eval.cpp:1369-1371): relative_fitness = relative_rmse = 1e-6, max_iteration = 30 [Open3D defaults, upstream]
+    // Multi-GPU (comm_): both clouds are resident on every rank, the correspondence searches are sharded over the ranks
+    // (me_set_shard: rank r searches the r-th share of the curve-sorted map), the step's additive sums are all-reduced, every rank
+    // solves the same small system and moves its copy of the map: the iterates are those of the single-GPU loop up to the order
+    // in which the sums are added.
     TicToc tic_toc;
+    const bool root = param_.dist_rank == 0;
+    if (comm_ && me_set_shard(ctx_, comm_->rank, comm_->world) != ME_OK) return fail(me_last_error(ctx_));
     for (int i = 0; i < 16; ++i) trans[i] = param_.initial_matrix_[i];
     bool identity = true;
     for (int i = 0; i < 16; ++i) identity = identity && (trans[i] == ((i % 5 == 0) ? 1.0 : 0.0));
@@ -452,6 +458,7 @@ int MapEval::performRegistration() {
             s.n_source = q.n_source;
             s.sum_d2 = q.sum_d2;
         }
+        if (comm_ && reduceIcp(s, q, method) != 0) return false;
         fit = s.n_source ? (double) s.n_corr / (double) s.n_source : 0.0;
         rmse = s.n_corr ? std::sqrt(s.sum_d2 / (double) s.n_corr) : 0.0;
         return true;
@@ -472,21 +479,24 @@ int MapEval::performRegistration() {
     }
     t3 = 0;  // no mesh stage
     t4 = tic_toc.toc();
+    if (comm_ && me_set_shard(ctx_, 0, 1) != ME_OK) return fail(me_last_error(ctx_));
     if (me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data()) != ME_OK)  // *map_3d_ = map_3d_->Transform(trans) (:1392)
         return fail(me_last_error(ctx_));
-    std::cout << "INFO: ICP registration time: " << t4 / 1000.0 << " [s]" << std::endl;
-    std::cout << "INFO: Aligned transformation: \n";
-    for (int r = 0; r < 4; ++r)
-        std::cout << trans[4 * r] << " " << trans[4 * r + 1] << " " << trans[4 * r + 2] << " " << trans[4 * r + 3] << std::endl;
-    std::cout << "INFO: ICP overlap ratio: " << fit << std::endl;
-    std::cout << "INFO: ICP correspondences RMSE: " << rmse << std::endl;
-    std::cout << "INFO: ICP correspondences size: " << s.n_corr << std::endl;
+    if (root) {
+        std::cout << "INFO: ICP registration time: " << t4 / 1000.0 << " [s]" << std::endl;
+        std::cout << "INFO: Aligned transformation: \n";
+        for (int r = 0; r < 4; ++r)
+            std::cout << trans[4 * r] << " " << trans[4 * r + 1] << " " << trans[4 * r + 2] << " " << trans[4 * r + 3] << std::endl;
+        std::cout << "INFO: ICP overlap ratio: " << fit << std::endl;
+        std::cout << "INFO: ICP correspondences RMSE: " << rmse << std::endl;
+        std::cout << "INFO: ICP correspondences size: " << s.n_corr << std::endl;
+    }
     // "Aligned cloud:" / "Aligned results:" lines (map_eval.cpp:223-225)
     // (`file_result << matrix`: Eigen's default IOFormat pads every coefficient to the width of the widest one of the WHOLE
     //  matrix, one space between columns, one row per line)
     file_result << std::fixed << std::setprecision(5) << "Aligned cloud: " << eigen_matrix4(trans.data(), 5) << std::endl;
     file_result << std::fixed << std::setprecision(5) << "Aligned results: " << fit << " " << s.n_corr << std::endl;
-    calculateMetrics();
+    if (metrics) calculateMetrics();
     t5 = tic_toc.toc();
     return last_error.empty() ? 0 : -1;
 }
@@ -507,14 +517,22 @@ void MapEval::calculateMetrics() {
         fail(me_last_error(ctx_));
         return;
     }
+    finishRegistrationMetrics(eg, ge, t_acc);
+    t_fcd += tt.toc() / 1000.0 - t_acc;
+}
+
+// the tail of calculateMetrics (map_eval.cpp:1171-1201): result vectors, cd_vec, the full Chamfer distance
+void MapEval::finishRegistrationMetrics(const me_nn_stats_out &eg, const me_nn_stats_out &ge, double t_acc_s) {
+    t_acc = t_acc_s;
     push_results(est_gt_results, eg);
     push_results(gt_est_results, ge);
     for (int i = 0; i < 5; ++i) cd_vec[i] = est_gt_results[1][i] + gt_est_results[1][i];  // (:1171)
-    std::cout << "INFO: RMSE/AC: " << eigen_row(est_gt_results[1], 6) << std::endl;
-    std::cout << "INFO: Fitness/Overlap: " << eigen_row(est_gt_results[2], 6) << std::endl;
     TicToc t1_;
     full_chamfer_dist = eg.mean_nn_dist + ge.mean_nn_dist;  // computeChamferDistance (:1194, :1429): same two searches
-    t_fcd = t1_.toc() / 1000.0 + (tt.toc() / 1000.0 - t_acc);
+    t_fcd = t1_.toc() / 1000.0;
+    if (param_.dist_rank > 0) return;
+    std::cout << "INFO: RMSE/AC: " << eigen_row(est_gt_results[1], 6) << std::endl;
+    std::cout << "INFO: Fitness/Overlap: " << eigen_row(est_gt_results[2], 6) << std::endl;
     std::cout << "INFO: Full Chamfer distance: " << full_chamfer_dist << std::endl;
 }
 

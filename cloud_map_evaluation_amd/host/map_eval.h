@@ -10,10 +10,7 @@
 #include <vector>
 
 #include "../../include/mapeval_hip.h"
-
-namespace medist {
-struct Comm;
-}
+#include "dist_comm.hpp"  // medist::Comm, medist::DevMem (multi-GPU: num_gpus > 1)
 
 using Vector5d = std::array<double, 5>;
 
@@ -69,7 +66,10 @@ public:
     void computeMME(PointCloud &cloud, PointCloud &gt);    // map_eval.cpp:149-189
     void calculateMetricsWithInitialMatrix();              // map_eval.cpp:1204-1260
     void finishInitialMatrixMetrics(const me_nn_stats_out &eg, const me_nn_stats_out &ge, double t_acc_s);  // its tail (:1238-1259)
-    int performRegistration();                             // map_eval.cpp:191-237 (point-to-point ICP only)
+    // map_eval.cpp:191-237, registration_methods 0 / 1 / 2; with a communicator: queries sharded, sums all-reduced (map_eval_dist.cpp);
+    // metrics = false: stop after the loop (the distributed host computes the ICP-path statistics on its slabs)
+    int performRegistration(bool metrics = true);
+    void finishRegistrationMetrics(const me_nn_stats_out &eg, const me_nn_stats_out &ge, double t_acc_s);  // calculateMetrics' tail
     void calculateMetrics();                               // map_eval.cpp:1147-1202
     double computeChamferDistance();                       // map_eval.cpp:1398-1431
     void calculateVMD(bool tables_ready = false, bool write_files = true);  // map_eval.cpp:240-390
@@ -99,8 +99,12 @@ public:
 private:
     int fail(const std::string &msg);
     int allReduceHost(std::vector<double> &v, bool min_op);
-    int gatherPerPoint(int slot, size_t n_global, const std::vector<double> *vals, const std::vector<uint8_t> *flags,
-                       std::vector<double> *vals_out, std::vector<uint8_t> *flags_out);
+    int gatherPerPoint(int slot, size_t n_global, const std::vector<int64_t> &tags, const std::vector<double> *vals,
+                       const std::vector<uint8_t> *flags, std::vector<double> *vals_out, std::vector<uint8_t> *flags_out);
+    int exchangeCloud(const std::vector<double> &pts, size_t i0, size_t i1, const double *T, int axis, const std::vector<double> &cuts,
+                      double halo, medist::DevMem &recv, std::vector<int64_t> &tags_out, int64_t *n_recv);
+    int reduceIcp(me_icp_sums &s, me_icp_lsq &q, int method);  // all-reduce of the registration step's additive sums
+    medist::DevMem pool_[7];  // device buffers of the collectives, kept for the run
     medist::Comm *comm_ = nullptr;
     bool dist_forced_ = false;
     me_ctx *render_ctx_ = nullptr;  // rank 0 of a multi-GPU run: the whole clouds, for the colour renderers

@@ -11,9 +11,12 @@
 // MAPEVAL_COMM=file + MAPEVAL_SINGLE_DEVICE=1 run N ranks on one GPU with file-based collectives (RCCL refuses two ranks on a
 // device).
 #include <sys/wait.h>
+#include <signal.h>
+#include <sys/prctl.h>
 #include <unistd.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <filesystem>
 #include <iomanip>
 #include <iostream>
@@ -22,6 +25,27 @@
 #include "dist_comm.hpp"
 #include "map_eval.h"
 #include "pcd_io.hpp"
+
+namespace {
+std::vector<pid_t> g_children;  // launcher only
+// SIGCHLD in the launcher: a child that ended badly ends the job (async-signal-safe calls only)
+void on_child_exit(int) {
+    int st = 0;
+    pid_t pid;
+    while ((pid = waitpid(-1, &st, WNOHANG)) > 0) {
+        const bool bad = !(WIFEXITED(st) && WEXITSTATUS(st) == 0);
+        for (pid_t &c : g_children)
+            if (c == pid) c = -1;  // reaped
+        if (bad) {
+            for (pid_t c : g_children)
+                if (c > 0) kill(c, SIGKILL);
+            static const char msg[] = "\n[ERROR] a rank of the multi-GPU run failed: stopping the others\n";
+            (void) !write(2, msg, sizeof msg - 1);
+            _exit(EXIT_FAILURE);
+        }
+    }
+}
+}  // namespace
 
 int main(int argc, char **argv) {
     // HIP runtime setting, before its first call: kernel arguments in device memory (a step is several hundred launches; 0.2-0.3 ms
@@ -80,14 +104,28 @@ int main(int argc, char **argv) {
             const pid_t pid = fork();
             if (pid < 0) {
                 std::cerr << "[ERROR] fork failed" << std::endl;
+                for (pid_t c : children) kill(c, SIGKILL);
                 return EXIT_FAILURE;
             }
             if (pid == 0) {
                 rank = r;
                 children.clear();
+                // a rank never outlives the launcher (rank 0): no orphan is left spinning in a collective
+                prctl(PR_SET_PDEATHSIG, SIGKILL);
+                if (getppid() != (pid_t) launcher_pid) _exit(EXIT_FAILURE);
                 break;
             }
             children.push_back(pid);
+        }
+        if (rank == 0) {
+            // ... and the launcher does not outlive a failed rank: RCCL collectives have no timeout, so a rank that exits with an
+            // error (GPU fault, out of memory, a failed library call) takes the whole job down instead of hanging it
+            g_children = children;
+            struct sigaction sa;
+            std::memset(&sa, 0, sizeof sa);
+            sa.sa_handler = on_child_exit;
+            sa.sa_flags = SA_NOCLDSTOP;
+            sigaction(SIGCHLD, &sa, nullptr);
         }
     }
     const bool single_device = std::getenv("MAPEVAL_SINGLE_DEVICE") && std::string(std::getenv("MAPEVAL_SINGLE_DEVICE")) == "1";
@@ -108,6 +146,7 @@ int main(int argc, char **argv) {
             if (!c->init(rank, world, param.gpu_device, base + ".id")) {
                 std::cerr << "[ERROR] rank " << rank << ": RCCL bootstrap failed: " << c->err << std::endl;
                 if (rank > 0) _exit(EXIT_FAILURE);
+                signal(SIGCHLD, SIG_DFL);
                 for (pid_t pid : children) {  // they fail on the same pre-flight; only then are the bootstrap files removed
                     int st = 0;
                     (void) waitpid(pid, &st, 0);
@@ -127,11 +166,24 @@ int main(int argc, char **argv) {
         if (comm) map_eval.setComm(comm.get(), forced);
         rc = map_eval.process();
     }
+    if (rc != 0 && world > 1) {
+        // a failed rank leaves at once (no communicator tear-down: its peers may be inside a collective it will never join)
+        if (rank > 0) _exit(EXIT_FAILURE);
+        signal(SIGCHLD, SIG_DFL);
+        for (pid_t c : g_children)
+            if (c > 0) kill(c, SIGKILL);
+        std::cerr << "[ERROR] rank 0 failed: the other ranks were stopped" << std::endl;
+        _exit(EXIT_FAILURE);
+    }
     comm.reset();
     if (rank > 0) _exit(rc == 0 ? EXIT_SUCCESS : EXIT_FAILURE);
-    for (pid_t pid : children) {
-        int st = 0;
-        if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : -1;
+    if (world > 1) {  // the children still running are reaped here; the SIGCHLD handler has taken the others (and checked them)
+        signal(SIGCHLD, SIG_DFL);
+        for (pid_t pid : g_children) {
+            if (pid <= 0) continue;
+            int st = 0;
+            if (waitpid(pid, &st, 0) > 0 && !(WIFEXITED(st) && WEXITSTATUS(st) == 0)) rc = rc ? rc : -1;
+        }
     }
     if (world > 1 && std::getenv("MAPEVAL_COMM") && std::string(std::getenv("MAPEVAL_COMM")) == "file") {
         std::error_code ec;

@@ -158,6 +158,11 @@ int me_transform_points_device(me_ctx *ctx, double *xyz_device, int64_t n, const
 int me_upload_slab_device(me_ctx *ctx, int slot, const double *xyz_device, int64_t n, double cell_size);
 int me_halo_pack_device(me_ctx *ctx, const double *xyz_device, int64_t n, int axis, const double *cuts, int world, double halo,
                         double *out_device, int64_t capacity, int64_t *counts);
+/* me_halo_pack_device that also packs, in the same order, tag_base + the input index of every copied point into tags_device
+ * (capacity entries; may be NULL): the receiver of the exchange then knows which point of the WHOLE cloud an entry of its slab is
+ * (the C++ host's per-point outputs: map_entropy.pcd, raw_rendered_dis_map.pcd, map_eval.cpp:485-495, 686-736). */
+int me_halo_pack_tagged_device(me_ctx *ctx, const double *xyz_device, int64_t n, int axis, const double *cuts, int world, double halo,
+                               double *out_device, int64_t *tags_device, int64_t tag_base, int64_t capacity, int64_t *counts);
 int me_voxel_partial_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, int64_t capacity, int64_t *n_rows);
 int me_voxel_merge_device(me_ctx *ctx, int slot, double voxel_size, const double *rows_device, int64_t n_rows);
 

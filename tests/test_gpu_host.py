@@ -278,3 +278,71 @@ def test_host_map_results_against_the_references_own_process(tmp_path):
     np.testing.assert_allclose(h["Comp"], g["Comp"], rtol=0, atol=2e-15)
     assert h["VMD"] == g["VMD"] and h["SCS"] == g["SCS"] and h["MME"][:2] == g["MME"][:2]  # 5 decimals, same digits
     assert g["FULL CD"] == [0.0] and h["FULL CD"][0] > 0  # documented deviation 2: the reference prints 0.00000
+
+
+@pytest.mark.parametrize("method", [2, 0])
+def test_multi_gpu_host_runs_the_registration_path_of_the_shipped_configs(tmp_path, method):
+    """Every shipped config asks for `evaluate_using_initial: false`, `registration_methods: 2` (config.yaml:2,53): with
+    `num_gpus: N` the registration loop of map_eval.cpp:191-237, :1366-1394 runs with the correspondence searches sharded over the
+    ranks and the step's sums all-reduced (host/map_eval_dist.cpp::reduceIcp), then the ICP path's statistics (gate d2 < max^2,
+    :1168) on the slabs.  Two ranks on this GPU over the file transport against the single-GPU run of the same binary: same
+    iterates (transform to 1e-9), inlier counts exact, metric lines to their printed digits."""
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.campus_pair(120_000, density=2500.0, seed=8, origin=(40.0, -20.0, 2.0))
+    est, gt = est.numpy(), gt.numpy()
+    ang = 0.004
+    R = np.array([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]])
+    est = (est - est.mean(0)) @ R.T + est.mean(0) + np.array([0.03, -0.02, 0.01])  # a small misalignment for ICP to undo
+
+    def run(name, num_gpus, env=None):
+        d = tmp_path / name
+        d.mkdir()
+        ed = d / "est"
+        ed.mkdir()
+        _write_pcd(ed / "map.pcd", est)
+        _write_pcd(d / "gt.pcd", gt)
+        cfg = d / "config.yaml"
+        txt = _cfg(ed, d / "gt.pcd", np.eye(4)).replace("registration_methods: 2", f"registration_methods: {method}")
+        txt = txt.replace("evaluate_using_initial: true", "evaluate_using_initial: false")
+        cfg.write_text(txt + (f"num_gpus: {num_gpus}\n" if num_gpus != 1 else ""))
+        e = dict(os.environ)
+        e.update(env or {})
+        r = subprocess.run([EXE, str(cfg)], capture_output=True, text=True, timeout=900, env=e)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return ed / "map_results", r.stdout
+
+    single, out1 = run("single", 1)
+    multi, out2 = run("w2", 2, env={"MAPEVAL_COMM": "file", "MAPEVAL_SINGLE_DEVICE": "1"})
+    assert "multi-GPU run: 2 rank(s) over file" in out2
+
+    def aligned(out):
+        m = re.search(r"Aligned transformation: \n((?:.*\n){4})", out)
+        return np.array([[float(v) for v in ln.split()] for ln in m.group(1).strip().splitlines()])
+
+    T1, T2 = aligned(out1), aligned(out2)
+    assert np.abs(T1 - np.eye(4)).max() > 1e-3  # ICP moved the map
+    np.testing.assert_allclose(T2, T1, atol=1e-6)  # (printed with 6 significant digits)
+    a, ta = _parse_results(single / "map_results.txt")
+    b, tb = _parse_results(multi / "map_results.txt")
+    assert a["counts"] == b["counts"] and a["Comp"] == b["Comp"]  # inlier counts: exact
+    np.testing.assert_allclose(a["RMSE/AC"], b["RMSE/AC"], rtol=1e-9)
+    for k in ("FULL CD", "VMD", "SCS", "MME"):
+        np.testing.assert_allclose(a[k][:2], b[k][:2], atol=2e-5)
+    assert re.search(r"^Aligned results: ", ta, flags=re.M) and re.search(r"^Aligned results: (.*)$", ta, flags=re.M).group(1) == \
+        re.search(r"^Aligned results: (.*)$", tb, flags=re.M).group(1)  # fitness and correspondence count of the last iteration
+
+
+def test_multi_gpu_host_a_failing_rank_stops_the_job(tmp_path):
+    """a rank that fails must not leave its peers blocked in a collective.  Rank 1 is made to fail after the
+    ranks have met (MAPEVAL_TEST_FAIL_RANK: its process() returns an error before the exchange); the launcher reports it and the
+    whole job ends with a non-zero status within seconds."""
+    import time
+    from cloud_map_evaluation_amd import synth
+
+    est, gt = synth.cube_pair(20_000, seed=3)
+    t0 = time.time()
+    _, out = _run_host(tmp_path, "fail", est.numpy(), gt.numpy(), np.eye(4), num_gpus=2,
+                       env={"MAPEVAL_COMM": "file", "MAPEVAL_SINGLE_DEVICE": "1", "MAPEVAL_TEST_FAIL_RANK": "1"}, expect_failure=True)
+    assert time.time() - t0 < 120.0
+    assert "failed" in out
