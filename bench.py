@@ -10,6 +10,7 @@ pinned host buffers (PCIe included) are reported next to it as `h2d_inclusive` â
 
 Workloads (--workload; all synthetic, seeded, equal-size clouds):
   c4_multisession (default)  50 M vs 50 M, est = union of three independent scans with their own drifts     (configs[3])
+  c4_dense                   the same pair sampled at the reference's default density (downsample_size 0.01 -> 10^4 pts/m^2)
   campus                     50 M vs 50 M, est = one independent scan (drift + noise + outliers + thinning)
   c3_20m                     20 M vs 20 M, full suite                                                          (configs[2])
   c5_tunnel                  100 M-point ground truth: tunnel + flat field + staircase, vmd_voxel_size 2.0     (configs[4])
@@ -49,6 +50,9 @@ OVERLAP = True  # --no-overlap switches the second lane off (the per-kernel timi
 WORKLOADS = {
     "c4_multisession": dict(points=50_000_000, density=2500.0, radius=0.1, voxel=3.0,
                             what="multisession_pair: GT campus scene, est = union of 3 independent scans with their own drifts"),
+    "c4_dense": dict(points=50_000_000, density=10_000.0, radius=0.1, voxel=3.0,
+                     what="multisession_pair at the reference's default density: downsample_size 0.01 (config.yaml:66) = 10^4 pts/m^2 of "
+                          "surface, k ~ 300 neighbours inside nn_radius 0.1"),
     "campus": dict(points=50_000_000, density=2500.0, radius=0.1, voxel=3.0,
                    what="scan_pair: GT campus scene, est = one independent scan (drift, noise, outliers, thinning)"),
     "c3_20m": dict(points=20_000_000, density=2500.0, radius=0.1, voxel=3.0, what="scan_pair at 20 M"),
@@ -88,7 +92,7 @@ def parse():
 def make_pair(args, device):
     from cloud_map_evaluation_amd import synth
 
-    if args.workload == "c4_multisession":
+    if args.workload in ("c4_multisession", "c4_dense"):
         return synth.multisession_pair(args.points, 3, density=args.density, seed=100, device=device)
     if args.workload == "c5_tunnel":
         return synth.tunnel_pair(args.points, density=args.density, seed=300, device=device, equal_sizes=True)
@@ -300,7 +304,8 @@ def main():
     # stream priorities: the library's default (main lane first) at every N â€” since the distributed step keeps its statistics and
     # voxel collectives under the other lane's MME kernels, "MME lane first" no longer helps there (10.8 vs 10.8-11.2 ms emulated
     # at 8 ranks, profiles/README.md)
-    eng = Engine(local_rank)
+    # (the clouds stay resident and unchanged for the whole run: the engine reads them where they lie â€” ME_FLAG_BORROW_DEVICE_INPUT)
+    eng = Engine(local_rank, borrow_device_input=True)
 
     def sync():
         torch.cuda.synchronize()

@@ -63,7 +63,6 @@ static int stream_priority_for(const char *lane) {
 }
 
 me_ctx *me_create(int device, int flags) {
-    (void) flags;
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -82,6 +81,7 @@ me_ctx *me_create(int device, int flags) {
     }
     me_ctx *ctx = new me_ctx();
     ctx->device = device;
+    ctx->borrow_device_input = (flags & ME_FLAG_BORROW_DEVICE_INPUT) != 0;
     // The primary context's stream gets the highest dispatch priority, a twin's the lowest: when both lanes have kernels
     // queued, the main lane's (MME, 1-NN: the step's critical path) are dispatched first and the second lane's index / voxel
     // kernels fill in — 54.9 -> 53.4 ms per bench step (round 3, three runs each).  ME_STREAM_PRIO=none|twin: measurement knob.
@@ -109,6 +109,7 @@ me_ctx *me_twin(me_ctx *ctx) {
     t->cloud.p[1] = ctx->cloud.p[1];
     t->shard_rank = ctx->shard_rank;
     t->shard_world = ctx->shard_world;
+    t->borrow_device_input = ctx->borrow_device_input;
     t->slab = ctx->slab;
     if (hipStreamCreateWithPriority(&t->stream, hipStreamNonBlocking, stream_priority_for("twin")) != hipSuccess) {
         delete t;

@@ -288,6 +288,85 @@ __global__ void k_oct_up(ONode *__restrict__ child, long long n_child, const uns
     parent_pbegin[p] = child_pbegin[b];
 }
 
+// The TOP of the octree in one launch (round 4): every level above `l0` has at most kOctTopMax nodes; one 1024-thread block builds
+// them all, level after level — what took a scan, k_cell_scatter and k_oct_up launch PER LEVEL (about ten levels of a few thousand
+// nodes down to one: ~40 launch-sized kernels per cloud, nothing else).  Same node records as k_oct_up writes.
+constexpr int kOctTopMax = 16384;
+__global__ void __launch_bounds__(1024)
+k_oct_top(ONode *__restrict__ nodes, unsigned int *__restrict__ pbeg, OctView v, int l0, const unsigned long long *__restrict__ codes0,
+          unsigned long long *__restrict__ ca, unsigned long long *__restrict__ cb, unsigned int *__restrict__ begin) {
+    __shared__ unsigned int s_cnt[16];
+    const int t = threadIdx.x;
+    const unsigned long long *cur = codes0;
+    for (int l = l0; l + 1 < v.n_levels; ++l) {
+        const long long nc = v.count[l], np = v.count[l + 1];
+        unsigned long long *nxt = ((l - l0) & 1) ? cb : ca;
+        ONode *child = nodes + v.off[l], *parent = nodes + v.off[l + 1];
+        const unsigned int *cpb = pbeg + v.off[l];
+        unsigned int *ppb = pbeg + v.off[l + 1];
+        // parents start where the 3-bit-shorter prefix changes: rank the flags in order (ballot inside a wave, 16 wave totals
+        // through LDS), 1024 children per sweep, coalesced
+        unsigned int running = 0;
+        for (long long base = 0; base < nc; base += 1024) {
+            const long long i = base + t;
+            const bool flag = i < nc && (i == 0 || (cur[i] >> 3) != (cur[i - 1] >> 3));
+            const unsigned long long m = __ballot(flag);
+            const int lane = t & 63, wv = t >> 6;
+            if (lane == 0) s_cnt[wv] = (unsigned int) __popcll(m);
+            __syncthreads();
+            unsigned int before = 0, total = 0;
+            for (int w = 0; w < 16; ++w) {
+                const unsigned int c = s_cnt[w];
+                if (w < wv) before += c;
+                total += c;
+            }
+            if (flag) {
+                const unsigned int pos = running + before + (unsigned int) __popcll(m & ((1ULL << lane) - 1ULL));
+                nxt[pos] = cur[i] >> 3;
+                begin[pos] = (unsigned int) i;
+            }
+            running += total;
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+        // parent records (k_oct_up)
+        for (long long p = t; p <= np; p += 1024) {
+            ONode nd;
+            if (p == np) {
+                for (int d = 0; d < 3; ++d) nd.lo[d] = nd.hi[d] = 0.0f;
+                nd.begin = (unsigned int) nc;
+                nd.parent = 0;
+                parent[p] = nd;
+                ppb[p] = cpb[nc];
+                continue;
+            }
+            const long long b = begin[p], e = (p + 1 < np) ? (long long) begin[p + 1] : nc;
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (long long c = b; c < e; ++c) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    lo[d] = fminf(lo[d], child[c].lo[d]);
+                    hi[d] = fmaxf(hi[d], child[c].hi[d]);
+                }
+                child[c].parent = (unsigned int) p;
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                nd.lo[d] = lo[d];
+                nd.hi[d] = hi[d];
+            }
+            nd.begin = (unsigned int) b;
+            nd.parent = 0;
+            parent[p] = nd;
+            ppb[p] = cpb[b];
+        }
+        __threadfence_block();
+        __syncthreads();
+        cur = nxt;
+    }
+}
+
 // the first point of every cell (code >> shift3 differs from the predecessor's) writes the cell's code and start; pos[i] =
 // cell starts before i (cell_start_ranks)
 __global__ void k_cell_scatter(const unsigned long long *__restrict__ codes, const unsigned int *__restrict__ pos, long long n,
@@ -425,7 +504,16 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
     bool bbox_ready = false;
     // prefiltered: slab mode, but the caller guarantees that every point lies inside [reg_lo, reg_hi) (the halo exchange
     // delivered exactly those): the flag / scan / compact filter and its host round trip are skipped
-    if ((ctx->slab.axis < 0 || prefiltered) && src_on_device) {
+    if (T) {  // the identity moves nothing (Open3D's Transform would multiply by 1 and add 0: bit-identical)
+        bool identity = true;
+        for (int i = 0; i < 16; ++i) identity = identity && T[i] == ((i % 5 == 0) ? 1.0 : 0.0);
+        if (identity) T = nullptr;
+    }
+    if ((ctx->slab.axis < 0 || prefiltered) && src_on_device && !T && ctx->borrow_device_input) {
+        // ME_FLAG_BORROW_DEVICE_INPUT: the cloud is read where it lies (the caller keeps the buffer valid and unchanged until this
+        // slot's next upload): no 48-byte-per-point copy, the bounding box comes from k_bbox (cloud_finish)
+        c.xyz.borrow(const_cast<double *>(src), (size_t) n * 3 * sizeof(double));
+    } else if ((ctx->slab.axis < 0 || prefiltered) && src_on_device) {
         // one pass: copy + transform + bounding-box partials
         ME_CHECK(ctx, c.xyz.ensure((size_t) n * 3 * sizeof(double)));
         const unsigned int nb = (unsigned int) std::min<long long>(1024, (n + 255) / 256);
@@ -537,6 +625,7 @@ int cloud_transform(me_ctx *ctx, int slot, const double *T) {
     }
     Mat4 m;
     std::memcpy(m.m, T, sizeof(m.m));
+    ME_CHECK(ctx, c.xyz.make_owned(ctx->stream));  // (a borrowed input buffer is the caller's: transform a private copy)
     hipLaunchKernelGGL(k_transform, dim3(grid_for(c.n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), c.n, m);
     ME_TRY(rotate_attributes(ctx, slot, T));  // normals / covariances follow the points (Open3D PointCloud::Transform)
     return cloud_finish(ctx, slot);
@@ -678,6 +767,17 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
             const unsigned long long *cur = c.nn_grid.cell_code;
             for (int l = 0; l + 1 < L; ++l) {
                 const long long nc = v.count[l], np = v.count[l + 1];
+                if (nc <= kOctTopMax) {  // everything from here up in ONE launch
+                    ME_CHECK(ctx, begin.ensure((size_t) (np + 1) * 4));
+                    ME_CHECK(ctx, ca.ensure((size_t) np * 8));
+                    ME_CHECK(ctx, cb.ensure((size_t) np * 8));
+                    // (`cur` may live in ca / cb: the kernel's first output buffer must be the other one)
+                    unsigned long long *first = (cur == ca.as<unsigned long long>()) ? cb.as<unsigned long long>() : ca.as<unsigned long long>();
+                    unsigned long long *second = (first == ca.as<unsigned long long>()) ? cb.as<unsigned long long>() : ca.as<unsigned long long>();
+                    hipLaunchKernelGGL(k_oct_top, dim3(1), dim3(1024), 0, ctx->stream, nodes, pbeg, v, l, cur, first, second,
+                                       begin.as<unsigned int>());
+                    break;
+                }
                 ME_CHECK(ctx, pos.ensure((size_t) nc * 4));
                 ME_CHECK(ctx, begin.ensure((size_t) (np + 1) * 4));
                 DevBuf &nxt = (l % 2 == 0) ? ca : cb;

@@ -22,12 +22,13 @@ constexpr unsigned int kXcdChunk = 128;  // virtual blocks per XCD chunk (see xc
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    bool owned = true;  // false: `p` is the caller's memory (ME_FLAG_BORROW_DEVICE_INPUT), read-only for the library
     ~DevBuf() { release(); }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     hipError_t ensure(size_t b) {
-        if (b <= bytes && p) return hipSuccess;
+        if (owned && b <= bytes && p) return hipSuccess;
         release();
         if (b == 0) b = 16;
         hipError_t e = hipMalloc(&p, b);
@@ -36,9 +37,28 @@ struct DevBuf {
         return e;
     }
     void release() {
-        if (p) (void) hipFree(p);
+        if (p && owned) (void) hipFree(p);
         p = nullptr;
         bytes = 0;
+        owned = true;
+    }
+    void borrow(void *ptr, size_t b) {
+        release();
+        p = ptr;
+        bytes = b;
+        owned = false;
+    }
+    // before the library writes into the buffer: a borrowed one becomes a private copy
+    hipError_t make_owned(hipStream_t stream) {
+        if (owned) return hipSuccess;
+        void *src = p;
+        const size_t b = bytes;
+        p = nullptr;
+        bytes = 0;
+        owned = true;
+        hipError_t e = ensure(b);
+        if (e == hipSuccess) e = hipMemcpyAsync(p, src, b, hipMemcpyDeviceToDevice, stream);
+        return e;
     }
     template <class T>
     T *as() const { return reinterpret_cast<T *>(p); }
@@ -196,6 +216,7 @@ struct me_ctx {
     void *host_pinned = nullptr;
     size_t host_pinned_bytes = 0;
     int shard_rank = 0, shard_world = 1;
+    bool borrow_device_input = false;   // me_create flag ME_FLAG_BORROW_DEVICE_INPUT
     me::SlabView slab{-1, 0, 0, 0, 0};  // applied to the next uploads
     // instrumentation
     bool timers_on = false;

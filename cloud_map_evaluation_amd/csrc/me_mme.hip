@@ -32,6 +32,14 @@
 
 namespace me {
 
+// sum over the two 32-lane halves of a wave (lanes l and l ^ 32 end with the total, bit-identical)
+__device__ __forceinline__ double half2_sum_d(double v) {
+    unsigned int lo = (unsigned int) __double2loint(v), hi = (unsigned int) __double2hiint(v);
+    auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int) d[0], (int) c[0]) + __hiloint2double((int) d[1], (int) c[1]);
+}
+
 #ifdef ME_AB  // round 1's kernel, for A/B measurements only (make EXTRA=-DME_AB; ME_MME_V=1 selects it)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_mme(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
@@ -389,6 +397,240 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
 
 #ifdef ME_AB
 // ------------------------------------------------------------------------------------------------------------
+// k_mme3h (round 4, MEASURED AND NOT ADOPTED: 25.62 ms per step against k_mme3's 25.67 on the 50 M + 50 M pair, results identical;
+// behind -DME_AB, ME_MME_V=8) — k_mme3 with the wavefront as 32 QUERIES x 2 CANDIDATE SLOTS instead of 64 queries x 1.
+// k_mme3's time is its fp64 accumulation: 13 instructions for every candidate SOME lane accepts (~80 % of the stream), executed by
+// 64 lanes of which ~12 accept.  The candidates a wave has to stream are the union of its queries' neighbourhoods, and the union of
+// 32 curve-consecutive queries is smaller than that of 64 (their patch is 0.11 m instead of 0.16 m across, next to a radius of
+// 0.1 m).  So a wave serves its 64 points in two passes of 32: lanes l and l + 32 stand for the same query, the lower half tests the
+// even candidates of a staged tile and the upper half the odd ones (a two-address ds_read costs what a broadcast does,
+// profiles/r04_issue_rates.txt), every step covers two candidates, and the halves' moments are added once per round.  Same
+// accepted set, same exact band; the moments are the same fp64 sums in a different order (valid flags and counts identical,
+// entropies to ~1e-14 as between any two summation orders).  Why it does not pay: the candidate set is quantised to whole cells —
+// the cell box of 32 queries grown by one is ~4 x 4 surface cells against ~4.5 x 4.5 for 64, 1.26x fewer candidates, not the 1.6x of the
+// continuous estimate — and the run table (12 % of k_mme3) is built twice per wavefront.
+// ------------------------------------------------------------------------------------------------------------
+template <int TILE, int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+k_mme3h(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
+       GridView g, FrameView fr, SlabView slab, double r2, int min_k, double *__restrict__ ent_s,
+       unsigned char *__restrict__ valid_s, double *__restrict__ part_sum, long long *__restrict__ part_cnt,
+       unsigned int xcd_chunk, int dbg, double cell_h, float thr_lo, float thr_hi) {
+    // cell_h = edge of a radius-grid cell; thr_lo / thr_hi = r^2 -+ E in FP32 (E = 2^-12 cell_h^2): kernel arguments, i.e.
+    // scalar registers for the whole kernel (computed in the kernel they lived in VGPRs and were spilled around the loop).
+    // dbg: profiling switches (profiles/README.md) — 1: no candidate streaming at all, 2: pre-test only, nothing accepted.
+    static_assert(TILE * 16 >= kGroupRows * 4, "the row masks of the cull alias the FP32 tile");
+    const unsigned int vb = xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);
+    const unsigned int loc = vb * blockDim.x + threadIdx.x;
+    const int shift3 = 3 * g.shift;
+    const int cell_lim = 1 << (kMortonBits - g.shift);
+    __shared__ int2 s_tab[4][kGroupTab + 1];
+    __shared__ float4 s_tf[4][TILE];     // FP32 records of the staged run (the cull's row masks while the table is built)
+    __shared__ double2 s_txy[4][TILE];   // its fp64 coordinates: (x, y) as one 16-byte record, z apart — two LDS reads per
+    __shared__ double s_tz[4][TILE];     // accepted candidate instead of three (a ds_read_b64 costs a SIMD 8.7 issue cycles)
+    const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));  // scalar: the wave's LDS bases stay out of VGPRs
+    int2 *tab = s_tab[wv];
+    float4 *tf = s_tf[wv];
+    double2 *txy = s_txy[wv];
+    double *tdz = s_tz[wv];
+    const int lane = threadIdx.x & 63;
+
+    double det_keep = 0.0;  // determinant of the neighbourhood covariance (valid when have_det)
+    bool have_det = false;  // the query has at least min_k neighbours
+    // TWO PASSES of 32 queries x 2 candidate slots (see the header of this kernel): in pass p the lanes l and l + 32 both stand for
+    // the query of lane 32 p + (l & 31); the lower half tests the even candidates of a tile, the upper half the odd ones.
+    // (the pass's query is loaded at the start of the pass, not carried: this kernel lives on 64 registers)
+    const int half = lane >> 5;
+  for (int pass = 0; pass < 2; ++pass) {
+    const long long qi = i_begin + (long long) (loc - (unsigned int) lane + (unsigned int) ((lane & 31) + 32 * pass));
+    double qx = 0, qy = 0, qz = 0;
+    unsigned long long mycell = ~0ULL;
+    bool done = true;
+    if (qi < i_end) {
+        const SPoint q = sp[qi];
+        qx = q.x;
+        qy = q.y;
+        qz = q.z;
+        mycell = codes[qi] >> shift3;
+        done = !slab_owned(slab, qx, qy, qz);  // slab mode: halo points are neighbours only, never queries
+    }
+    double det_pass = 0.0;
+    bool have_pass = false;
+    // A lane accumulates in exactly ONE round (the one whose group it belongs to), so the moments live inside the round:
+    // nothing of them is alive while the next round's table is built.
+#ifdef ME_MME_STATS
+    int st_round = 0;
+#endif
+    while (__ballot(!done)) {
+        GroupBox bx;
+        int nk = 0;
+        const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
+        const bool in = wave_group_table<1, true>(!done, cx, cy, cz, g, cell_lim, lane, tab, bx, &nk,
+                                                  reinterpret_cast<unsigned int *>(tf));
+        // wave-uniform, and kept in scalar registers (there is no scalar fp64 arithmetic: computed once per round on the
+        // vector unit, then moved over)
+        const double ox = uniform_f64(fr.ox + (double) bx.x0 * cell_h), oy = uniform_f64(fr.oy + (double) bx.y0 * cell_h),
+                     oz = uniform_f64(fr.oz + (double) bx.z0 * cell_h);
+        const float ax = (float) (-2.0 * (qx - ox)), ay = (float) (-2.0 * (qy - oy)), az = (float) (-2.0 * (qz - oz));
+        const float s = fmaf(az, az, fmaf(ay, ay, ax * ax));
+        // (the group predicate rides on the thresholds: lanes outside the group accept nothing)
+        const float t_hi = (in && dbg != 2) ? fmaf(-0.25f, s, thr_hi) : -INFINITY;
+        const float t_lo = (in && dbg != 2) ? fmaf(-0.25f, s, thr_lo) : -INFINITY;
+        int k = 0;
+        double s1x = 0, s1y = 0, s1z = 0;
+        double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+#ifdef ME_MME_STATS
+        int st_cand = 0;
+#endif
+        auto test = [&](const float4 &c, int j) {
+            const float u = fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
+            const bool hi = u < t_hi;
+            const unsigned long long mh = __ballot(hi);
+            if (mh) {  // some lane may hold this candidate inside its radius
+                bool acc = u < t_lo;
+                // (both compares land in scalar register pairs: the band test is scalar work, no VALU instruction)
+                if (__builtin_expect(mh != __ballot(acc), 0)) {  // a lane in the band: its exact test decides
+                    asm volatile("; band: exact test" ::: "memory");     // (keeps the compiler from evaluating it always)
+                    const double2 exy = txy[j];
+                    const double ex = exy.x - qx, ey = exy.y - qy, ez = tdz[j] - qz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    acc = acc || (hi && d2 < r2);                        // strict, nanoflann RadiusResultSet [upstream]
+                }
+                if (acc) {
+                    const double2 pxy = txy[j];
+                    const double dx = pxy.x - qx, dy = pxy.y - qy, dz = tdz[j] - qz;
+                    ++k;
+                    s1x += dx;
+                    s1y += dy;
+                    s1z += dz;
+                    sxx = fma(dx, dx, sxx);
+                    sxy = fma(dx, dy, sxy);
+                    sxz = fma(dx, dz, sxz);
+                    syy = fma(dy, dy, syy);
+                    syz = fma(dy, dz, syz);
+                    szz = fma(dz, dz, szz);
+                }
+            }
+        };
+        if (dbg != 1) wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) {
+            for (int base = cs; base < ce; base += TILE) {
+                const int n = min(TILE, ce - base), n4 = (n + 3) & ~3;
+#ifdef ME_MME_STATS
+                st_cand += n;
+#endif
+                if (lane >= n && lane < n4) tf[lane] = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
+                if (lane < n) {
+                    const SPoint p = sp[base + lane];
+                    const double px = p.x - ox, py = p.y - oy, pz = p.z - oz;
+                    const float fx = (float) px, fy = (float) py, fz = (float) pz;
+                    // |p'|^2 of the ROUNDED coordinates (the error bound is stated for them), rounded once
+                    const double w = ((double) fx * (double) fx + (double) fy * (double) fy) + (double) fz * (double) fz;
+                    tf[lane] = make_float4(fx, fy, fz, (float) w);
+                    txy[lane] = make_double2(p.x, p.y);
+                    tdz[lane] = p.z;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                int j = 0;
+                // (two records in flight, not four: eight registers fewer is what keeps this kernel at 64 VGPRs without
+                // spilling inside the run loop — the spills of the four-deep version were 3.2x the kernel's useful HBM traffic)
+                // the tile is padded to a multiple of four with records no query accepts: two candidates per step and half
+                for (; j < n4; j += 4) {
+                    const float4 c0 = tf[j + half], c1 = tf[j + 2 + half];
+                    test(c0, j + half);
+                    test(c1, j + 2 + half);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
+            }
+        });
+#ifdef ME_MME_STATS
+        {
+            int ka = in ? k - 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) ka += __shfl_xor(ka, o, 64);
+            const int served = __popcll(__ballot(in));
+            if (lane == 0) {
+                atomicAdd(&g_mme_stat[0], 1ULL);
+                atomicAdd(&g_mme_stat[1], (unsigned long long) st_cand);
+                atomicAdd(&g_mme_stat[2], (unsigned long long) served);
+                atomicAdd(&g_mme_stat[3], (unsigned long long) ka);
+                if (st_round > 0) {  // what the rounds after a wave's first one cost and serve
+                    atomicAdd(&g_mme_stat[4], 1ULL);
+                    atomicAdd(&g_mme_stat[5], (unsigned long long) st_cand);
+                    atomicAdd(&g_mme_stat[6], (unsigned long long) served);
+                }
+            }
+            ++st_round;
+        }
+#endif
+        // the two halves hold the moments over the even / the odd candidates of the same query: add them (every lane takes part)
+        k += __shfl_xor(k, 32, 64);
+        s1x = half2_sum_d(s1x);
+        s1y = half2_sum_d(s1y);
+        s1z = half2_sum_d(s1z);
+        sxx = half2_sum_d(sxx);
+        sxy = half2_sum_d(sxy);
+        sxz = half2_sum_d(sxz);
+        syy = half2_sum_d(syy);
+        syz = half2_sum_d(syz);
+        szz = half2_sum_d(szz);
+        if (in) {
+            done = true;
+            const int kk = k - 1;  // drop the query itself (map_eval.cpp:1672-1673)
+            if (kk >= min_k) {     // (:1675 k >= 10, :1458 k >= 5)
+                const double inv_k = 1.0 / (double) kk, inv_km1 = 1.0 / (double) (kk - 1);
+                const double cxx = (sxx - s1x * s1x * inv_k) * inv_km1;
+                const double cxy = (sxy - s1x * s1y * inv_k) * inv_km1;
+                const double cxz = (sxz - s1x * s1z * inv_k) * inv_km1;
+                const double cyy = (syy - s1y * s1y * inv_k) * inv_km1;
+                const double cyz = (syz - s1y * s1z * inv_k) * inv_km1;
+                const double czz = (szz - s1z * s1z * inv_k) * inv_km1;
+                // Eigen 3x3 determinant (cofactor expansion along row 0)
+                det_pass = cxx * (cyy * czz - cyz * cyz) - cxy * (cxy * czz - cyz * cxz) + cxz * (cxy * cyz - cyy * cxz);
+                have_pass = true;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (half == pass) {  // this pass served the lane's own query
+        det_keep = det_pass;
+        have_det = have_pass;
+    }
+  }
+    const bool active = i_begin + (long long) loc < i_end;  // (not owned / too few neighbours: H = 0, valid = 0)
+    // (the logarithm stays outside the round loop: inside, the compiler hoists its polynomial constants into VGPRs that
+    // live across the candidate loop and spills them)
+    double H = 0.0;
+    bool ok = false;
+    if (active) {
+        if (have_det) {
+            const double h = 0.5 * log(2.0 * M_PI * M_E * det_keep);  // ComputeEntropy (:1656); NaN for det < 0
+            if (!isnan(h) && !isinf(h)) {                              // (:1692)
+                H = h;
+                ok = true;
+            }
+        }
+        unsigned int loc_e = loc;
+        asm volatile("" : "+v"(loc_e));  // (recomputed, not carried: the 64-bit index was spilled across the whole kernel)
+        const long long i = i_begin + (long long) loc_e;
+        ent_s[i] = H;                       // 0.0 where invalid (:1614)
+        valid_s[i] = ok ? 1 : 0;
+    }
+    __shared__ double smd[4];
+    __shared__ long long smi[4];
+    const double bs = block_sum_256(H, smd);
+    const long long bc = block_sum_256_ll(ok ? 1LL : 0LL, smi);
+    if (threadIdx.x == 0) {
+        part_sum[blockIdx.x] = bs;
+        part_cnt[blockIdx.x] = bc;
+    }
+}
+
+
+#endif  // ME_AB
+
+#ifdef ME_AB
+// ------------------------------------------------------------------------------------------------------------
 // k_mme6 (round 3, MEASURED AND NOT ADOPTED: 33.8 ms per step against k_mme3's 26.1 on the 50 M + 50 M pair, results
 // identical; profiles/README.md "round 3" has the counters) — the radius test on the MATRIX pipe, 16 queries x 4
 // candidate slices per wavefront.
@@ -733,7 +975,15 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     hipLaunchKernelGGL((k_mme6<T, W>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),                                \
                        c.codes.as<unsigned long long>(), b, e, c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(),             \
                        val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), c.cell_h, thr_lo, thr_hi)
-        if (use7) {
+        if (variant == 8 && waves < 8) {
+            hipLaunchKernelGGL((k_mme3h<32, 7>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
+                               c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), dbg,
+                               c.cell_h, thr_lo, thr_hi);
+        } else if (variant == 8) {
+            hipLaunchKernelGGL((k_mme3h<32, 8>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,
+                               c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), dbg,
+                               c.cell_h, thr_lo, thr_hi);
+        } else if (use7) {
             ME_TRY(mme7_launch(ctx, c, b, e, nb, radius, min_k, ent_s.as<double>(), val_s.as<unsigned char>(), ps, pc));
         } else if (variant == 1) {
             hipLaunchKernelGGL(k_mme, dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, e,

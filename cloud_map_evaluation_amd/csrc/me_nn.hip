@@ -372,6 +372,7 @@ k_nn_grid_mfma(const SPoint *__restrict__ qsp, long long q_begin, long long q_en
     // version fetched the candidates with scalar loads (s_load, candidate in SGPRs): the scalar cache misses on this
     // stream (rocprofv3 SQC counters: 75 % of the requests), so every group of four paid an L2 round trip that 8 waves
     // per SIMD could not hide (68 % VALU issue).
+    __shared__ float4 s_tile[4][64];  // (doubles as the row masks of the adjacency cull while a round's table is built)
     float4 *tile = s_tile[threadIdx.x >> 6];
     double ox = 0, oy = 0, oz = 0;  // the round's local origin (wave-uniform)
     // A run is padded to a multiple of four with records of rank +inf: no scalar tail loop (with 6-point cells most runs end
@@ -417,6 +418,7 @@ k_nn_grid_mfma(const SPoint *__restrict__ qsp, long long q_begin, long long q_en
         }
     };
     // (the candidate set of a round is a superset of the lane's own 3x3x3 block; extra candidates only help)
+    __shared__ int2 s_tab[4][kGroupTab + 1];
     int2 *tab = s_tab[threadIdx.x >> 6];
     while (__ballot(!done)) {
         GroupBox bx;
@@ -1146,8 +1148,10 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         FrameView fr{r.origin[0], r.origin[1], r.origin[2], r.fine_h};
         // Cascade: fine grid -> (what it leaves) the radius grid, when that is a coarser level -> (what that leaves) the octree.
         const bool two_pass = r.grid.cell_start && r.grid.shift > r.nn_grid.shift;
-        ME_CHECK(ctx, ctx->nn_flags.ensure((size_t) (e - b) + 64));
-        ME_CHECK(ctx, ctx->nn_list_a.ensure((size_t) (e - b) * 4 + 64));
+        if (two_pass) {
+            ME_CHECK(ctx, ctx->nn_flags.ensure((size_t) (e - b) + 64));
+            ME_CHECK(ctx, ctx->nn_list_a.ensure((size_t) (e - b) * 4 + 64));
+        }
         unsigned int *list_a = two_pass ? ctx->nn_list_a.as<unsigned int>() : q.nn_list.as<unsigned int>();
         unsigned int *cnt_a = two_pass ? d_cnt + 2 : d_cnt;
         {
@@ -1169,8 +1173,9 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
                 hipLaunchKernelGGL((k_nn_grid<false>), dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
                                    r.n, r.nn_grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt,
                                    xcd_chunk_setting(), (const unsigned int *) nullptr, (const unsigned int *) nullptr,
-                                   ctx->nn_flags.as<unsigned char>());
-                ME_TRY(select_flagged_u32(ctx, ctx->nn_flags.as<unsigned char>(), e - b, list_a, cnt_a));
+                                   two_pass ? ctx->nn_flags.as<unsigned char>() : (unsigned char *) nullptr);
+                // (one pass only: the unresolved queries were appended to the octree's list directly, in any order)
+                if (two_pass) ME_TRY(select_flagged_u32(ctx, ctx->nn_flags.as<unsigned char>(), e - b, list_a, cnt_a));
             }
         }
         if (two_pass) {

@@ -924,6 +924,7 @@ int voxel_downsample(me_ctx *ctx, int slot, double voxel_size, long long *n_out)
     hipLaunchKernelGGL(k_set_u32v, dim3(1), dim3(1), 0, ctx->stream, seg_start.as<unsigned int>(), V, (unsigned int) n);
     hipLaunchKernelGGL(k_vds_mean, dim3(grid_for(V)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), perm.as<unsigned int>(),
                        seg_start.as<unsigned int>(), V, out.as<double>());
+    if (!c.xyz.owned) ME_CHECK(ctx, c.xyz.ensure((size_t) V * 24));  // (a borrowed input buffer is the caller's: the result gets its own)
     ME_CHECK(ctx, hipMemcpyAsync(c.xyz.p, out.p, (size_t) V * 24, hipMemcpyDeviceToDevice, ctx->stream));
     if (c.have_normals) {  // Open3D averages the normals of a voxel as well (sum / count, not re-normalised)
         hipLaunchKernelGGL(k_vds_mean, dim3(grid_for(V)), dim3(256), 0, ctx->stream, c.normals.as<double>(), perm.as<unsigned int>(),

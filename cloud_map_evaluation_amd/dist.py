@@ -340,15 +340,24 @@ def _comm(t, comm_device):
     return t if t.device == comm_device else t.to(comm_device)
 
 
-def dist_slab_cuts(gt_part, dist, comm_device, world: int, sample: int = 16384):
+def dist_slab_cuts(gt_part, dist, comm_device, world: int, sample: int = 16384, est_part=None):
     """Equal-count slab faces along the longest axis of the GLOBAL ground-truth cloud, from each rank's part of it.
     Returns (axis, cuts[world + 1]) with cuts[0] = -inf, cuts[-1] = +inf; identical on every rank.
     ONE collective: every rank contributes a fixed-size strided sample of its points (NaN-padded when it holds fewer), the
-    all-gathered sample gives the extent (-> axis) and, sorted along that axis, the cuts at its k/world quantiles."""
+    all-gathered sample gives the extent (-> axis) and, sorted along that axis, the cuts at its k/world quantiles.
+    est_part (round 4): half of the sample is drawn from the rank's part of the ESTIMATED map, so that a slab holds 1/world of
+    BOTH clouds' points together — every per-point pass costs per point of either cloud, and with cuts by the ground truth alone
+    the slab where the map is densest carried 19 % more MME work than the mean (profiles/README.md)."""
     import torch
 
     inf = float("inf")
     t = gt_part
+    if est_part is not None and world > 1 and int(est_part.shape[0]) > 0:
+        h = sample // 2
+        ne, ng = int(est_part.shape[0]), int(gt_part.shape[0])
+        pe = est_part[::max(1, -(-ne // h))][:h]
+        pg = gt_part[::max(1, -(-ng // (sample - h)))][:sample - h] if ng else gt_part[:0]
+        t = torch.cat([pg, pe])
     n = int(t.shape[0])
     if world == 1:
         if n == 0:
@@ -459,7 +468,7 @@ def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, wor
     T = np.asarray(P.initial_matrix_, dtype=np.float64)
     if not np.array_equal(T, np.eye(4)):
         est_part = eng.transform_points(est_part.clone(), T)  # (:1206) before the exchange: slabs are cut in the map frame
-    axis, cuts = dist_slab_cuts(gt_part, dist, comm_device, world)
+    axis, cuts = dist_slab_cuts(gt_part, dist, comm_device, world, est_part=est_part)
     tr.mark("cuts")
     est_r, gt_r = halo_exchange(eng, dist, comm_device, [est_part, gt_part], axis, cuts, halo)
     tr.mark("halo_exchange")

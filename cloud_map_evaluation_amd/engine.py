@@ -63,9 +63,12 @@ def _addr(a) -> int:
 
 
 class Engine:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, borrow_device_input: bool = False):
+        """borrow_device_input: ME_FLAG_BORROW_DEVICE_INPUT — cuda tensors uploaded without a transform are read where they lie
+        (no copy); the Engine keeps a reference to them until the slot's next upload, the caller must not modify them meanwhile."""
         self._L = _lib.load()
-        self._ctx = self._L.me_create(int(device), 0)
+        self._ctx = self._L.me_create(int(device), 1 if borrow_device_input else 0)
+        self._held = {}  # slot -> the array / tensor of its last upload (borrowed device inputs must outlive their use)
         if not self._ctx:
             raise MapEvalError(self._L.me_last_error(None).decode())
         self.device = device
@@ -80,6 +83,7 @@ class Engine:
             if not t._ctx:
                 raise MapEvalError(self._L.me_last_error(self._ctx).decode())
             t.device = self.device
+            t._held = self._held
             t._owned = False
             t._twin = None
             self._twin = t
@@ -131,7 +135,7 @@ class Engine:
             raise ValueError("expected an (N,3) array")
         fn = self._L.me_upload_cloud_device if on_device else self._L.me_upload_cloud
         self._ck(fn(self._ctx, slot, _addr(xyz), int(xyz.shape[0]), _addr(Tm), float(cell_size)))
-        self._keepalive = xyz
+        self._held[slot] = xyz
 
     def upload_slab(self, slot: int, xyz, cell_size: float = 0.0):
         """upload() for a cuda tensor that already IS this rank's slab + halo (what the halo exchange delivered): no filter."""
@@ -143,7 +147,7 @@ class Engine:
             xyz = xyz.to(torch.float64).contiguous()
         torch.cuda.current_stream(xyz.device).synchronize()
         self._ck(self._L.me_upload_slab_device(self._ctx, slot, xyz.data_ptr(), int(xyz.shape[0]), float(cell_size)))
-        self._keepalive = xyz
+        self._held[slot] = xyz
 
     def voxel_downsample(self, slot: int, voxel_size: float) -> int:
         """open3d VoxelDownSample (map_eval.cpp:38-39) on the uploaded cloud, in place; returns the new point count."""

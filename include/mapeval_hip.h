@@ -67,8 +67,13 @@ typedef struct me_nn_stats_out {
 } me_nn_stats_out;
 
 /* ---- lifetime ---------------------------------------------------------------------------------------------- */
-/* device: HIP device ordinal (one context per GPU).  flags: reserved, pass 0.  NULL on failure. */
+/* device: HIP device ordinal (one context per GPU).  flags: 0, or ME_FLAG_BORROW_DEVICE_INPUT.  NULL on failure. */
 me_ctx *me_create(int device, int flags);
+/* ME_FLAG_BORROW_DEVICE_INPUT: me_upload_cloud_device / me_upload_slab_device without a transform (T NULL or the identity) read the
+ * caller's device buffer WHERE IT LIES instead of copying it: the caller keeps it valid and unchanged until the slot's next upload
+ * (or me_destroy).  Saves one 48-byte-per-point pass per cloud; calls that modify the cloud in place (me_transform_cloud,
+ * me_voxel_downsample) switch to a private copy first.  No reference counterpart (Open3D owns its points_). */
+#define ME_FLAG_BORROW_DEVICE_INPUT 1
 void me_destroy(me_ctx *ctx);
 const char *me_last_error(me_ctx *ctx); /* ctx may be NULL: returns the last me_create error */
 int me_version(void);

@@ -66,7 +66,7 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
         per_rank, detail = [], []
         if world > 1:
             # what the halo exchange delivers to every rank (untimed): the cuts are those every rank computes
-            axis, cuts = medist.dist_slab_cuts(gt, None, dev, world)
+            axis, cuts = medist.dist_slab_cuts(gt, None, dev, world, est_part=est)
             packs = [[eng.halo_pack(p, axis, cuts, halo) for p in pc] for pc in pieces]  # [src][cloud] -> (points, counts)
         for rank in range(world):
             if world == 1:
@@ -96,7 +96,7 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
                     medist.suite_step_dist(eng, fd, dev, pieces[rank][0], pieces[rank][1], P, rank, world, True, halo=halo, overlap=OVERLAP)
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
-            best_t = {k: round(eng.timer(k)[0], 2) for k in ("mme", "nn_grid", "nn1", "sort", "morton", "gather", "cells", "voxel",
+            best_t = {k: round(eng.timer(k)[0], 2) for k in ("mme", "nn_grid", "nn_grid2", "nn1", "nn_far", "sort", "morton", "gather", "cells", "voxel",
                                                             "slab_filter", "halo_pack", "nn_stats") if eng.timer(k)[1]}
             eng.timers_enable(False)
             medist.dist_slab_cuts = _orig_cuts
@@ -117,10 +117,10 @@ GLOBAL = {}
 OVERLAP = __import__("os").environ.get("ME_EMU_OVERLAP", "1") != "0"  # 0: one lane (what the phases cost without the other lane)
 
 
-def _patched_cuts(gt_part, d, cd, w, sample=16384):
+def _patched_cuts(gt_part, d, cd, w, sample=16384, est_part=None):
     """Collective 1 repeats the rank's own sample here, so a rank alone would cut by its OWN quantiles: do the same device work, then
     hand back the global cuts (those the precomputed exchange was made for)."""
-    _orig_cuts(gt_part, None, cd, w, sample)
+    _orig_cuts(gt_part, None, cd, w, sample, est_part=est_part)
     return GLOBAL["cuts"]
 
 

@@ -19,7 +19,7 @@ def test_workloads_and_defaults(monkeypatch):
     monkeypatch.setattr("sys.argv", ["bench.py", "--workload", "c5_tunnel", "--cpu-sample", "0", "--points", "1000"])
     a = bench.parse()
     assert a.voxel == 2.0 and a.points == 1000 and a.cpu_baseline == "off"  # config_geode.yaml:60; --cpu-sample 0 kept as an alias
-    assert set(bench.WORKLOADS) == {"c4_multisession", "campus", "c3_20m", "c5_tunnel"}
+    assert set(bench.WORKLOADS) == {"c4_multisession", "c4_dense", "campus", "c3_20m", "c5_tunnel"}
 
 
 def test_committed_traffic_figure_belongs_to_the_committed_kernels():
