@@ -402,6 +402,12 @@ def main():
                                 "traffic_source": traffic_src,
                                 "avg_launch_ms": avg_ms, "units_per_launch": units, "algorithmic_bytes_per_launch": alg_bytes,
                                 "kernel_ms_per_step": {k: v[0] for k, v in fam.items()},
+                                # the second hot kernel, same definition (60 B per 1-NN query)
+                                "nn_grid": ({"avg_launch_ms": fam["nn_grid"][0] / fam["nn_grid"][1],
+                                             "achieved": BYTES_PER_NN_QUERY * (n_e + n_g) * shard / fam["nn_grid"][1] / (fam["nn_grid"][0] / fam["nn_grid"][1] * 1e-3) / 1e9,
+                                             "frac": BYTES_PER_NN_QUERY * (n_e + n_g) * shard / fam["nn_grid"][1] / (fam["nn_grid"][0] / fam["nn_grid"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "traffic": (json.load(open(tpath)).get("nn_grid") if (os.path.exists(tpath) and traffic is not None) else None)}
+                                            if "nn_grid" in fam else None),
                                 "nn_fallback_fraction": (nn_fallback / nn_total) if nn_total else None,
                                 "queries_per_s": {"nn": (n_e + n_g) * shard / ((fam.get("nn1", (0, 0))[0] + fam.get("nn_far", (0, 0))[0] + fam.get("nn_grid", (0, 0))[0] + fam.get("nn_grid2", (0, 0))[0]) * 1e-3)
                                                   if ("nn1" in fam or "nn_grid" in fam) else None,
@@ -416,7 +422,21 @@ def main():
     if world == 1 and not args.no_h2d:
         est_p, gt_p = est_h.pin_memory(), gt_h.pin_memory()
         h_ms, h_res = timed(est_p, gt_p, max(2, min(3, args.steps)), 1)
+        # the two spans side by side (small items): SURVEY 8(d) words the span from HOST memory, the task contract
+        # fixes `value` to the HBM-resident one.  first_cloud_idle_ms: nothing can be computed on a cloud before its last byte has
+        # arrived, so the GPU idles for the map's copy (measured alone, pinned -> device)
+        up = torch.empty_like(est_d) if est_d is not None else None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            up.copy_(est_p, non_blocking=True)
+        torch.cuda.synchronize()
+        first_idle = (time.perf_counter() - t0) / 3 * 1e3
+        del up
+        line["hbm_resident"] = {"ms_per_step": ms_per_step, "value": value, "unit": "Mpts/s",
+                                "note": "clouds resident in HBM when the timed region starts (= `value`, the contract's span)"}
         line["h2d_inclusive"] = {"ms_per_step": h_ms, "value": (n_e + n_g) / 1e6 / (h_ms / 1e3), "unit": "Mpts/s",
+                                 "first_cloud_idle_ms": first_idle, "pcie_gb_s": 24 * n_e / (first_idle * 1e-3) / 1e9,
                                  "note": "same step with both clouds starting in pinned host memory (2 x 24 B/pt over PCIe Gen5; the "
                                          "ground truth crosses the link under the map's MME kernel) and every scalar back on the host",
                                  "bytes_h2d": 24 * (n_e + n_g),

@@ -733,10 +733,16 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
                 break;
             }
         ME_TRY(build_grid_table(ctx, c, c.shift, c.grid_tab, c.grid));
+        c.n_mid = 0;
         if (nn_shift == c.shift) {
             c.nn_grid = c.grid;
         } else {
             ME_TRY(build_grid_table(ctx, c, nn_shift, c.nn_tab, c.nn_grid));
+            // tables of the levels in between, for the 1-NN cascade (me_nn.hip): each is one scan + one scatter + the hash inserts
+            for (int k = nn_shift + 1; k < c.shift && c.n_mid < Cloud::kMaxMid; ++k) {
+                ME_TRY(build_grid_table(ctx, c, k, c.mid_tab[c.n_mid], c.mid_grid[c.n_mid]));
+                ++c.n_mid;
+            }
         }
         // --- sparse octree above the 1-NN cells (general 1-NN path) ---
         {

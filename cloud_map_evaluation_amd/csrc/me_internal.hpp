@@ -157,6 +157,12 @@ struct Cloud {
     // (1-NN fast path); they share storage when the two levels coincide
     GridTable grid_tab, nn_tab;
     GridView grid{}, nn_grid{};
+    // the levels strictly between the 1-NN grid and the radius grid (dense clouds only: at 10^4 pts/m^2 the 1-NN cells are 2.5 cm and
+    // the radius cells 10 cm): the 1-NN cascade passes what a level leaves unresolved to the next coarser one
+    static constexpr int kMaxMid = 4;
+    GridTable mid_tab[kMaxMid];
+    GridView mid_grid[kMaxMid]{};
+    int n_mid = 0;
     long long level_unique[kMortonBits + 1] = {0};  // occupied cells per Morton level
     // last NN result with this cloud as the query (sorted query order)
     DevBuf nn_d2, nn_idx, nn_list;
@@ -229,7 +235,7 @@ struct me_ctx {
     std::vector<hipEvent_t> event_pool;
     long long nn_fallback = 0, nn_queries = 0;  // counted only while timers are on
     me::DevBuf nn_far;                           // queries whose octree walk k_nn1 handed over to k_nn_far
-    me::DevBuf nn_flags, nn_list_a;              // 1-NN cascade: unresolved flags of the fine-grid pass, their ordered list
+    me::DevBuf nn_flags, nn_list_a, nn_list_b;   // 1-NN cascade: unresolved flags of the fine-grid pass, their ordered list, ping-pong
     me::DevBuf nn1_dbg_buf;                      // octree-walk counters (nodes opened, leaves scanned, points, max per query)
     unsigned long long *nn1_dbg() {
         if (!nn1_dbg_buf.p) {

@@ -1146,11 +1146,19 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         ME_CHECK(ctx, q.nn_list.ensure((size_t) (e - b) * 4 + 64));
         ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));  // [0] unresolved-list length, [1] far-list length, [2] first-pass list
         FrameView fr{r.origin[0], r.origin[1], r.origin[2], r.fine_h};
-        // Cascade: fine grid -> (what it leaves) the radius grid, when that is a coarser level -> (what that leaves) the octree.
-        const bool two_pass = r.grid.cell_start && r.grid.shift > r.nn_grid.shift;
+        // Cascade: fine grid -> (what it leaves) every coarser level up to the radius grid -> (what that leaves) the octree.
+        const GridView *levels[Cloud::kMaxMid + 1];
+        int n_levels = 0;
+        if (r.grid.cell_start && r.grid.shift > r.nn_grid.shift) {
+            for (int k = 0; k < r.n_mid; ++k)
+                if (r.mid_grid[k].shift > r.nn_grid.shift && r.mid_grid[k].shift < r.grid.shift) levels[n_levels++] = &r.mid_grid[k];
+            levels[n_levels++] = &r.grid;
+        }
+        const bool two_pass = n_levels > 0;
         if (two_pass) {
             ME_CHECK(ctx, ctx->nn_flags.ensure((size_t) (e - b) + 64));
             ME_CHECK(ctx, ctx->nn_list_a.ensure((size_t) (e - b) * 4 + 64));
+            if (n_levels > 1) ME_CHECK(ctx, ctx->nn_list_b.ensure((size_t) (e - b) * 4 + 64));
         }
         unsigned int *list_a = two_pass ? ctx->nn_list_a.as<unsigned int>() : q.nn_list.as<unsigned int>();
         unsigned int *cnt_a = two_pass ? d_cnt + 2 : d_cnt;
@@ -1179,10 +1187,22 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
             }
         }
         if (two_pass) {
+            // level after level: the list of level k (curve-ordered after the compaction, roughly so afterwards: the appends of a
+            // pass keep the order of its input up to the scheduling of its waves) -> level k + 1; the last level appends to the
+            // octree's list.  [2], [3] of the counter block are the ping-pong lists' lengths.
             TimerScope ts(ctx, "nn_grid2");
-            hipLaunchKernelGGL((k_nn_grid<true>), dim3(2048), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
-                               r.grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt,
-                               xcd_chunk_setting(), (const unsigned int *) list_a, (const unsigned int *) cnt_a, (unsigned char *) nullptr);
+            const unsigned int *in_list = list_a, *in_cnt = cnt_a;
+            for (int k = 0; k < n_levels; ++k) {
+                const bool last = k + 1 == n_levels;
+                unsigned int *out_list = last ? q.nn_list.as<unsigned int>() : ((k & 1) ? ctx->nn_list_a.as<unsigned int>() : ctx->nn_list_b.as<unsigned int>());
+                unsigned int *out_cnt = last ? d_cnt : ((k & 1) ? d_cnt + 2 : d_cnt + 3);
+                if (!last && k >= 1) ME_CHECK(ctx, hipMemsetAsync(out_cnt, 0, 4, ctx->stream));  // (that list was read two passes ago: reuse it)
+                hipLaunchKernelGGL((k_nn_grid<true>), dim3(2048), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
+                                   *levels[k], fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), out_list, out_cnt, xcd_chunk_setting(),
+                                   in_list, in_cnt, (unsigned char *) nullptr);
+                in_list = out_list;
+                in_cnt = out_cnt;
+            }
         }
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)

@@ -352,12 +352,20 @@ def dist_slab_cuts(gt_part, dist, comm_device, world: int, sample: int = 16384, 
 
     inf = float("inf")
     t = gt_part
-    if est_part is not None and world > 1 and int(est_part.shape[0]) > 0:
+    n_gt_rows = sample  # rows of a rank's sample block that hold ground-truth points (the axis is chosen from those alone: the
+    #                     extent of the estimated map is at the mercy of its outliers)
+    if est_part is not None and world > 1:
         h = sample // 2
+        n_gt_rows = sample - h
         ne, ng = int(est_part.shape[0]), int(gt_part.shape[0])
-        pe = est_part[::max(1, -(-ne // h))][:h]
-        pg = gt_part[::max(1, -(-ng // (sample - h)))][:sample - h] if ng else gt_part[:0]
-        t = torch.cat([pg, pe])
+        blk = torch.full((sample, 3), float("nan"), dtype=torch.float64, device=gt_part.device)
+        if ng:
+            pg = gt_part[::max(1, -(-ng // n_gt_rows))][:n_gt_rows]
+            blk[:pg.shape[0]] = pg
+        if ne:
+            pe = est_part[::max(1, -(-ne // h))][:h]
+            blk[n_gt_rows:n_gt_rows + pe.shape[0]] = pe
+        t = blk
     n = int(t.shape[0])
     if world == 1:
         if n == 0:
@@ -365,7 +373,9 @@ def dist_slab_cuts(gt_part, dist, comm_device, world: int, sample: int = 16384, 
         ext = (t.amax(0) - t.amin(0)).tolist()
         return int(np.argmax(ext)), [-inf, inf]
     smp = torch.full((sample, 3), float("nan"), dtype=torch.float64, device=t.device)
-    if n:
+    if n_gt_rows < sample:
+        smp = t  # (already a NaN-padded block: ground truth first, then the map)
+    elif n:
         pick = t[::max(1, -(-n // sample))][:sample]
         smp[:pick.shape[0]] = pick
     if _single(dist):
@@ -380,7 +390,10 @@ def dist_slab_cuts(gt_part, dist, comm_device, world: int, sample: int = 16384, 
     m = int(pts.shape[0])
     if m == 0:
         return 0, [-inf] + [float(k) for k in range(1, world)] + [inf]
-    ext = (pts.amax(0) - pts.amin(0)).tolist()
+    gt_rows = allp.reshape(-1, sample, 3)[:, :n_gt_rows].reshape(-1, 3)
+    gt_rows = gt_rows[~torch.isnan(gt_rows[:, 0])]
+    ref = gt_rows if int(gt_rows.shape[0]) else pts
+    ext = (ref.amax(0) - ref.amin(0)).tolist()
     axis = int(np.argmax(ext))
     v = torch.sort(pts[:, axis]).values
     # face k sits between the two sample values around the k/world quantile (the midpoint: no sample point lies ON a face)

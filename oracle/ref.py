@@ -121,6 +121,7 @@ def lib():
                                           C.POINTER((C.c_double * 5) * 5), i64p]
         L.ref_chamfer.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_char_p, dp]
         L.ref_mme.argtypes = [C.c_int, dp, C.c_int64, C.c_double, C.c_char_p, dp, bp, dp]
+        L.ref_mme_raw.argtypes = [C.c_int, dp, C.c_int64, C.c_double, C.c_char_p, dp, bp, bp, dp]
         L.ref_compute_entropy.restype = C.c_double
         L.ref_compute_entropy.argtypes = [dp]
         L.ref_vmd.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_double, C.c_char_p, dp, dp]
@@ -274,6 +275,22 @@ def mme(variant: int, xyz, radius: float):
         _check(lib().ref_mme(variant, _dp(xyz), len(xyz), radius, wd.encode(), _dp(ent), valid.ctypes.data_as(C.POINTER(C.c_uint8)),
                              C.byref(mean)))
     return mean.value, ent, valid.astype(bool)
+
+
+def mme_raw(variant: int, xyz, radius: float):
+    """mme() plus the RAW bits of valid_entropy_points as the reference's loop left them: in the parallel variants they are written
+    from several threads into a std::vector<bool> (map_eval.cpp:1586, :1694) — a lost update clears a flag whose entropy was stored.
+    -> (mean, entropies[n], valid[n] (race-free reconstruction), valid_raw[n])"""
+    xyz = _pts(xyz)
+    ent = np.zeros(len(xyz))
+    valid = np.zeros(len(xyz), np.uint8)
+    raw = np.zeros(len(xyz), np.uint8)
+    mean = C.c_double(0)
+    u8 = C.POINTER(C.c_uint8)
+    with _Workdir() as wd:
+        _check(lib().ref_mme_raw(variant, _dp(xyz), len(xyz), radius, wd.encode(), _dp(ent), valid.ctypes.data_as(u8),
+                                 raw.ctypes.data_as(u8), C.byref(mean)))
+    return mean.value, ent, valid.astype(bool), raw.astype(bool)
 
 
 def compute_entropy(cov) -> float:

@@ -231,8 +231,15 @@ int ref_chamfer(const double *a, int64_t na, const double *b, int64_t nb, const 
 // MME loops on one cloud with a fresh MapEval (so that valid_entropy_points is this call's alone):
 // variant 0 = ComputeMeanMapEntropy (serial, k >= 5, :1438-1535), 1 = ...UsingNormal (OpenMP, k >= 10, :1538-1606),
 // 2 = ...UsingNormalTBB (k >= 10, :1608-1737).  entropies[n], valid[n] nullable.
+// valid_raw (nullable): the bits of valid_entropy_points exactly as the reference's loop left them, race included.
+int ref_mme_raw(int variant, const double *xyz, int64_t n, double radius, const char *workdir, double *entropies, uint8_t *valid,
+                uint8_t *valid_raw, double *mean);
 int ref_mme(int variant, const double *xyz, int64_t n, double radius, const char *workdir, double *entropies, uint8_t *valid,
             double *mean) {
+    return ref_mme_raw(variant, xyz, n, radius, workdir, entropies, valid, nullptr, mean);
+}
+int ref_mme_raw(int variant, const double *xyz, int64_t n, double radius, const char *workdir, double *entropies, uint8_t *valid,
+                uint8_t *valid_raw, double *mean) {
     return guarded([&] {
         ref_config c{};
         Param p = make_param(c, workdir);
@@ -253,6 +260,8 @@ int ref_mme(int variant, const double *xyz, int64_t n, double radius, const char
         // so the flag reported here is what a race-free run of the reference leaves.
         if (valid)
             for (int64_t i = 0; i < n; ++i) valid[i] = (me.valid_entropy_points[(size_t) i] || ent[(size_t) i] != 0.0) ? 1 : 0;
+        if (valid_raw)
+            for (int64_t i = 0; i < n; ++i) valid_raw[i] = me.valid_entropy_points[(size_t) i] ? 1 : 0;
     });
 }
 
