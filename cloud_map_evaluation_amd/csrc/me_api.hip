@@ -514,7 +514,7 @@ int me_timers_reset(me_ctx *ctx) {
     ctx->timers_collect();
     ctx->timers.clear();
     ctx->nn_fallback = ctx->nn_queries = 0;
-    if (ctx->nn1_dbg_buf.p) (void) hipMemsetAsync(ctx->nn1_dbg_buf.p, 0, 64, ctx->stream);
+    if (ctx->nn1_dbg_buf.p) (void) hipMemsetAsync(ctx->nn1_dbg_buf.p, 0, 128, ctx->stream);
     return ME_OK;
 }
 
@@ -532,8 +532,9 @@ int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launc
         // counters of the octree walk since the last reset (collected while timers are on): nodes opened, leaf cells scanned,
         // points scanned, the longest chain (opened + scanned) of one query
         // ... and of k_nn_far: nodes opened, points scanned, the longest chain of one query
-        static const char *names[8] = {"nn1_opened", "nn1_scans", "nn1_points", "nn1_max_opened", "nn1_far", "nn1_far_opened", "nn1_far_points", "nn1_far_max"};
-        for (int k = 0; k < 8; ++k)
+        static const char *names[12] = {"nn1_opened", "nn1_scans", "nn1_points", "nn1_max_opened", "nn1_far", "nn1_far_opened", "nn1_far_points", "nn1_far_max",
+                                         "nn1_wave_max_10ns", "nn1_wave_sum_10ns", "nn1_max_run", "nn1_waves"};
+        for (int k = 0; k < 12; ++k)
             if (std::strcmp(name, names[k]) == 0) {
                 unsigned long long v = 0;
                 if (ctx->nn1_dbg_buf.p) {

@@ -239,8 +239,8 @@ struct me_ctx {
     me::DevBuf nn1_dbg_buf;                      // octree-walk counters (nodes opened, leaves scanned, points, max per query)
     unsigned long long *nn1_dbg() {
         if (!nn1_dbg_buf.p) {
-            if (nn1_dbg_buf.ensure(64) != hipSuccess) return nullptr;
-            (void) hipMemsetAsync(nn1_dbg_buf.p, 0, 64, stream);  // ordered before the kernels that count into it
+            if (nn1_dbg_buf.ensure(128) != hipSuccess) return nullptr;
+            (void) hipMemsetAsync(nn1_dbg_buf.p, 0, 128, stream);  // ordered before the kernels that count into it
         }
         return nn1_dbg_buf.as<unsigned long long>();
     }

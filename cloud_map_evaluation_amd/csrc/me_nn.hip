@@ -543,12 +543,19 @@ __device__ __forceinline__ double octet_min(double v) {  // (DPP exchanges, me_i
     return v;
 }
 
-constexpr int kNn1Block = 128;  // 16 octets per block: 16 x 18 levels x (8 floats + 9 ints) = 19.6 KB of walk cache
-__global__ void __launch_bounds__(kNn1Block)
+constexpr int kNn1Block = 64;  // 8 octets per block (one wavefront): 8 x (levels + 1) x (8 floats + 9 ints) x 4 B of walk cache, 6 KB at 10 levels
+// (96 VGPRs, five wavefronts per SIMD: at 80 / 72 / 64 registers the compiler spills 19 / 27 / 41 dwords and the launch is slower —
+// 0.86 / 0.93 / 1.00 / 1.40 ms on the bench pair: the kernel is bound by instruction issue, not by the walks in flight)
+constexpr int kNn1Waves = 5;
+__global__ void __launch_bounds__(kNn1Block) __attribute__((amdgpu_waves_per_eu(kNn1Waves, 8)))
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
       OctView oct, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
       const unsigned int *__restrict__ list_count, int use_bound, unsigned long long *__restrict__ dbg,
-      unsigned int *__restrict__ far_list, unsigned int *__restrict__ far_count, int far_cap) {
+      unsigned int *__restrict__ far_list, unsigned int *__restrict__ far_count, int far_cap, unsigned int *__restrict__ work) {
+    // work: a zeroed counter.  A wavefront's first group of eight queries is its block index, every further one is drawn from
+    // the counter (round 4; one resident wavefront per slot of the chip).  On the bench pair this changed nothing measurable
+    // (0.92 -> 0.96 ms: the launch is bound by instruction issue, profiles/EXPERIMENTS.md) — it is kept for lists whose walks
+    // are of very unequal length, where a static deal makes the launch as long as the unluckiest pair of groups.
     // far_list: a walk that has taken `far_cap` steps is ABANDONED here — its best so far is stored as usual, a valid upper
     // bound — and its query appended to far_list for k_nn_far (a whole wavefront per query, big leaves scanned 64 points
     // abreast): the longest chain of dependent steps in this kernel is far_cap, not the walk of the farthest outlier.
@@ -564,14 +571,23 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
     const ONode *__restrict__ nodes = oct.nodes;
     const long long n_items = list ? (long long) *list_count : (q_end - q_begin);
     const int sub = threadIdx.x & 7;
-    const long long octets_per_pass = (long long) gridDim.x * (blockDim.x >> 3);
-    for (long long t = (long long) blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);; t += octets_per_pass) {
+    const unsigned long long t_wave0 = dbg ? wall_clock64() : 0ULL;  // (100 MHz)
+    unsigned long long w_open = 0, w_scan = 0, w_pts = 0;
+    unsigned int w_max = 0;
+    static_assert(kNn1Block == 64, "one wavefront per block: the group counter is drawn by lane 0 of the block");
+    for (long long g = blockIdx.x;;) {
+        const long long t = g * 8 + (threadIdx.x >> 3);
         const bool alive = t < n_items;
         if (!__ballot(alive)) break;  // wave-uniform exit
+        {  // the next group, drawn now so that the atomic's round trip hides under this group's walk
+            unsigned int nx = 0;
+            if (threadIdx.x == 0) nx = atomicAdd(work, 1u);
+            g = (long long) gridDim.x + (long long) (unsigned int) __builtin_amdgcn_readfirstlane((int) nx);
+        }
         const long long i = q_begin + (alive ? (list ? (long long) list[t] : t) : 0);
         const SPoint q = qsp[i];
         const double qx = q.x, qy = q.y, qz = q.z;
-        unsigned int n_open = 0, n_scan = 0;  // nodes opened / leaf cells scanned by this octet (profiling counters, `dbg`)
+        unsigned int n_open = 0, n_scan = 0;  // nodes opened / point runs scanned by this octet (profiling counters, `dbg`)
         unsigned long long n_pts = 0;
         double best = INFINITY;
         long long best_i = 0x7fffffffffffffffLL;
@@ -582,37 +598,40 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
         } else if (use_bound && alive) {
             best = d2_out[i];  // caller's upper bound (me_nn_points_bounded): only closer points are of interest
         }
-        // scan of one run of sorted points [jb, je) (a leaf cell) by the octets flagged `go` (the shuffles run converged over
-        // the whole wave)
+        // Per-LANE running best over every scan of this query (round 4, as k_nn_far does): the octet-wide (distance, index)
+        // butterfly is paid once per query, not once per scanned run; between scans the walk only needs the pruning bound, an
+        // upper bound of the octet's minimum: the lanes' bests rounded UP to FP32 and min-reduced with three DPP moves.
+        double lb = best;
+        long long li = best_i;
+        double bound = best;  // pruning bound: min(best found, tightest box upper bound seen)
+        // scan of one run of sorted points [jb, je) by the octets flagged `go`, sixteen points per trip (two independent loads
+        // per lane in flight; clamped addresses keep them unconditional)
         auto scan_points = [&](bool go, long long jb, long long je) {
             if (!go) jb = je = 0;
             n_scan += go ? 1u : 0u;
             n_pts += (unsigned long long) (je - jb);
-            double lb = best;
-            long long li = best_i;
-            for (long long j = jb + sub; __ballot(j < je); j += 8) {
-                if (j < je) {
-                    const SPoint p = rsp[j];
-                    const double d = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
-                    if (d < lb || (d == lb && p.idx < li)) {  // ties -> smallest reference index (as the oracle)
-                        lb = d;
-                        li = p.idx;
-                    }
+            for (long long j = jb + sub; __ballot(j < je); j += 16) {
+                const long long j1 = j + 8;
+                const long long last = je > 0 ? je - 1 : 0;
+                const SPoint p0 = rsp[j < je ? j : last];
+                const SPoint p1 = rsp[j1 < je ? j1 : last];
+                const double d0 = dist2_exact(qx, qy, qz, p0.x, p0.y, p0.z);
+                const double d1 = dist2_exact(qx, qy, qz, p1.x, p1.y, p1.z);
+                if (j < je && (d0 < lb || (d0 == lb && p0.idx < li))) {  // ties -> smallest reference index (as the oracle)
+                    lb = d0;
+                    li = p0.idx;
+                }
+                if (j1 < je && (d1 < lb || (d1 == lb && p1.idx < li))) {
+                    lb = d1;
+                    li = p1.idx;
                 }
             }
-            auto stage = [&](double od, long long oi) {
-                if (od < lb || (od == lb && oi < li)) {
-                    lb = od;
-                    li = oi;
-                }
-            };
-            stage(octet_partner_d<0>(lb), octet_partner_ll<0>(li));
-            stage(octet_partner_d<1>(lb), octet_partner_ll<1>(li));
-            stage(octet_partner_d<2>(lb), octet_partner_ll<2>(li));
-            if (go) {
-                best = lb;
-                best_i = li;
-            }
+            // (squared distances are >= 0: their FP32 images order like their bit patterns)
+            int m = __float_as_int(__double2float_ru(lb));
+            m = min(m, octet_partner_i<0>(m));
+            m = min(m, octet_partner_i<1>(m));
+            m = min(m, octet_partner_i<2>(m));
+            if (go) bound = fmin(bound, (double) __int_as_float(m));
         };
         bool far_flag = false;
         if (L == 0) {
@@ -621,29 +640,44 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
             // Walk state: level l = the level of the node whose CHILDREN (level l-1) are being considered.  Lane `sub` owns
             // child `sub`: after the one burst that fetches the <= 8 child records (+ the `begin` of the record after
             // each, i.e. the child's end) it keeps, per level, the child's lower bound (a float rounded DOWN: still a
-            // lower bound) and its [begin, end) in a block-local LDS cache.  Returning to a parent therefore costs no memory
-            // round trip at all (the first version re-fetched the parent's header and its children and recomputed the
-            // bounds: three dependent round trips per node visited), and a descent costs one.  These few hundred far
-            // queries are pure pointer chasing: the kernel's time IS the longest chain of dependent fetches.
+            // lower bound) and its [begin, end) on the level below in a block-local LDS cache.  Returning to a parent therefore
+            // costs no memory round trip at all, and a descent costs one.
+            // Round 4: the octets of a wavefront that DESCEND in an iteration issue their child-record loads BEFORE the other
+            // octets scan their leaf cells, so the iteration waits for one round trip, not two; the block is one wavefront with
+            // 6 KB of cache (20 wavefronts per CU in flight instead of 16).
             float *c_lb = reinterpret_cast<float *>(s_dyn) + (threadIdx.x >> 3) * lv * 8;  // [level][8]
             unsigned int *c_beg = s_dyn + (kNn1Block / 8) * lv * 8 + (threadIdx.x >> 3) * lv * 9;  // [level][9]: child begins + the end of the last one
             unsigned long long taken_lo = 0, taken_hi = 0;  // "children already entered" per level: levels 1..8 / 9..16
-            double bound = best;  // pruning bound: min(best found, tightest box upper bound seen)
             bool walking = alive;
             int l = L;
-            // fetch the children [cb, ce) of a node onto level l's cache line; lane `sub` bounds child `sub`
-            auto open_node = [&](bool go, int lev, long long cb, long long ce) {
-                if (!go) {  // (an idle octet's cb / ce may be POINT indices of the leaf it has just scanned)
+            // the children [cb, ce) of a node, for level lev's cache line; lane `sub` bounds child `sub`.  Two halves: the loads
+            // (issued early) and the bounds (after whatever else the iteration has to wait for)
+            struct Fetched {
+                float4 a, bb;
+                unsigned int nxt;
+            };
+            auto open_load = [&](bool go, int lev, long long cb) {
+                if (!go) {  // (an idle octet's cb may be a POINT index of the leaf it is about to scan)
+                    cb = 0;
+                    lev = 1;
+                }
+                const long long at = s_off[lev - 1] + cb + sub;
+                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(nodes + at);
+                // (the buffer has 8 records of slack: short groups are masked, not skipped)
+                Fetched f;
+                f.a = g[0];
+                f.bb = g[1];
+                f.nxt = nodes[at + 1].begin;
+                return f;
+            };
+            auto open_finish = [&](bool go, int lev, long long cb, long long ce, const Fetched &ft) {
+                if (!go) {
                     cb = ce = 0;
                     lev = 1;
                 }
                 const int cnt = (int) (ce - cb);
                 n_open += go ? 1u : 0u;
-                const float4 *__restrict__ g = reinterpret_cast<const float4 *>(nodes + s_off[lev - 1] + cb + sub);
-                // (the buffer has 8 records of slack: short groups are masked, not skipped)
-                const float4 a = g[0], bb = g[1];
-                const unsigned int nxt = nodes[s_off[lev - 1] + cb + sub + 1].begin;
-                const float f[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
+                const float f[6] = {ft.a.x, ft.a.y, ft.a.z, ft.a.w, ft.bb.x, ft.bb.y};
                 const bool mine = go && sub < cnt;
                 // every child box also yields an UPPER bound on the answer (some point lies inside it, no farther than
                 // its farthest corner): keeps the depth-first walk from sweeping a wide region on a loose `best`
@@ -652,13 +686,15 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                 if (go) {
                     bound = fmin(bound, ub);
                     c_lb[lev * 8 + sub] = mine ? __double2float_rd(lbd) : INFINITY;
-                    c_beg[lev * 9 + sub] = __float_as_uint(bb.z);  // ONode::begin
-                    if (sub == 7 || sub == cnt - 1) c_beg[lev * 9 + sub + 1] = nxt;
+                    c_beg[lev * 9 + sub] = __float_as_uint(ft.bb.z);  // ONode::begin
+                    if (sub == 7 || sub == cnt - 1) c_beg[lev * 9 + sub + 1] = ft.nxt;
                 }
             };
             {
                 const ONode *__restrict__ root = nodes + s_off[L];
-                open_node(walking, L, root[0].begin, root[1].begin);
+                const long long rb = root[0].begin, re = root[1].begin;
+                const Fetched ft = open_load(walking, L, rb);
+                open_finish(walking, L, rb, re, ft);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -670,19 +706,16 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                 }
                 const unsigned int tk = (l <= 8) ? (unsigned int) (taken_lo >> (8 * (l - 1))) & 0xffu
                                                  : (unsigned int) (taken_hi >> (8 * (l - 9))) & 0xffu;
-                const double lbd = walking ? (double) c_lb[l * 8 + sub] : INFINITY;
-                const bool ok = walking && !((tk >> sub) & 1u) && lbd <= bound;  // <=: ties may hold a smaller index
-                double kd = ok ? lbd : INFINITY;
-                int kc = ok ? sub : 8;
-                auto pick = [&](double od, int oc) {
-                    if (od < kd || (od == kd && oc < kc)) {
-                        kd = od;
-                        kc = oc;
-                    }
-                };
-                pick(octet_partner_d<0>(kd), octet_partner_i<0>(kc));
-                pick(octet_partner_d<1>(kd), octet_partner_i<1>(kc));
-                pick(octet_partner_d<2>(kd), octet_partner_i<2>(kc));
+                const float lbf = walking ? c_lb[l * 8 + sub] : INFINITY;
+                const bool ok = walking && !((tk >> sub) & 1u) && (double) lbf <= bound;  // <=: ties may hold a smaller index
+                // nearest admissible child: (lower bound, child) packed so that one integer minimum picks it (bounds are >= 0:
+                // their bit patterns order like the values)
+                unsigned long long key = ok ? (((unsigned long long) __float_as_uint(lbf)) << 3) | (unsigned int) sub : ~0ULL;
+                auto kmin = [&](unsigned long long o) { key = o < key ? o : key; };
+                kmin((unsigned long long) octet_partner_ll<0>((long long) key));
+                kmin((unsigned long long) octet_partner_ll<1>((long long) key));
+                kmin((unsigned long long) octet_partner_ll<2>((long long) key));
+                const int kc = key == ~0ULL ? 8 : (int) (key & 7u);
                 bool go_leaf = false, go_down = false;
                 long long cb = 0, ce = 0;
                 if (walking) {
@@ -704,17 +737,32 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                         }
                     }
                 }
-                if (__ballot(go_leaf)) {
-                    scan_points(go_leaf, cb, ce);
-                    bound = fmin(bound, best);
-                }
-                if (__ballot(go_down)) {
-                    open_node(go_down, go_down ? l : 1, cb, ce);
+                const bool any_down = __ballot(go_down) != 0ULL;
+                Fetched ft;
+                ft.a = ft.bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                ft.nxt = 0u;
+                if (any_down) ft = open_load(go_down, go_down ? l : 1, cb);
+                if (__ballot(go_leaf)) scan_points(go_leaf, cb, ce);
+                if (any_down) {
+                    open_finish(go_down, go_down ? l : 1, cb, ce, ft);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
             }
             far_flag = far;
+        }
+        {  // the query's answer: exact minimum over the octet's lanes, ties -> smallest reference index
+            auto stage = [&](double od, long long oi) {
+                if (od < lb || (od == lb && oi < li)) {
+                    lb = od;
+                    li = oi;
+                }
+            };
+            stage(octet_partner_d<0>(lb), octet_partner_ll<0>(li));
+            stage(octet_partner_d<1>(lb), octet_partner_ll<1>(li));
+            stage(octet_partner_d<2>(lb), octet_partner_ll<2>(li));
+            best = lb;
+            best_i = li;
         }
         {  // abandoned walks go to the far list (wave-aggregated append)
             const unsigned long long fm = __ballot(far_flag && sub == 0);
@@ -729,14 +777,35 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
         if (alive && sub == 0) {
             d2_out[i] = best;
             idx_out[i] = (int) best_i;
-            if (dbg) {  // (me_timer_get "nn1_opened" / "nn1_scans" / "nn1_points" / "nn1_max_opened"; only while timers are on)
-                atomicAdd(&dbg[0], (unsigned long long) n_open);
-                atomicAdd(&dbg[1], (unsigned long long) n_scan);
-                atomicAdd(&dbg[2], n_pts);
-                atomicMax(&dbg[3], (unsigned long long) (n_open + n_scan));
-            }
+            w_open += n_open;  // (profiling counters: summed per wavefront, see the end of the kernel)
+            w_scan += n_scan;
+            w_pts += n_pts;
+            w_max = max(w_max, n_open + n_scan);
         }
     }  // grid-stride loop over octets
+    if (dbg) {
+        // me_timer_get "nn1_opened" / "nn1_scans" / "nn1_points" / "nn1_max_opened" (only while timers are on).  ONE atomic per
+        // wavefront and counter: an atomic per query — 470 k of them on four addresses, serialised in one L2 channel — cost the
+        // instrumented launch 0.8 ms of its 1.65 (round 4; the untimed steps never paid it)
+        for (int m = 8; m < 64; m <<= 1) {
+            w_open += __shfl_xor(w_open, m, 64);
+            w_scan += __shfl_xor(w_scan, m, 64);
+            w_pts += __shfl_xor(w_pts, m, 64);
+            w_max = max(w_max, (unsigned int) __shfl_xor((int) w_max, m, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned long long dt = wall_clock64() - t_wave0;  // "nn1_wave_max_10ns" / "nn1_wave_sum_10ns" / "nn1_waves"
+            if (w_open | w_scan) {
+                atomicAdd(&dbg[0], w_open);
+                atomicAdd(&dbg[1], w_scan);
+                atomicAdd(&dbg[2], w_pts);
+                atomicMax(&dbg[3], (unsigned long long) w_max);
+                atomicMax(&dbg[8], dt);
+                atomicAdd(&dbg[9], dt);
+                atomicAdd(&dbg[11], 1ULL);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1144,7 +1213,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
     } else if (e > b) {
         const unsigned int nb = (unsigned int) (((e - b + 255) / 256 + 7) / 8 * 8);  // multiple of 8 (XCD chunking)
         ME_CHECK(ctx, q.nn_list.ensure((size_t) (e - b) * 4 + 64));
-        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));  // [0] unresolved-list length, [1] far-list length, [2] first-pass list
+        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));  // [0] unresolved-list length, [1] far-list length, [4] k_nn1's group counter, [2] first-pass list
         FrameView fr{r.origin[0], r.origin[1], r.origin[2], r.fine_h};
         // Cascade: fine grid -> (what it leaves) every coarser level up to the radius grid -> (what that leaves) the octree.
         const GridView *levels[Cloud::kMaxMid + 1];
@@ -1206,14 +1275,15 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         }
         {
             // the list length stays on the device: a fixed grid strides over it (no host round trip)
-            const unsigned int nbf = (unsigned int) std::min<long long>(2LL * nb, 256 * 32);
+            // one octet per listed query, at most one resident wavefront per slot of the chip (8 octets per block)
+            const unsigned int nbf = (unsigned int) std::min<long long>((e - b + 7) / 8, 256 * 4 * kNn1Waves);
             // (the far list can hold every query of the list: sized like it)
             ME_CHECK(ctx, ctx->nn_far.ensure((size_t) (e - b) * 4 + 64));
             {
                 TimerScope ts(ctx, "nn1");
                 hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
                                    r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0,
-                                   ctx->timers_on ? ctx->nn1_dbg() : nullptr, ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap());
+                                   ctx->timers_on ? ctx->nn1_dbg() : nullptr, ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4);
             }
             {
                 TimerScope ts(ctx, "nn_far");
@@ -1277,12 +1347,12 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
         ME_CHECK(ctx, ctx->nn_far.ensure((size_t) m * 4 + 64));
         ME_CHECK(ctx, ctx->red.ensure(64));
         unsigned int *d_cnt = ctx->red.as<unsigned int>();
-        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+        ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));  // ([4]: k_nn1's group counter)
         TimerScope ts(ctx, "nn1");
-        hipLaunchKernelGGL(k_nn1, dim3(std::min<unsigned int>(2 * nb, 256 * 32)), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream,
+        hipLaunchKernelGGL(k_nn1, dim3((unsigned int) std::min<long long>((m + 7) / 8, 256 * 4 * kNn1Waves)), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream,
                            qs.as<SPoint>(), 0LL, m, r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
                            (const unsigned int *) nullptr, bounded ? 1 : 0, ctx->timers_on ? ctx->nn1_dbg() : nullptr,
-                           ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap());
+                           ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4);
         hipLaunchKernelGGL(k_nn_far, dim3(kFarGrid), dim3(256), 0, ctx->stream, qs.as<SPoint>(), 0LL, r.sp.as<SPoint>(), r.oct, d2_device,
                            qi.as<int>(), ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn_far_leaf(), ctx->timers_on ? ctx->nn1_dbg() : nullptr);
     }
