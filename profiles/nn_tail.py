@@ -27,7 +27,7 @@ with Engine(0) as eng:
             ms, cnt = eng.timer(t)
             rec[t + "_ms"] = ms
         for c in ("nn_fallback_queries", "nn1_opened", "nn1_scans", "nn1_points", "nn1_max_opened", "nn1_far", "nn1_far_opened",
-                  "nn1_far_points", "nn1_far_max", "nn1_wave_max_10ns", "nn1_wave_sum_10ns", "nn1_max_run", "nn1_waves"):
+                  "nn1_far_points", "nn1_far_max", "nn1_wave_max_10ns", "nn1_wave_sum_10ns", "nn1_waves"):
             rec[c] = eng.timer(c)[1]
         eng.timers_enable(False)
         out[name] = rec
