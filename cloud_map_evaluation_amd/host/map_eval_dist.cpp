@@ -34,6 +34,8 @@
 #include <iomanip>
 #include <iostream>
 #include <limits>
+#include <utility>
+#include <vector>
 
 #include "dist_comm.hpp"
 #include "map_eval.h"
@@ -224,6 +226,16 @@ int MapEval::processDist(double t_loaded) {
     const int rank = comm_->rank, world = comm_->world;
     const size_t n_e = map_3d_->size(), n_g = gt_3d_->size();
     t1 = t_loaded;
+    // wall-clock split of the run (rank 0 prints it at the end): a phase ends when its last call has returned — the C ABI's
+    // calls return their scalars, so nothing of a phase is still in flight at its mark
+    TicToc3 phase_clock;
+    double phase_last = 0.0;
+    std::vector<std::pair<const char *, double>> phases;
+    auto mark = [&](const char *name) {
+        const double now = phase_clock.toc();
+        phases.emplace_back(name, now - phase_last);
+        phase_last = now;
+    };
     // ---- the map in its final pose: initial_matrix (:1206), or the registration result (performRegistration, :191-237) ----
     int gate_mode = ME_GATE_LE_UNSQUARED;  // (:1219, sic) — the ICP path gates d2 < max^2 (:1168)
     if (!param_.evaluate_using_initial_) {
@@ -243,6 +255,7 @@ int MapEval::processDist(double t_loaded) {
     if (const char *fr = std::getenv("MAPEVAL_TEST_FAIL_RANK"))
         if (std::atoi(fr) == rank) fail("MAPEVAL_TEST_FAIL_RANK: this rank was told to fail");
     if (!comm_->all_ok(last_error.empty())) return fail("a rank failed before the exchange: stopping");
+    mark(param_.evaluate_using_initial_ ? "pose" : "registration");
     // ---- this rank's piece of each cloud (distributed input) ----
     auto piece = [&](size_t n, size_t &i0, size_t &i1) {
         i0 = (size_t) ((unsigned long long) n * (unsigned long long) rank / (unsigned long long) world);
@@ -289,6 +302,7 @@ int MapEval::processDist(double t_loaded) {
             if (!(cuts[(size_t) k] > cuts[(size_t) k - 1])) cuts[(size_t) k] = std::nextafter(cuts[(size_t) k - 1], INFINITY);
         }
     }
+    mark("cuts");
     const double halo = std::max(1.0, 1.0001 * param_.nn_radius_);  // MME needs halo >= nn_radius; 1 m covers the usual 1-NN reach
     // ---- one-shot halo exchange, then the slab upload (what arrived IS slab + halo: no filter pass) ----
     medist::DevMem recv_e, recv_g;
@@ -296,9 +310,11 @@ int MapEval::processDist(double t_loaded) {
     int64_t got_e = 0, got_g = 0;
     if (exchangeCloud(map_3d_->points_, e0, e1, nullptr, axis, cuts, halo, recv_e, tags_e, &got_e) != 0) return -1;
     if (exchangeCloud(gt_3d_->points_, g0, g1, nullptr, axis, cuts, halo, recv_g, tags_g, &got_g) != 0) return -1;
+    mark("halo_exchange");
     DIST_TRY(me_set_slab(ctx_, axis, cuts[(size_t) rank], cuts[(size_t) rank + 1], halo));
     DIST_TRY(me_upload_slab_device(ctx_, ME_SLOT_EST, recv_e.as<double>(), got_e, param_.nn_radius_));
     DIST_TRY(me_upload_slab_device(ctx_, ME_SLOT_GT, recv_g.as<double>(), got_g, param_.nn_radius_));
+    mark("index");
     if (rank == 0)
         std::cout << "INFO: multi-GPU run: " << world << " rank(s) over " << comm_->name() << ", slabs along axis " << axis << ", halo "
                   << halo << " m; rank 0 holds " << got_e << " + " << got_g << " of " << n_e << " + " << n_g << " points" << std::endl;
@@ -310,6 +326,7 @@ int MapEval::processDist(double t_loaded) {
             me_upload_cloud(render_ctx_, ME_SLOT_GT, gt_3d_->points_.data(), (int64_t) n_g, nullptr, param_.nn_radius_) != ME_OK)
             return fail(me_last_error(render_ctx_));
     }
+    mark("render_context");
     TicToc3 clock;
 
     // ---- MME (computeMME, :149-189): est k >= 10, gt k >= 5 ----
@@ -352,6 +369,7 @@ int MapEval::processDist(double t_loaded) {
         }
     }
     t2 = t1 + clock.toc();
+    mark("mme");
 
     // ---- AC / COM / CD (calculateMetricsWithInitialMatrix, :1204-1260) ----
     const int dirs[2][2] = {{ME_SLOT_EST, ME_SLOT_GT}, {ME_SLOT_GT, ME_SLOT_EST}};
@@ -444,6 +462,7 @@ int MapEval::processDist(double t_loaded) {
         if (render_ctx_ && me_set_nn_result(render_ctx_, ME_SLOT_EST, ME_SLOT_GT, d2_all.data()) != ME_OK) return fail(me_last_error(render_ctx_));
     }
     t5 = t4 = t3 = t1 + clock.toc();
+    mark("nn_metrics");
 
     // ---- AWD / CDF / SCS (calculateVMD, :240-390): Chan merge of every rank's voxel partials, then the replicated tables ----
     for (int s = 0; s < 2; ++s) {
@@ -462,10 +481,17 @@ int MapEval::processDist(double t_loaded) {
     }
     calculateVMD(/*tables_ready=*/true, /*write_files=*/rank == 0);
     if (!last_error.empty()) return -1;
+    mark("voxel_awd_scs");
     if (rank == 0 && param_.save_immediate_result_) {
         std::swap(ctx_, render_ctx_);  // me_render_distance on the whole-cloud context
         saveRegistrationResults();
         std::swap(ctx_, render_ctx_);
+        mark("result_files");
+    }
+    if (rank == 0) {
+        std::cout << "INFO: multi-GPU phases on rank 0 [ms]:";
+        for (const auto &ph : phases) std::cout << " " << ph.first << "=" << std::fixed << std::setprecision(1) << ph.second;
+        std::cout << " total=" << phase_clock.toc() << std::defaultfloat << std::setprecision(6) << std::endl;
     }
     return last_error.empty() ? 0 : -1;
 }

@@ -210,6 +210,7 @@ def test_multi_gpu_host_one_rank_through_rccl_equals_single_gpu(tmp_path, identi
     single, _ = _run_host(tmp_path, "single", est, gt, T)
     forced, out = _run_host(tmp_path, "forced", est, gt, T, env={"MAPEVAL_FORCE_DIST": "1"})
     assert "multi-GPU run: 1 rank(s) over rccl" in out
+    assert "multi-GPU phases on rank 0 [ms]:" in out and " halo_exchange=" in out and " total=" in out  # (the run times itself)
     if identity:
         _same_outputs(single, forced)
     else:
