@@ -1,8 +1,11 @@
 #!/usr/bin/env python
 """Strong-scaling ESTIMATE on ONE GPU for the distributed-input step (dist.suite_step_dist): every rank of an N-rank job is
 run one after another with a stand-in process group whose collectives return what the real ones would (the all-to-all
-delivers the points the other ranks would have sent — precomputed, untimed; all-reduces are identities; all-gathers repeat
-the rank's own message), so a rank's time is the compute + host work it would spend between collectives.  RCCL latency of
+delivers the points the other ranks would have sent — precomputed, untimed; all-reduces are identities; all-gathers deliver
+what the other ranks DID contribute in an untimed recording pass of every rank's step (round 4 — until then they repeated the
+rank's own message, which made every rank search its own open queries world - 1 more times in the cross-rank step: queries next
+to its own slab, the ones its tree cannot prune, instead of the other ranks' which it mostly prunes at the root), so a rank's
+time is the compute + host work it would spend between collectives.  RCCL latency of
 the ~10 small collectives (~0.3-0.5 ms per step) and the halo payload (2 x 24 B x N / world^2 per link: < 0.3 ms at 8 ranks
 over xGMI) are NOT included.  usage: python profiles/emulate_scaling.py [points] [--workload campus|c4_multisession] [--worlds 1,2,4,8]"""
 import json
@@ -20,9 +23,11 @@ class FakeDist:
     class ReduceOp:
         SUM, MAX, MIN = "sum", "max", "min"
 
-    def __init__(self, world, rank, recv_counts=None, recv_points=None):
+    def __init__(self, world, rank, recv_counts=None, recv_points=None, record=None, replay=None):
         self.world, self.rank = world, rank
         self.recv_counts, self.recv_points = recv_counts, recv_points
+        self.record, self.replay = record, replay  # {gather index within the step: {rank: message}}
+        self.n_gather = 0
 
     def is_initialized(self):
         return True
@@ -37,8 +42,17 @@ class FakeDist:
         return None
 
     def all_gather(self, parts, buf):
-        for p in parts:
-            p.copy_(buf)
+        idx = self.n_gather
+        self.n_gather += 1
+        if self.record is not None:
+            self.record.setdefault(idx, {})[self.rank] = buf.clone()
+        for k, p in enumerate(parts):
+            src = buf
+            if self.replay is not None and k != self.rank:
+                r = self.replay.get(idx, {}).get(k)
+                if r is not None and r.shape == buf.shape and r.dtype == buf.dtype:
+                    src = r  # (a message of another shape — a rank whose step took another branch — falls back to the own copy)
+            p.copy_(src)
 
     def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
         if out.dtype == torch.int64:
@@ -68,19 +82,30 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
             # what the halo exchange delivers to every rank (untimed): the cuts are those every rank computes
             axis, cuts = medist.dist_slab_cuts(gt, None, dev, world, est_part=est)
             packs = [[eng.halo_pack(p, axis, cuts, halo) for p in pc] for pc in pieces]  # [src][cloud] -> (points, counts)
+        recorded = {}
+
+        def make_fd(rank, record, replay):
+            rc = torch.tensor([[packs[s][c][1][rank] for c in range(2)] for s in range(world)], dtype=torch.int64, device=dev)
+            segs = []
+            for s in range(world):
+                for c in range(2):
+                    pts, cnts = packs[s][c]
+                    o = sum(cnts[:rank])
+                    segs.append(pts[o:o + cnts[rank]])
+            return FakeDist(world, rank, rc, torch.cat(segs), record=record, replay=replay)
+
+        if world > 1:
+            GLOBAL["cuts"] = (axis, cuts)
+            medist.dist_slab_cuts = _patched_cuts
+            for rank in range(world):
+                fd = make_fd(rank, recorded, None)
+                medist.suite_step_dist(eng, fd, dev, pieces[rank][0], pieces[rank][1], P, rank, world, True, halo=halo, overlap=OVERLAP)
+            torch.cuda.synchronize()
         for rank in range(world):
             if world == 1:
                 fd, args = None, None
             else:
-                rc = torch.tensor([[packs[s][c][1][rank] for c in range(2)] for s in range(world)], dtype=torch.int64, device=dev)
-                segs = []
-                for s in range(world):
-                    for c in range(2):
-                        pts, cnts = packs[s][c]
-                        o = sum(cnts[:rank])
-                        segs.append(pts[o:o + cnts[rank]])
-                fd = FakeDist(world, rank, rc, torch.cat(segs))
-
+                fd = make_fd(rank, None, recorded)
                 GLOBAL["cuts"] = (axis, cuts)
                 medist.dist_slab_cuts = _patched_cuts
             best, best_t = 1e9, None
@@ -88,6 +113,8 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
                 eng.timers_enable(rep == 2)
                 if rep == 2:
                     eng.timers_reset()
+                if fd is not None:
+                    fd.n_gather = 0
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 if world == 1:
