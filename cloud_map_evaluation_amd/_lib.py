@@ -18,7 +18,7 @@ ME_GATE_LT_SQUARED = 1
 # every symbol include/mapeval_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "me_create", "me_destroy", "me_twin", "me_last_error", "me_version", "me_set_shard", "me_set_slab",
-    "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_patch", "me_nn_fetch", "me_slab_points", "me_set_mme_result", "me_set_nn_result", "me_voxel_partials",
+    "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_points_covered", "me_nn_patch", "me_nn_fetch", "me_slab_points", "me_set_mme_result", "me_set_nn_result", "me_voxel_partials",
     "me_transform_points_device", "me_upload_slab_device", "me_halo_pack_device", "me_halo_pack_tagged_device", "me_voxel_partial_rows_device", "me_voxel_merge_device",
     "me_upload_cloud", "me_upload_cloud_device", "me_cloud_size", "me_download_cloud", "me_voxel_downsample",
     "me_transform_cloud",
@@ -135,6 +135,7 @@ def load():
     L.me_nn_unresolved.argtypes = [vp, C.c_int, dp, dp, C.c_int64, C.POINTER(C.c_int64)]
     L.me_nn_points.argtypes = [vp, C.c_int, dp, C.c_int64, dp]
     L.me_nn_points_bounded.argtypes = [vp, C.c_int, dp, C.c_int64, dp]
+    L.me_nn_points_covered.argtypes = [vp, C.c_int, dp, C.c_int64, dp, C.c_int, dp]
     L.me_nn_patch.argtypes = [vp, C.c_int, dp, C.c_int64]
     L.me_nn_fetch.argtypes = [vp, C.c_int, ip, dp]
     L.me_slab_points.argtypes = [vp, C.c_int, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
@@ -191,7 +192,7 @@ def load():
     L.me_timers_enable.argtypes = [vp, C.c_int]
     L.me_timers_reset.argtypes = [vp]
     L.me_timer_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    for f in ("me_voxel_downsample", "me_transform_cloud", "me_set_slab", "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_patch", "me_nn_fetch", "me_slab_points", "me_set_mme_result", "me_set_nn_result", "me_voxel_partials", "me_set_shard", "me_upload_cloud", "me_upload_cloud_device", "me_download_cloud", "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats",
+    for f in ("me_voxel_downsample", "me_transform_cloud", "me_set_slab", "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_points_covered", "me_nn_patch", "me_nn_fetch", "me_slab_points", "me_set_mme_result", "me_set_nn_result", "me_voxel_partials", "me_set_shard", "me_upload_cloud", "me_upload_cloud_device", "me_download_cloud", "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats",
               "me_nn_partial_sums", "me_nn_sigma_sums", "me_chamfer", "me_mme", "me_voxel_gaussians", "me_awd_scs",
               "me_run_suite", "me_w2_batch", "me_scs_table", "me_timers_enable", "me_timers_reset", "me_timer_get"):
         getattr(L, f).restype = C.c_int

@@ -366,6 +366,14 @@ int me_nn_points_bounded(me_ctx *ctx, int ref_slot, const double *xyz_device, in
     return me::nn_points(ctx, ref_slot, xyz_device, m, d2_inout_device, true);
 }
 
+int me_nn_points_covered(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_inout_device, int axis,
+                         const double *covered_device) {
+    if (!ctx) return ME_ERR_ARG;
+    if (axis < 0 || axis > 2) return ctx->fail(ME_ERR_ARG, "me_nn_points_covered: axis must be 0, 1 or 2");
+    if (m > 0 && !covered_device) return ctx->fail(ME_ERR_ARG, "me_nn_points_covered: covered intervals missing");
+    return me::nn_points(ctx, ref_slot, xyz_device, m, d2_inout_device, true, axis, covered_device);
+}
+
 int me_nn_fetch(me_ctx *ctx, int query_slot, int32_t *idx, double *d2) {
     if (!ctx) return ME_ERR_ARG;
     if (query_slot < 0 || query_slot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");

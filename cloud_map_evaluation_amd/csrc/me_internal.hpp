@@ -312,7 +312,8 @@ int voxel_downsample(me_ctx *ctx, int slot, double voxel_size, long long *n_out)
 int nn_search(me_ctx *ctx, int qslot, int rslot);
 int nn_fetch(me_ctx *ctx, int qslot, int32_t *idx, double *d2);
 int nn_unresolved(me_ctx *ctx, int qslot, double *xyz_device, double *d2_device, long long capacity, long long *count);
-int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, double *d2_device, bool bounded);
+int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, double *d2_device, bool bounded, int cov_axis = 0,
+              const double *cov_device = nullptr);
 int nn_patch(me_ctx *ctx, int qslot, const double *d2_device, long long count);
 int icp_p2p_sums(me_ctx *ctx, int qslot, double max_distance, me_icp_sums *out);
 int nn_partial(me_ctx *ctx, int qslot, double gate, int gate_mode, const double trunc[5], me_nn_partial *out);

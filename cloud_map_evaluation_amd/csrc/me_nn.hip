@@ -39,6 +39,32 @@ __device__ __forceinline__ double box_lower_bound(const float *__restrict__ b, d
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+// Lower bound of the squared distance from q to the points of box b whose coordinate along `axis` lies OUTSIDE [clo, chi) — the
+// interval of that axis the query's owner has already searched completely (its slab + halo, me_nn_points_covered): no point inside
+// it can beat the bound that came with the query, so only the part of a box that sticks out of it counts; a box that lies inside
+// gets +inf.  q itself lies inside the interval (it is owned by that rank).  Monotone operations on the outward-rounded box: still a
+// lower bound.  Without this a rank DISPROVES a far outlier of its neighbour — a ball of metres around the query that reaches across
+// the face — by walking every occupied cell the ball touches on its side, most of them in the strip the owner's halo covers.
+__device__ __forceinline__ double box_lower_bound_cov(const float *__restrict__ b, double qx, double qy, double qz, int axis, double clo,
+                                                      double chi) {
+    double d[3];
+    d[0] = fmax(fmax((double) b[0] - qx, qx - (double) b[3]), 0.0);
+    d[1] = fmax(fmax((double) b[1] - qy, qy - (double) b[4]), 0.0);
+    d[2] = fmax(fmax((double) b[2] - qz, qz - (double) b[5]), 0.0);
+    const double qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+    const double lo = axis == 0 ? (double) b[0] : (axis == 1 ? (double) b[1] : (double) b[2]);
+    const double hi = axis == 0 ? (double) b[3] : (axis == 1 ? (double) b[4] : (double) b[5]);
+    if (qa >= clo && qa < chi) {
+        const double up = hi >= chi ? fmax(lo, chi) - qa : INFINITY;   // the part at or above the interval's upper end
+        const double dn = lo < clo ? qa - fmin(hi, clo) : INFINITY;    // the part below its lower end
+        const double da = fmin(up, dn);
+        if (axis == 0) d[0] = da;
+        else if (axis == 1) d[1] = da;
+        else d[2] = da;
+    }
+    return (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+}
+
 // squared distance to the farthest corner of the box: an upper bound on the distance to ANY point inside it
 // (monotone operations on the outward-rounded box, so it is >= the computed distance of every contained point)
 __device__ __forceinline__ double box_upper_bound(const float *__restrict__ b, double qx, double qy, double qz) {
@@ -551,7 +577,9 @@ __global__ void __launch_bounds__(kNn1Block) __attribute__((amdgpu_waves_per_eu(
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
       OctView oct, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
       const unsigned int *__restrict__ list_count, int use_bound, unsigned long long *__restrict__ dbg,
-      unsigned int *__restrict__ far_list, unsigned int *__restrict__ far_count, int far_cap, unsigned int *__restrict__ work) {
+      unsigned int *__restrict__ far_list, unsigned int *__restrict__ far_count, int far_cap, unsigned int *__restrict__ work,
+      const double *__restrict__ cov, int cov_axis) {
+    // cov: per query [lo, hi) along cov_axis that its owner has searched already (box_lower_bound_cov); nullptr = none
     // work: a zeroed counter.  A wavefront's first group of eight queries is its block index, every further one is drawn from
     // the counter (round 4; one resident wavefront per slot of the chip).  On the bench pair this changed nothing measurable
     // (0.92 -> 0.96 ms: the launch is bound by instruction issue, profiles/EXPERIMENTS.md) — it is kept for lists whose walks
@@ -587,6 +615,11 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
         const long long i = q_begin + (alive ? (list ? (long long) list[t] : t) : 0);
         const SPoint q = qsp[i];
         const double qx = q.x, qy = q.y, qz = q.z;
+        double clo = INFINITY, chi = -INFINITY;  // (empty interval: nothing covered)
+        if (cov && alive) {
+            clo = cov[2 * (i - q_begin)];
+            chi = cov[2 * (i - q_begin) + 1];
+        }
         unsigned int n_open = 0, n_scan = 0;  // nodes opened / point runs scanned by this octet (profiling counters, `dbg`)
         unsigned long long n_pts = 0;
         double best = INFINITY;
@@ -682,7 +715,7 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                 // every child box also yields an UPPER bound on the answer (some point lies inside it, no farther than
                 // its farthest corner): keeps the depth-first walk from sweeping a wide region on a loose `best`
                 const double ub = octet_min(mine ? box_upper_bound(f, qx, qy, qz) : INFINITY);
-                const double lbd = box_lower_bound(f, qx, qy, qz);
+                const double lbd = cov ? box_lower_bound_cov(f, qx, qy, qz, cov_axis, clo, chi) : box_lower_bound(f, qx, qy, qz);
                 if (go) {
                     bound = fmin(bound, ub);
                     c_lb[lev * 8 + sub] = mine ? __double2float_rd(lbd) : INFINITY;
@@ -821,7 +854,8 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
 __global__ void __launch_bounds__(256)
 k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__restrict__ rsp, OctView oct,
          double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ far_list,
-         const unsigned int *__restrict__ far_count, int far_leaf, unsigned long long *__restrict__ dbg) {
+         const unsigned int *__restrict__ far_count, int far_leaf, unsigned long long *__restrict__ dbg,
+         const double *__restrict__ cov, int cov_axis) {
     __shared__ long long s_off[kMaxLevels];
     __shared__ float s_lb[4][kMaxLevels + 1][8];
     __shared__ unsigned int s_beg[4][kMaxLevels + 1][9], s_pb[4][kMaxLevels + 1][9];
@@ -841,6 +875,7 @@ k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__rest
         const long long i = q_begin + (long long) far_list[t];
         const SPoint q = qsp[i];
         const double qx = q.x, qy = q.y, qz = q.z;
+        const double clo = cov ? cov[2 * (i - q_begin)] : INFINITY, chi = cov ? cov[2 * (i - q_begin) + 1] : -INFINITY;
         double best = d2_out[i];
         long long best_i = idx_out[i] >= 0 ? (long long) idx_out[i] : 0x7fffffffffffffffLL;
         double bound = best;
@@ -865,7 +900,7 @@ k_nn_far(const SPoint *__restrict__ qsp, long long q_begin, const SPoint *__rest
                 const float f[6] = {a.x, a.y, a.z, a.w, bb.x, bb.y};
                 const bool mine = lane < cnt;
                 if (mine) ub = box_upper_bound(f, qx, qy, qz);
-                c_lb[lev * 8 + lane] = mine ? __double2float_rd(box_lower_bound(f, qx, qy, qz)) : INFINITY;
+                c_lb[lev * 8 + lane] = mine ? __double2float_rd(cov ? box_lower_bound_cov(f, qx, qy, qz, cov_axis, clo, chi) : box_lower_bound(f, qx, qy, qz)) : INFINITY;
                 c_beg[lev * 9 + lane] = __float_as_uint(bb.z);
                 c_pb[lev * 9 + lane] = pbegin[at];
                 if (lane == 7 || lane == cnt - 1) {
@@ -1283,13 +1318,14 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
                 TimerScope ts(ctx, "nn1");
                 hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
                                    r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0,
-                                   ctx->timers_on ? ctx->nn1_dbg() : nullptr, ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4);
+                                   ctx->timers_on ? ctx->nn1_dbg() : nullptr, ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4,
+                                   (const double *) nullptr, 0);
             }
             {
                 TimerScope ts(ctx, "nn_far");
                 hipLaunchKernelGGL(k_nn_far, dim3(kFarGrid), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, r.sp.as<SPoint>(), r.oct,
                                    q.nn_d2.as<double>(), q.nn_idx.as<int>(), ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn_far_leaf(),
-                                   ctx->timers_on ? ctx->nn1_dbg() : nullptr);
+                                   ctx->timers_on ? ctx->nn1_dbg() : nullptr, (const double *) nullptr, 0);
             }
         }
         if (ctx->timers_on) {  // fallback share, for the bench report
@@ -1328,7 +1364,8 @@ int nn_unresolved(me_ctx *ctx, int qslot, double *xyz_device, double *d2_device,
     return ME_OK;
 }
 
-int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, double *d2_device, bool bounded) {
+int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, double *d2_device, bool bounded, int cov_axis,
+              const double *cov_device) {
     if (rslot < 0 || rslot > 1 || m < 0 || (m > 0 && (!xyz_device || !d2_device))) return ctx->fail(ME_ERR_ARG, "me_nn_points: bad argument");
     Cloud &r = ctx->cloud[rslot];
     if (!r.uploaded) return ctx->fail(ME_ERR_STATE, "me_nn_points: reference cloud not uploaded");
@@ -1352,9 +1389,9 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
         hipLaunchKernelGGL(k_nn1, dim3((unsigned int) std::min<long long>((m + 7) / 8, 256 * 4 * kNn1Waves)), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream,
                            qs.as<SPoint>(), 0LL, m, r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
                            (const unsigned int *) nullptr, bounded ? 1 : 0, ctx->timers_on ? ctx->nn1_dbg() : nullptr,
-                           ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4);
+                           ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4, cov_device, cov_axis);
         hipLaunchKernelGGL(k_nn_far, dim3(kFarGrid), dim3(256), 0, ctx->stream, qs.as<SPoint>(), 0LL, r.sp.as<SPoint>(), r.oct, d2_device,
-                           qi.as<int>(), ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn_far_leaf(), ctx->timers_on ? ctx->nn1_dbg() : nullptr);
+                           qi.as<int>(), ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn_far_leaf(), ctx->timers_on ? ctx->nn1_dbg() : nullptr, cov_device, cov_axis);
     }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());

@@ -496,7 +496,7 @@ def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, wor
             lane.est_ready.set()
         tr.mark("upload_est")
         res = _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_loc, lane,
-                                 (axis, cuts[rank], cuts[rank + 1], halo), tr)
+                                 (axis, cuts[rank], cuts[rank + 1], halo), tr, cuts=cuts)
         tr.dump(rank)
         return res
     except BaseException:
@@ -522,16 +522,20 @@ def _hp_stream(device):
 _CROSS_CAP = 4096  # open queries per direction and rank the folded all-gather carries (overflow: exact-size fallback)
 
 
-def _pad_rows(t, rows: int, width: int, device):
+def _pad_rows(t, rows: int, width: int, device, bound_pad: bool = False):
+    """t padded with zero rows to `rows` rows; bound_pad: the last column of the padding is -1 (an open-query message: a bound no
+    squared distance beats, the padded slots are pruned at the root of every tree)."""
     import torch
 
     out = torch.zeros((rows, width), dtype=torch.float64, device=device)
+    if bound_pad:
+        out[:, width - 1] = -1.0
     if t is not None and t.shape[0]:
         out[:t.shape[0]] = t.to(device)
     return out
 
 
-def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_loc, lane, slab, tr=None):
+def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, n_loc, lane, slab, tr=None, cuts=None):
     import torch
 
     tr = tr or _Trace()
@@ -576,7 +580,7 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         table = head.to(torch.int64).cpu()
         allq = None
     else:
-        msg = torch.cat([head] + [_pad_rows(mineq[i][:cap] if mineq[i] is not None else None, cap, 4, comm_device) for i in range(2)])
+        msg = torch.cat([head] + [_pad_rows(mineq[i][:cap] if mineq[i] is not None else None, cap, 4, comm_device, bound_pad=True) for i in range(2)])
         parts = [torch.empty_like(msg) for _ in range(world)]
         dist.all_gather(parts, msg)
         allq = torch.stack(parts)                                 # (world, 1 + 2 cap, 4)
@@ -586,28 +590,54 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     n_cross = int(table[:, 0].sum() + table[:, 1].sum())
     if not single and n_cross > 0:
         cmax = [int(table[:, 0].max()), int(table[:, 1].max())]
-        if max(cmax) > cap:  # overflow: the exact-size gather of round 2
+        if max(cmax) > cap:  # overflow: the exact-size gather of round 2, answered rank by rank
             msg = torch.cat([_pad_rows(mineq[i], cmax[i], 4, comm_device) for i in range(2)])
             parts = [torch.empty_like(msg) for _ in range(world)]
             dist.all_gather(parts, msg)
             allq = torch.stack(parts)
             offs = [0, cmax[0]]
+            d2 = torch.full(allq.shape[:2], float("inf"), dtype=torch.float64, device=comm_device)
+            for i, (q, r) in enumerate(dirs):
+                base = offs[i]
+                sel = [(k, int(table[k, i])) for k in range(world) if k != rank and int(table[k, i]) > 0]
+                if sel:
+                    qs = torch.cat([allq[k, base:base + c] for k, c in sel])
+                    ans = eng.nn_points(r, qs[:, :3].contiguous().to(wdev), bound=qs[:, 3].contiguous().to(wdev)).to(comm_device)
+                    o = 0
+                    for k, c in sel:
+                        d2[k, base:base + c] = ans[o:o + c]
+                        o += c
+                if cnt[i]:
+                    d2[rank, base:base + cnt[i]] = allq[rank, base:base + cnt[i], 3]  # the owner's own search is its answer
         else:
+            # Round 4: every slot of the fixed-capacity message is answered in ONE call per direction — the padding and the rank's
+            # own rows carry the bound -1, which no squared distance beats: their walks end at the root of the tree — instead of
+            # slicing the message rank by rank (2 x world slices, concatenations and scatter-backs: ~60 small tensor ops, most
+            # of this phase's 2 ms at 8 ranks; the searches themselves are a few hundred microseconds).
             offs = [1, 1 + cap]
-            cmax = [cap, cap]
-        d2 = torch.full(allq.shape[:2], float("inf"), dtype=torch.float64, device=comm_device)
-        for i, (q, r) in enumerate(dirs):
-            base = offs[i]
-            sel = [(k, int(table[k, i])) for k in range(world) if k != rank and int(table[k, i]) > 0]
-            if sel:
-                qs = torch.cat([allq[k, base:base + c] for k, c in sel])
-                ans = eng.nn_points(r, qs[:, :3].contiguous().to(wdev), bound=qs[:, 3].contiguous().to(wdev)).to(comm_device)
-                o = 0
-                for k, c in sel:
-                    d2[k, base:base + c] = ans[o:o + c]
-                    o += c
-            if cnt[i]:
-                d2[rank, base:base + cnt[i]] = allq[rank, base:base + cnt[i], 3]  # the owner's own search is its answer
+            d2 = allq[:, :, 3].clone()  # every slot starts at its owner's bound (padding: -1; row 0 is the header: unused)
+            # the band of the slab axis every OWNER has searched completely (its slab + halo holds every point of both clouds in
+            # it): the answering rank only looks outside it (me_nn_points_covered)
+            cov = None
+            if cuts is not None and len(cuts) == world + 1:
+                h = float(slab[3])
+                band = torch.tensor([[cuts[k] - h, cuts[k + 1] + h] for k in range(world)], dtype=torch.float64)
+                cov = band[:, None, :].expand(world, cap, 2).reshape(-1, 2).contiguous()
+            for i, (q, r) in enumerate(dirs):
+                base = offs[i]
+                if int(table[:, i].sum()) - cnt[i] <= 0:
+                    continue  # nobody else has an open query in this direction
+                blk = allq[:, base:base + cap]                       # (world, cap, 4)
+                b = blk[:, :, 3].clone()
+                b[rank] = -1.0                                       # the owner's own search is its answer
+                qx = blk[:, :, :3].reshape(-1, 3).contiguous().to(wdev)
+                if cov is not None:
+                    ans = eng.nn_points(r, qx, bound=b.reshape(-1).to(wdev), covered=cov.to(wdev), axis=int(slab[0])).to(comm_device)
+                else:
+                    ans = eng.nn_points(r, qx, bound=b.reshape(-1).to(wdev)).to(comm_device)
+                ans = ans.view(world, cap)
+                ans[rank] = blk[rank, :, 3]
+                d2[:, base:base + cap] = ans
         dist.all_reduce(d2, op=dist.ReduceOp.MIN)
         for i, (q, r) in enumerate(dirs):
             if cnt[i]:

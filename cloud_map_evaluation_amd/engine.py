@@ -393,20 +393,27 @@ class Engine:
                                               C.byref(n)))
         return torch.cat([out, d2[:, None]], 1) if with_d2 else out
 
-    def nn_points(self, ref_slot: int, xyz, bound=None):
+    def nn_points(self, ref_slot: int, xyz, bound=None, covered=None, axis: int = 0):
         """Exact squared distance of arbitrary points (cuda tensor (m,3) float64) to this rank's part of ref_slot;
-        bound (m,): upper bounds -> min(bound, nearest here), far ranks prune at once (me_nn_points_bounded)."""
+        bound (m,): upper bounds -> min(bound, nearest here), far ranks prune at once (me_nn_points_bounded);
+        covered (m,2) + axis: the band [lo, hi) of `axis` each query's owner has searched already (me_nn_points_covered)."""
         import torch
 
         xyz = xyz.to(torch.device("cuda", self.device), torch.float64).contiguous()
+        cov = None
         if bound is None:
             d2 = torch.empty(xyz.shape[0], dtype=torch.float64, device=xyz.device)
             fn = self._L.me_nn_points
         else:
             d2 = bound.to(xyz.device, torch.float64).clone().contiguous()
             fn = self._L.me_nn_points_bounded
+            if covered is not None:
+                cov = covered.to(xyz.device, torch.float64).contiguous()
         torch.cuda.current_stream(xyz.device).synchronize()
-        self._ck(fn(self._ctx, ref_slot, xyz.data_ptr(), int(xyz.shape[0]), d2.data_ptr()))
+        if cov is not None:
+            self._ck(self._L.me_nn_points_covered(self._ctx, ref_slot, xyz.data_ptr(), int(xyz.shape[0]), d2.data_ptr(), int(axis), cov.data_ptr()))
+        else:
+            self._ck(fn(self._ctx, ref_slot, xyz.data_ptr(), int(xyz.shape[0]), d2.data_ptr()))
         return d2
 
     def nn_fetch(self, query_slot: int):

@@ -117,8 +117,18 @@ int me_nn_unresolved(me_ctx *ctx, int query_slot, double *xyz_device, double *d2
 int me_nn_points(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_device);
 /* Same with an upper bound per point: on entry d2_inout_device[i] bounds the answer (+inf = none), on exit it holds
  * min(bound, nearest squared distance here).  A rank whose points are all farther prunes at the root, which is what
- * makes the cross-rank step cheap: the querying rank passes the distance it already has. */
+ * makes the cross-rank step cheap: the querying rank passes the distance it already has.  A NEGATIVE bound marks a slot that
+ * needs no answer (the padding of a fixed-capacity message, a rank's own queries): it comes back unchanged after one step. */
 int me_nn_points_bounded(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_inout_device);
+/* me_nn_points_bounded for queries whose OWNER has already searched everything in a band of one axis: covered_device[2 i],
+ * covered_device[2 i + 1] = [lo, hi) along `axis` — the owner's slab + halo, which holds every point of the cloud in that band
+ * (me_halo_pack_device) — and d2_inout_device[i] = the nearest squared distance found there.  The caller thereby guarantees that no
+ * point inside the band is closer than the bound; this rank then only has to look at the part of its tree OUTSIDE the band.  Same
+ * result as me_nn_points_bounded — min(bound, nearest squared distance here) — for a fraction of the walk: without it a neighbour
+ * disproves a far outlier (a ball of metres reaching across the face) cell by cell inside the strip both ranks hold
+ * (the computeChamferDistance / getDiffRegResult searches have no distance limit, map_eval.cpp:1398-1431, :1100-1110). */
+int me_nn_points_covered(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_inout_device, int axis,
+                         const double *covered_device);
 /* Overwrites the squared distances of the unresolved queries (same order as me_nn_unresolved returned them) with the
  * globally min-reduced values d2_device[count]. */
 int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t count);

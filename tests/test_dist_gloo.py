@@ -248,7 +248,7 @@ class OracleSlabEngine(OracleShardEngine):
             xyz = np.concatenate([xyz, self.d2[q][self.unres[q]][:, None]], 1)
         return torch.from_numpy(xyz)
 
-    def nn_points(self, r, xyz, bound=None):
+    def nn_points(self, r, xyz, bound=None, covered=None, axis=0):  # (covered: a search hint of the real engine, the answer is the same)
         import oracle
         import torch
 
