@@ -373,3 +373,73 @@ def test_transform_cloud_in_place(eng, cube):
     np.testing.assert_allclose(after[0], before[0], rtol=1e-9)
     _, d2 = eng.nn1(0, 1)
     assert np.array_equal(d2, oracle.nn1(gt, est_t)[1])
+
+
+def test_nn1_cascade_over_several_grid_levels_is_bit_exact():
+    """Round 4: on a cloud much denser than the search cell the fine 1-NN grid sits several levels below the radius grid and
+    the queries it cannot settle go through one list pass per coarser level before the octree (me_nn.hip, k_nn_grid<FROM_LIST>).
+    A 3 m patch at ~10^5 pts/m^2 with drifted, noisy, thinned queries and outliers: the passes must have run, and every
+    squared distance and neighbour index must be the oracle's."""
+    import oracle
+
+    from cloud_map_evaluation_amd.engine import Engine
+
+    rng = np.random.default_rng(41)
+    n = 900_000
+    xy = rng.uniform(0.0, 3.0, (n, 2))
+    gt = np.column_stack([xy, 0.05 * np.sin(3.0 * xy[:, 0]) * np.cos(2.0 * xy[:, 1]) + rng.normal(0, 0.002, n)]) + np.array([50.0, -20.0, 2.0])
+    est = gt[rng.choice(n, 400_000, replace=False)].copy()
+    est += np.array([0.012, -0.008, 0.015])                 # drift: a few fine cells
+    est += rng.normal(0, 0.004, est.shape)
+    est[:3000] += rng.normal(0, 0.08, (3000, 3))            # coarser levels
+    est[3000:3400] += rng.normal(0, 1.5, (400, 3))          # octree
+    with Engine(0) as eng:
+        eng.upload(0, est, cell_size=0.1)
+        eng.upload(1, gt, cell_size=0.1)
+        eng.timers_enable(True)
+        eng.timers_reset()
+        idx, d2 = eng.nn1(0, 1)
+        passes = eng.timer("nn_grid2")[1]
+        eng.timers_enable(False)
+        idx_b, d2_b = eng.nn1(1, 0)
+    assert passes >= 1, "the cascade did not run: the scene is not dense enough for a fine grid below the radius grid"
+    oi, od2 = oracle.nn1(gt, est)
+    assert np.array_equal(d2, od2) and np.array_equal(idx, oi)
+    oi, od2 = oracle.nn1(est, gt)
+    assert np.array_equal(d2_b, od2) and np.array_equal(idx_b, oi)
+
+
+def test_borrowed_device_input_gives_the_same_results_and_leaves_the_callers_buffer_alone(campus):
+    """ME_FLAG_BORROW_DEVICE_INPUT (round 4): a device-resident cloud without a transform is read in place.  Same indices,
+    distances, entropies and voxel tables as the copying context, bit for bit; a later transform of the cloud must not write
+    into the caller's tensor."""
+    import torch
+
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, gt = campus
+    dev = torch.device("cuda", 0)
+    e_d, g_d = torch.from_numpy(est).to(dev), torch.from_numpy(gt).to(dev)
+    e_keep = e_d.clone()
+    out = []
+    for borrow in (False, True):
+        with Engine(0, borrow_device_input=borrow) as eng:
+            eng.upload(0, e_d, cell_size=0.1)
+            eng.upload(1, g_d, cell_size=0.1)
+            idx, d2 = eng.nn1(0, 1)
+            m = eng.mme(0, 0.1, 10)
+            tab = eng.voxel_gaussians(1, 1.0)
+            T = np.eye(4)
+            T[:3, 3] = [0.01, 0.02, -0.01]
+            eng.transform_cloud(0, T)                # makes the cloud own its points first
+            idx2, d22 = eng.nn1(0, 1)
+            out.append((idx, d2, m, tab, idx2, d22))
+        torch.cuda.synchronize()
+        assert torch.equal(e_d, e_keep), "the engine wrote into a borrowed buffer"
+    a, b = out
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    for x, y in zip(a[3], b[3]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
