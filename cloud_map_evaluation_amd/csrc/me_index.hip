@@ -189,25 +189,36 @@ __device__ __forceinline__ void fine_cell(const double *__restrict__ xyz, long l
 
 // sort keys: the Hilbert index of the point's cell at level `min_level` (the finest level the order matters at), placed at
 // bits [3 min_level, 63) — or the Morton code itself (hilbert == 0)
+// pack_bits > 0 (round 4): key and point index travel in ONE 64-bit word, (key >> 3 min_level) << pack_bits | i, and the sort is a
+// keys-only sort of the bits above pack_bits — 16 bytes per point and radix pass instead of 24 (8-byte key + 4-byte value, read and
+// written); the index in the low bits also breaks ties the way the stable pair sort did: the permutation is the same.
 __global__ void k_morton(const double *__restrict__ xyz, long long n, double ox, double oy, double oz, double fine_h,
-                         int min_level, int hilbert, unsigned long long *__restrict__ keys, unsigned int *__restrict__ iota) {
+                         int min_level, int hilbert, int pack_bits, unsigned long long *__restrict__ keys, unsigned int *__restrict__ iota) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     unsigned int cx, cy, cz;
     fine_cell(xyz, i, ox, oy, oz, fine_h, cx, cy, cz);
+    unsigned long long key;
     if (hilbert)
-        keys[i] = hilbert_key(cx >> min_level, cy >> min_level, cz >> min_level, kMortonBits - min_level) << (3 * min_level);
+        key = hilbert_key(cx >> min_level, cy >> min_level, cz >> min_level, kMortonBits - min_level) << (3 * min_level);
     else
-        keys[i] = spread21((unsigned long long) cx) | (spread21((unsigned long long) cy) << 1) | (spread21((unsigned long long) cz) << 2);
-    iota[i] = (unsigned int) i;
+        key = spread21((unsigned long long) cx) | (spread21((unsigned long long) cy) << 1) | (spread21((unsigned long long) cz) << 2);
+    if (pack_bits > 0) {
+        keys[i] = ((key >> (3 * min_level)) << pack_bits) | (unsigned long long) i;
+    } else {
+        keys[i] = key;
+        iota[i] = (unsigned int) i;
+    }
 }
 
 // sorted points, and their Morton codes (the cell keys of every level; recomputed here rather than carried through the sort)
-__global__ void k_gather(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, long long n, double ox,
-                         double oy, double oz, double fine_h, SPoint *__restrict__ sp, unsigned long long *__restrict__ codes) {
+// (packed != nullptr: the sorted (key, index) words of the keys-only sort, the index in the low bits under idx_mask)
+__global__ void k_gather(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, const unsigned long long *__restrict__ packed,
+                         unsigned long long idx_mask, long long n, double ox, double oy, double oz, double fine_h,
+                         SPoint *__restrict__ sp, unsigned long long *__restrict__ codes) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned int s = perm[i];
+    const unsigned int s = packed ? (unsigned int) (packed[i] & idx_mask) : perm[i];
     SPoint p;
     p.x = xyz[3 * (long long) s];
     p.y = xyz[3 * (long long) s + 1];
@@ -709,13 +720,31 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     ME_CHECK(ctx, c.sp.ensure((size_t) n * sizeof(SPoint)));
     // ME_SORT_DEPTH: levels below the search cell that the order (and therefore the choice of the 1-NN grid) may use
     static const int sort_depth = std::getenv("ME_SORT_DEPTH") ? std::atoi(std::getenv("ME_SORT_DEPTH")) : 2;
-    const int sort_min_level = std::max(0, c.shift - std::max(0, sort_depth));
     // ME_HILBERT=0: points sorted along the Z curve (the first version) for A/B measurements
     static const int hilbert = std::getenv("ME_HILBERT") ? std::atoi(std::getenv("ME_HILBERT")) : 1;
+    // Keys-only sort when key and index fit one 64-bit word (round 4, k_morton): 3 (21 - min_level) key bits + ceil(log2 n) index
+    // bits.  A 50 M-point cloud at a 0.1 m cell in a 200 m scene needs 33 + 3 depth + 26: depth 1 fits, depth 2 does not.  The depth
+    // is lowered to make it fit — and if the 1-NN grid then lands on the finest sorted level (a dense cloud, which might have chosen
+    // a finer one had it been sorted), the index is rebuilt with the pair sort at the full depth and the slot remembers it.
+    int idx_bits = 1;
+    while ((1LL << idx_bits) < n) ++idx_bits;
+    static const int pack_allowed = std::getenv("ME_SORT_PACK") ? std::atoi(std::getenv("ME_SORT_PACK")) : 1;
+    int sort_min_level = std::max(0, c.shift - std::max(0, sort_depth));
+    int pack_bits = 0;
+    if (pack_allowed && !c.sort_pairs_hint) {
+        int lvl = sort_min_level;
+        while (lvl < c.shift && 3 * (kMortonBits - lvl) + idx_bits > 64) ++lvl;
+        if (3 * (kMortonBits - lvl) + idx_bits <= 64) {
+            sort_min_level = lvl;
+            pack_bits = idx_bits;
+        }
+    }
+    const bool depth_cut = pack_bits > 0 && sort_min_level > std::max(0, c.shift - std::max(0, sort_depth));
+    if (pack_bits > 0) ME_CHECK(ctx, perm.ensure((size_t) n * 8));  // (the sorted words)
     {
         TimerScope ts(ctx, "morton");
         hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, c.origin[0],
-                           c.origin[1], c.origin[2], c.fine_h, sort_min_level, hilbert, codes_in.as<unsigned long long>(),
+                           c.origin[1], c.origin[2], c.fine_h, sort_min_level, hilbert, pack_bits, codes_in.as<unsigned long long>(),
                            iota.as<unsigned int>());
     }
     // Nothing below consumes the order inside a cell 4x finer than the search cell: the 1-NN grid (and the octree leaves) is
@@ -723,13 +752,19 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     // cell (38 000 pts/m^2 of surface at r = 0.1 m); denser clouds simply get more points per 1-NN cell.  So the radix sort
     // skips the low bits: 5 passes instead of 8 on the bench scene (6 with the five levels sorted at first).
     // The sort is stable, so the order inside such a cell is the input order: still deterministic.
-    ME_TRY(sort_pairs_u64_u32(ctx, codes_in.as<unsigned long long>(), c.codes.as<unsigned long long>(),
-                              iota.as<unsigned int>(), perm.as<unsigned int>(), n, 3 * sort_min_level, 63));
+    if (pack_bits > 0)
+        ME_TRY(sort_keys_u64(ctx, codes_in.as<unsigned long long>(), perm.as<unsigned long long>(), n, pack_bits,
+                             pack_bits + 3 * (kMortonBits - sort_min_level)));
+    else
+        ME_TRY(sort_pairs_u64_u32(ctx, codes_in.as<unsigned long long>(), c.codes.as<unsigned long long>(),
+                                  iota.as<unsigned int>(), perm.as<unsigned int>(), n, 3 * sort_min_level, 63));
     {
         TimerScope ts(ctx, "gather");
         hipLaunchKernelGGL(k_gather, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
-                           perm.as<unsigned int>(), n, c.origin[0], c.origin[1], c.origin[2], c.fine_h, c.sp.as<SPoint>(),
-                           c.codes.as<unsigned long long>());
+                           pack_bits > 0 ? (const unsigned int *) nullptr : perm.as<unsigned int>(),
+                           pack_bits > 0 ? perm.as<unsigned long long>() : (const unsigned long long *) nullptr,
+                           pack_bits > 0 ? ((1ULL << pack_bits) - 1ULL) : 0ULL, n, c.origin[0], c.origin[1], c.origin[2], c.fine_h,
+                           c.sp.as<SPoint>(), c.codes.as<unsigned long long>());
     }
     // --- occupied cells per Morton level -> pick the 1-NN grid level; build the cell tables ---
     {
@@ -756,6 +791,12 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
                 nn_shift = k;
                 break;
             }
+        if (depth_cut && nn_shift == sort_min_level && nn_shift < c.shift) {
+            // the finest sorted level holds >= 6 points per cell: with the full depth a finer one might have been chosen.  Build
+            // again with the pair sort (and start with it next time this slot is indexed).
+            c.sort_pairs_hint = true;
+            return cloud_build_index(ctx, slot, c.cell_size_req);
+        }
         ME_TRY(build_grid_table(ctx, c, c.shift, c.grid_tab, c.grid));
         c.n_mid = 0;
         if (nn_shift == c.shift) {

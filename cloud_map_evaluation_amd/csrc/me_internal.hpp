@@ -130,6 +130,7 @@ struct FrameView {
 };
 
 struct Cloud {
+    bool sort_pairs_hint = false;  // the keys-only sort had to cut the sort depth and the cloud was dense: use the pair sort (me_index.hip)
     long long n = 0;        // points held (slab mode: owned + halo)
     long long n_total = 0;  // points the caller passed to the upload
     SlabView slab{-1, 0, 0, 0, 0};
@@ -298,6 +299,7 @@ int sort_pairs_u64_u32(me_ctx *ctx, const unsigned long long *k_in, unsigned lon
 int exclusive_scan_u32(me_ctx *ctx, const unsigned int *in, unsigned int *out, long long n);
 int cell_start_ranks(me_ctx *ctx, const unsigned long long *codes, long long n, int shift3, unsigned int *out);
 int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n);
+int sort_keys_u64(me_ctx *ctx, const unsigned long long *in, unsigned long long *out, long long n, int begin_bit, int end_bit);
 int select_flagged_u32(me_ctx *ctx, const unsigned char *flags, long long n, unsigned int *out, unsigned int *count_device);
 
 // ---- me_index.hip ----
@@ -627,7 +629,33 @@ __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, i
     // The leader is the MIDDLE pending lane, not the first: the lanes hold curve-consecutive points, the first pending lane
     // sits at one end of the stretch of space they cover and its Chebyshev ball reaches half as far into it.
     const int rank = __popcll(pm & ((1ULL << lane) - 1ULL));
-    const int leader = __ffsll((long long) __ballot(pending && rank == (__popcll(pm) >> 1))) - 1;
+    const int n_pending = __popcll(pm);
+    int leader = __ffsll((long long) __ballot(pending && rank == (n_pending >> 1))) - 1;
+#ifndef ME_LEADER_MIDDLE
+    // Round 4: when the middle lane's group does not hold every pending lane, the lanes at the quartiles of the pending stretch
+    // are tried as well — ranks k/6 of it — and the leader whose group is the largest wins (a few ballots; a round costs thousands of
+    // instructions).
+    {
+        auto group_size = [&](int l) {
+            const int ax = readlane_i(cx, l), ay = readlane_i(cy, l), az = readlane_i(cz, l);
+            const int ux = cx - ax, uy = cy - ay, uz = cz - az;
+            return __popcll(__ballot(pending && ux >= -R && ux <= R && uy >= -R && uy <= R && uz >= -R && uz <= R));
+        };
+        int best = group_size(leader);
+        if (best < n_pending && n_pending >= 8) {
+#pragma unroll
+            for (int c = 1; c <= 5; ++c) {
+                if (c == 3) continue;  // (the middle: tried already)
+                const int l = __ffsll((long long) __ballot(pending && rank == ((c * n_pending) / 6))) - 1;
+                const int b = group_size(l);
+                if (b > best) {
+                    best = b;
+                    leader = l;
+                }
+            }
+        }
+    }
+#endif
 #endif
     const int lx = readlane_i(cx, leader), ly = readlane_i(cy, leader), lz = readlane_i(cz, leader);
     const int ex = cx - lx, ey = cy - ly, ez = cz - lz;

@@ -1,5 +1,6 @@
 // me_prims.hip — device-wide sort / scan primitives (rocPRIM) behind plain functions, so that the slow-to-compile
 // rocPRIM templates are instantiated in exactly one translation unit.
+#include <cstdlib>
 #include <cstring>
 #include <string.h>
 
@@ -62,6 +63,18 @@ int select_flagged_u32(me_ctx *ctx, const unsigned char *flags, long long n, uns
     ME_CHECK(ctx, rocprim::select(nullptr, bytes, idx, flags, out, count_device, (size_t) n, ctx->stream));
     ME_CHECK(ctx, ctx->tmp[5].ensure(bytes));
     ME_CHECK(ctx, rocprim::select(ctx->tmp[5].p, bytes, idx, flags, out, count_device, (size_t) n, ctx->stream));
+    return ME_OK;
+}
+
+// (nine bits per onesweep pass — four passes over a 36-bit key instead of five — does not build: rocPRIM's rank table for 512 digits
+// needs 524 KB of LDS)
+int sort_keys_u64(me_ctx *ctx, const unsigned long long *in, unsigned long long *out, long long n, int begin_bit, int end_bit) {
+    if (n <= 0) return ME_OK;
+    size_t bytes = 0;
+    ME_CHECK(ctx, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, ctx->stream));
+    ME_CHECK(ctx, ctx->tmp[5].ensure(bytes));
+    TimerScope ts(ctx, "sort");
+    ME_CHECK(ctx, rocprim::radix_sort_keys(ctx->tmp[5].p, bytes, in, out, (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, ctx->stream));
     return ME_OK;
 }
 
