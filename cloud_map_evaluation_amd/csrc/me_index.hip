@@ -732,8 +732,11 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     int sort_min_level = std::max(0, c.shift - std::max(0, sort_depth));
     int pack_bits = 0;
     if (pack_allowed && !c.sort_pairs_hint) {
+        // (the depth is cut to 1 at most: at depth 0 the finest sorted level is the search cell itself, which holds its 6 points
+        // in any cloud worth indexing — the rebuild below would be certain)
+        const int lvl_max = std::max(sort_min_level, c.shift - std::min(std::max(0, sort_depth), 1));
         int lvl = sort_min_level;
-        while (lvl < c.shift && 3 * (kMortonBits - lvl) + idx_bits > 64) ++lvl;
+        while (lvl < lvl_max && 3 * (kMortonBits - lvl) + idx_bits > 64) ++lvl;
         if (3 * (kMortonBits - lvl) + idx_bits <= 64) {
             sort_min_level = lvl;
             pack_bits = idx_bits;
@@ -791,10 +794,11 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
                 nn_shift = k;
                 break;
             }
-        if (depth_cut && nn_shift == sort_min_level && nn_shift < c.shift) {
+        if (depth_cut && nn_shift == sort_min_level) {
             // the finest sorted level holds >= 6 points per cell: with the full depth a finer one might have been chosen.  Build
             // again with the pair sort (and start with it next time this slot is indexed).
             c.sort_pairs_hint = true;
+            ts.end();
             return cloud_build_index(ctx, slot, c.cell_size_req);
         }
         ME_TRY(build_grid_table(ctx, c, c.shift, c.grid_tab, c.grid));

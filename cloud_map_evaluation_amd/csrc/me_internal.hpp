@@ -277,10 +277,15 @@ struct me_ctx {
 namespace me {
 
 // RAII scope for a named kernel-family timer
-struct TimerScope {
+struct TimerScope {  // (scopes do not nest: a scope that calls into another timed phase ends itself first)
     me_ctx *c;
+    bool open = true;
     TimerScope(me_ctx *ctx, const char *name) : c(ctx) { c->timer_begin(name); }
-    ~TimerScope() { c->timer_end(); }
+    void end() {
+        if (open) c->timer_end();
+        open = false;
+    }
+    ~TimerScope() { end(); }
 };
 
 // chunk size of the XCD-aware block order (ME_XCD_CHUNK overrides; a huge value = one contiguous piece per XCD)

@@ -443,3 +443,39 @@ def test_borrowed_device_input_gives_the_same_results_and_leaves_the_callers_buf
     for x, y in zip(a[3], b[3]):
         assert np.array_equal(np.asarray(x), np.asarray(y))
     assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
+def test_index_rebuilds_with_the_pair_sort_when_the_packed_sort_had_to_cut_its_depth():
+    """Round 4: the keys-only sort packs (key, point index) into 64 bits and lowers the sort depth when they do not fit; a DENSE
+    cloud whose 1-NN grid then lands on the finest sorted level is indexed again with the pair sort at the full depth
+    (me_index.hip).  A dense 3 m patch plus two points 600 m away (extent -> 13 bits of cells, 20 bits of index: depth 2 needs
+    65 bits): two sorts must have run for that upload, one for the next upload of the slot, and the results are the oracle's."""
+    import oracle
+
+    from cloud_map_evaluation_amd.engine import Engine
+
+    rng = np.random.default_rng(43)
+    n = 700_000
+    xy = rng.uniform(0.0, 3.0, (n, 2))
+    gt = np.column_stack([xy, 0.04 * np.sin(4.0 * xy[:, 0]) + rng.normal(0, 0.002, n)])
+    gt = np.concatenate([gt, np.array([[600.0, 10.0, 1.0], [-5.0, 610.0, 2.0]])])
+    assert 2 ** 19 < len(gt) <= 2 ** 20
+    est = gt[rng.choice(n, 200_000, replace=False)] + np.array([0.01, -0.01, 0.012]) + rng.normal(0, 0.004, (200_000, 3))
+    with Engine(0) as eng:
+        eng.timers_enable(True)
+        eng.timers_reset()
+        eng.upload(1, gt, cell_size=0.1)
+        first = eng.timer("sort")[1]
+        eng.timers_reset()
+        eng.upload(1, gt, cell_size=0.1)
+        second = eng.timer("sort")[1]
+        eng.timers_enable(False)
+        eng.upload(0, est, cell_size=0.1)
+        idx, d2 = eng.nn1(0, 1)
+        m = eng.mme(1, 0.1, 5)
+    assert (first, second) == (2, 1), (first, second)
+    oi, od2 = oracle.nn1(gt, est)
+    assert np.array_equal(d2, od2) and np.array_equal(idx, oi)
+    om = oracle.mme(gt, 0.1, 5)
+    assert m[3] == om[3] and np.array_equal(np.asarray(m[2]).astype(bool), om[2].astype(bool))  # valid counts and flags
+    np.testing.assert_allclose(m[0], om[0], rtol=1e-9)
