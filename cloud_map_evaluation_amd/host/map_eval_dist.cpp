@@ -1,7 +1,7 @@
 // map_eval_dist.cpp — `num_gpus: N` for the drop-in binary: MapEval::process() between "clouds loaded and down-sampled"
 // and "results written" (map_eval/src/map_eval.cpp:51-85) sharded over N GPUs, one process per GPU, collectives over RCCL
 // (dist_comm.hpp).  C++ restatement of cloud_map_evaluation_amd/dist.py::suite_step_slab on the library's slab entry points
-// (include/mapeval_hip.h: me_set_slab, me_nn_unresolved / me_nn_points_bounded / me_nn_patch, me_nn_partial_sums /
+// (include/mapeval_hip.h: me_set_slab, me_nn_unresolved / me_nn_points_covered / me_nn_patch, me_nn_partial_sums /
 // me_nn_sigma_sums / me_nn_finalize, me_voxel_partial_rows_device / me_voxel_merge_device, me_slab_points):
 //
 //   every rank starts from ITS 1/N of each cloud's points (the r-th contiguous piece: what it would have read of the files; this
@@ -12,7 +12,8 @@
 //              ncclSend / ncclRecv (Comm::all_to_all_v); what arrives IS the rank's slab + halo (me_upload_slab_device)
 //     MME      per-point on the slab, {sum H, n_valid} all-reduced                        (1 collective, 4 doubles)
 //     AC/COM   local 1-NN both ways; queries that a closer point on another rank could beat go through the cross-rank
-//              step: counts all-reduce, queries + bounds all-gather, bounded search on every rank, MIN all-reduce, patch;
+//              step: counts all-reduce, queries + bounds all-gather, bounded search on every rank (outside the band the owner has
+//              searched: me_nn_points_covered), MIN all-reduce, patch;
 //              partial sums all-reduce, sigma numerators all-reduce
 //     AWD/SCS  voxel partial rows of the owned points: counts ride on the sums, one padded all-gather per cloud, Chan
 //              merge on the device, me_awd_scs on the merged (replicated) tables
@@ -416,7 +417,18 @@ int MapEval::processDist(double t_loaded) {
                     // the bound to beat = the owner's own result; every other rank may lower it
                     if (hipMemcpy(dst, src + off_d[d], (size_t) c * 8, hipMemcpyDeviceToDevice) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
                         return fail("hipMemcpy");
-                    if (k != rank) DIST_TRY(me_nn_points_bounded(ctx_, dirs[d][1], src + off_x[d], c, dst));
+                    if (k != rank) {
+                        // rank k has searched its slab +- halo completely (it holds every point of both clouds in that band):
+                        // only what sticks out of the band can beat its bound (me_nn_points_covered)
+                        medist::DevMem &cov = pool_[3];  // (the tag buffer of the exchange: free by now)
+                        std::vector<double> band((size_t) c * 2);
+                        for (int64_t j = 0; j < c; ++j) {
+                            band[(size_t) 2 * j] = cuts[(size_t) k] - halo;
+                            band[(size_t) 2 * j + 1] = cuts[(size_t) k + 1] + halo;
+                        }
+                        if (!cov.ensure(band.size() * 8) || !h2d(cov.p, band.data(), band.size() * 8)) return fail("device buffers of the cross-rank step");
+                        DIST_TRY(me_nn_points_covered(ctx_, dirs[d][1], src + off_x[d], c, dst, axis, cov.as<double>()));
+                    }
                 }
             COMM_TRY(comm_->all_reduce_min_f64(ans.as<double>(), row * (size_t) world));
             for (int d = 0; d < 2; ++d)
