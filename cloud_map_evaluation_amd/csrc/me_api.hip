@@ -50,6 +50,46 @@ void me_ctx::timers_collect() {
     pending.clear();
 }
 
+namespace me {
+__global__ void __launch_bounds__(64) k_mail(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, unsigned int bytes) {
+    if (((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst) | bytes) & 7u) == 0) {
+        for (unsigned int i = threadIdx.x; i < bytes / 8; i += 64)
+            reinterpret_cast<unsigned long long *>(dst)[i] = reinterpret_cast<const unsigned long long *>(src)[i];
+    } else {
+        for (unsigned int i = threadIdx.x; i < bytes; i += 64) dst[i] = src[i];
+    }
+}
+
+int mail_post(me_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+    if (bytes == 0) return ME_OK;
+    if (!ctx->mail_h) {
+        void *h = nullptr, *d = nullptr;
+        ME_CHECK(ctx, hipHostMalloc(&h, kMailBytes, hipHostMallocMapped));
+        ME_CHECK(ctx, hipHostGetDevicePointer(&d, h, 0));
+        ctx->mail_h = static_cast<unsigned char *>(h);
+        ctx->mail_d = static_cast<unsigned char *>(d);
+    }
+    const size_t off = (ctx->mail_used + 15) & ~(size_t) 15;
+    if (off + bytes > kMailBytes) {  // (too big for the mailbox: the ordinary copy)
+        ME_CHECK(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return ME_OK;
+    }
+    hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, static_cast<const unsigned char *>(dev_src), ctx->mail_d + off,
+                       (unsigned int) bytes);
+    ctx->mail_pending.push_back({host_dst, off, bytes});
+    ctx->mail_used = off + bytes;
+    return ME_OK;
+}
+
+int mail_sync(me_ctx *ctx) {
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (const auto &m : ctx->mail_pending) std::memcpy(m.host, ctx->mail_h + m.off, m.bytes);
+    ctx->mail_pending.clear();
+    ctx->mail_used = 0;
+    return ME_OK;
+}
+}  // namespace me
+
 extern "C" {
 
 int me_version(void) { return 100; }
@@ -137,6 +177,7 @@ void me_destroy(me_ctx *ctx) {
     }
     for (auto e : ctx->event_pool) (void) hipEventDestroy(e);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    if (ctx->mail_h) (void) hipHostFree(ctx->mail_h);
     delete ctx;
 }
 

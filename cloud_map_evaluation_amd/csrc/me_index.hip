@@ -623,8 +623,8 @@ int cloud_finish(me_ctx *ctx, int slot, bool bbox_ready) {
     if (!bbox_ready)  // (an upload from a device buffer has produced the partials in its single pass, k_ingest)
         hipLaunchKernelGGL(k_bbox, dim3(nb), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, ctx->red.as<double>());
     std::vector<double> part((size_t) nb * 6);
-    ME_CHECK(ctx, hipMemcpyAsync(part.data(), ctx->red.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_TRY(mail_post(ctx, part.data(), ctx->red.p, part.size() * sizeof(double)));
+    ME_TRY(mail_sync(ctx));
     for (int d = 0; d < 3; ++d) {
         double lo = INFINITY, hi = -INFINITY;
         for (unsigned int b = 0; b < nb; ++b) {
@@ -778,8 +778,8 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
         hipLaunchKernelGGL(k_level_hist, dim3((unsigned int) std::min<long long>(1024, (n + 255) / 256)), dim3(256), 0,
                            ctx->stream, c.codes.as<unsigned long long>(), n, d_hist);
         unsigned long long h_hist[32];
-        ME_CHECK(ctx, hipMemcpyAsync(h_hist, d_hist, sizeof(h_hist), hipMemcpyDeviceToHost, ctx->stream));
-        ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ME_TRY(mail_post(ctx, h_hist, d_hist, sizeof(h_hist)));
+        ME_TRY(mail_sync(ctx));
         long long acc = 1;
         for (int k = kMortonBits; k >= 0; --k) {  // level k: cell edge fine_h * 2^k
             if (k < kMortonBits) acc += (long long) h_hist[k];

@@ -213,6 +213,17 @@ struct me_ctx {
         me::Cloud &operator[](int i) const { return *p[i]; }
     } cloud;
     me_ctx *twin = nullptr;  // owned by the primary context
+    // Small device -> host results (sums, counts, the level histogram) go through a pinned, device-mapped MAILBOX written by a
+    // one-wavefront kernel (me::mail_post / me::mail_sync, me_api.hip; round 4).  hipMemcpyAsync to pageable host memory is a blit
+    // kernel of ONE 1024-thread workgroup: it needs 16 free wave slots on one CU at once, and while the other lane's k_nn_grid /
+    // k_mme3 keeps every CU full that took 3 - 5.6 ms per read on the critical path (profiles/r04_timeline_two_lane.txt).
+    unsigned char *mail_h = nullptr, *mail_d = nullptr;
+    size_t mail_used = 0;
+    struct MailItem {
+        void *host;
+        size_t off, bytes;
+    };
+    std::vector<MailItem> mail_pending;
     bool is_twin = false;
     me_ctx() {
         cloud.p[0] = &own_cloud[0];
@@ -297,6 +308,11 @@ inline unsigned int xcd_chunk_setting() {
     }();
     return v;
 }
+
+// ---- me_api.hip: small results to the host without a blit kernel (see me_ctx::mail_h) ----
+constexpr size_t kMailBytes = 128 * 1024;
+int mail_post(me_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);  // asynchronous on ctx->stream
+int mail_sync(me_ctx *ctx);                                                     // hipStreamSynchronize + delivery of what was posted
 
 // ---- me_prims.hip (rocPRIM-backed primitives) ----
 int sort_pairs_u64_u32(me_ctx *ctx, const unsigned long long *k_in, unsigned long long *k_out,

@@ -1007,8 +1007,8 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     hipLaunchKernelGGL(k_mme_final, dim3(1), dim3(256), 0, ctx->stream, ps2, pc2, (long long) kStage, (long long) kStage, outs, outc);
     double hs = 0;
     long long hc = 0;
-    ME_CHECK(ctx, hipMemcpyAsync(&hs, outs, 8, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&hc, outc, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(mail_post(ctx, &hs, outs, 8));  // (not hipMemcpyAsync: me_ctx::mail_h)
+    ME_TRY(mail_post(ctx, &hc, outc, 8));
     if (entropies || valid) {
         DevBuf &eo = ctx->tmp[2], &vo = ctx->tmp[3];
         ME_CHECK(ctx, eo.ensure((size_t) n * 8));
@@ -1024,7 +1024,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
         if (entropies) ME_CHECK(ctx, hipMemcpyAsync(entropies, eo.p, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (valid) ME_CHECK(ctx, hipMemcpyAsync(valid, vo.p, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
     }
-    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_TRY(mail_sync(ctx));
     ME_CHECK(ctx, hipGetLastError());
 #ifdef ME_MME_STATS
     {

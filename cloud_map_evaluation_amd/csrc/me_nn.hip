@@ -1453,9 +1453,9 @@ int nn_partial(me_ctx *ctx, int qslot, double gate, int gate_mode, const double 
     }
     double hd[kStatD];
     long long hi[kStatI];
-    ME_CHECK(ctx, hipMemcpyAsync(hd, pd + (size_t) nb * kStatD, sizeof(hd), hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(hi, pi + (size_t) nb * kStatI, sizeof(hi), hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_TRY(mail_post(ctx, hd, pd + (size_t) nb * kStatD, sizeof(hd)));
+    ME_TRY(mail_post(ctx, hi, pi + (size_t) nb * kStatI, sizeof(hi)));
+    ME_TRY(mail_sync(ctx));
     out->n_query = e - b;
     out->n_corr = hi[0];
     for (int k = 0; k < 5; ++k) {
@@ -1486,8 +1486,8 @@ int nn_sigma(me_ctx *ctx, int qslot, double gate, int gate_mode, const double me
         hipLaunchKernelGGL(k_nn_sigma, dim3(nb), dim3(256), 0, ctx->stream, q.nn_d2.as<double>(), b, e, sp, m, pd);
         hipLaunchKernelGGL(k_final_sum_d, dim3(5), dim3(256), 0, ctx->stream, pd, nb, 5, pd + (size_t) nb * 5);
     }
-    ME_CHECK(ctx, hipMemcpyAsync(sigma_num, pd + (size_t) nb * 5, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_TRY(mail_post(ctx, sigma_num, pd + (size_t) nb * 5, 5 * 8));
+    ME_TRY(mail_sync(ctx));
     return ME_OK;
 }
 
