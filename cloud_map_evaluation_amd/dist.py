@@ -621,8 +621,8 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
             cov = None
             if cuts is not None and len(cuts) == world + 1:
                 h = float(slab[3])
-                band = torch.tensor([[cuts[k] - h, cuts[k + 1] + h] for k in range(world)], dtype=torch.float64)
-                cov = band[:, None, :].expand(world, cap, 2).reshape(-1, 2).contiguous()
+                band = torch.tensor([[cuts[k] - h, cuts[k + 1] + h] for k in range(world)], dtype=torch.float64).to(wdev)
+                cov = band[:, None, :].expand(world, cap, 2).reshape(-1, 2).contiguous()  # (expanded on the device: 16 bytes per rank cross the bus)
             for i, (q, r) in enumerate(dirs):
                 base = offs[i]
                 if int(table[:, i].sum()) - cnt[i] <= 0:
@@ -632,7 +632,7 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
                 b[rank] = -1.0                                       # the owner's own search is its answer
                 qx = blk[:, :, :3].reshape(-1, 3).contiguous().to(wdev)
                 if cov is not None:
-                    ans = eng.nn_points(r, qx, bound=b.reshape(-1).to(wdev), covered=cov.to(wdev), axis=int(slab[0])).to(comm_device)
+                    ans = eng.nn_points(r, qx, bound=b.reshape(-1).to(wdev), covered=cov, axis=int(slab[0])).to(comm_device)
                 else:
                     ans = eng.nn_points(r, qx, bound=b.reshape(-1).to(wdev)).to(comm_device)
                 ans = ans.view(world, cap)
