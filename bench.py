@@ -46,6 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 BYTES_PER_NN_QUERY = 60.0   # 24 B query + 24 B reference point + 12 B result (M = N)
 BYTES_PER_MME_QUERY = 33.0  # 24 B point + 8 B entropy + 1 B valid
 OVERLAP = True  # --no-overlap switches the second lane off (the per-kernel timing pass always runs without it)
+PY_DRIVER = False  # --py-driver: the single-GPU step driven from Python (dist.suite_step + a Python thread) instead of the one C call
 
 WORKLOADS = {
     "c4_multisession": dict(points=50_000_000, density=2500.0, radius=0.1, voxel=3.0,
@@ -78,6 +79,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive timing")
     ap.add_argument("--no-overlap", action="store_true", help="single lane: every stage back to back on one stream")
+    ap.add_argument("--py-driver", action="store_true", help="N = 1: drive the step from Python (round 4's bench) instead of me_run_suite_from")
     a = ap.parse_args()
     w = WORKLOADS[a.workload]
     a.points = a.points or w["points"]
@@ -120,9 +122,15 @@ def suite_step(eng, dist, world, est_d, gt_d, P, evaluate_gt_mme, comm_dev=None)
         # est_d / gt_d are this rank's 1/N of the clouds: slabs + one all-to-all halo exchange
         return medist.suite_step_dist(eng, dist, comm_dev or dev, est_d, gt_d, P, dist.get_rank(), world, evaluate_gt_mme, halo=1.0,
                                       overlap=OVERLAP)  # (the per-kernel timing pass and --no-overlap run ONE lane here too)
-    # single GPU: the HBM-bound stages (index of the ground truth, both voxel tables) run on the engine's second lane
-    # under the VALU-bound MME / 1-NN kernels (dist._Lane); same calls, same results
-    return medist.suite_step(eng, None, dev, est_d, gt_d, P, evaluate_gt_mme, overlap=OVERLAP)
+    # single GPU: ONE call through the C ABI (me_run_suite_from) — what a C++ host makes from its one thread.  The HBM-bound stages
+    # (index of the ground truth, both voxel tables) and one 1-NN direction run on the library's internal second lane under the
+    # VALU-bound MME / 1-NN kernels (csrc/me_suite.hip).  PY_DRIVER: the same schedule driven from Python (dist._Lane: the round-4
+    # bench), kept as a cross-check of the numbers.
+    if PY_DRIVER:
+        return medist.suite_step(eng, None, dev, est_d, gt_d, P, evaluate_gt_mme, overlap=OVERLAP)
+    from cloud_map_evaluation_amd.engine import Engine
+
+    return Engine.suite_dict(eng.run_suite_from(est_d, gt_d, P, overlap=OVERLAP))
 
 
 def _best_of(fn, reps=3):
@@ -255,9 +263,10 @@ def cpu_baseline_sample(args, P, evaluate_gt_mme, n=2_000_000):
 
 
 def main():
-    global OVERLAP
+    global OVERLAP, PY_DRIVER
     args = parse()
     OVERLAP = not args.no_overlap
+    PY_DRIVER = args.py_driver
     import numpy as np
     import torch
 
@@ -332,6 +341,24 @@ def main():
     ms_per_step, res = timed(est_d, gt_d, args.steps, args.warmup)
     value = (n_e + n_g) / 1e6 / (ms_per_step / 1e3)
 
+    # cross-checks of the headline (N = 1, a few steps each): the same schedule driven from Python, and the engine without
+    # ME_FLAG_BORROW_DEVICE_INPUT (the default of me_create: the upload copies the resident cloud first)
+    xcheck = {}
+    if world == 1 and not args.no_roofline:
+        k = max(2, min(5, args.steps))
+        PY_DRIVER = not PY_DRIVER
+        ms_other, res_other = timed(est_d, gt_d, k, 1)
+        PY_DRIVER = not PY_DRIVER
+        xcheck["other_driver"] = {"driver": "python (dist.suite_step)" if not PY_DRIVER else "C ABI (me_run_suite_from)", "ms_per_step": ms_other,
+                                  "steps": k, "same_results": bool(res_other["cd"] == res["cd"] and res_other["mme_valid"] == res["mme_valid"]
+                                                                   and res_other["awd"] == res["awd"] and res_other["mme_est"] == res["mme_est"])}
+        eng_copy = Engine(local_rank, borrow_device_input=False)
+        eng_main, eng = eng, eng_copy
+        ms_copy, res_copy = timed(est_d, gt_d, k, 1)
+        eng = eng_main
+        eng_copy.close()
+        xcheck["copying_upload"] = {"ms_per_step": ms_copy, "steps": k, "same_results": bool(res_copy["cd"] == res["cd"] and res_copy["awd"] == res["awd"])}
+
     w = WORKLOADS[args.workload]
     line = {
         "metric": "Mpts/sec full metric suite (CD+MME+AWD) on 50M-pt pair",
@@ -346,10 +373,19 @@ def main():
                                    f"distributed input (1/{world} of each cloud per rank), spatial slabs x{world} along the longest axis "
                                    "(+1 m halo) filled by one all-to-all halo exchange; cross-rank 1-NN resolve (all-gather + "
                                    "min-reduce), all-reduced partial sums, all-gathered voxel partials merged on the device (RCCL)")},
+        "driver": ("python: dist.suite_step + a Python thread on me_twin" if (world == 1 and PY_DRIVER) else
+                   "C ABI: one me_run_suite_from call per step (ME_SUITE_DEVICE_INPUT%s), the second lane is a thread inside the library"
+                   % ("|ME_SUITE_OVERLAP" if OVERLAP else "")) if world == 1 else "python: dist.suite_step_dist over torch.distributed (RCCL)",
+        "engine_flags": {"ME_FLAG_BORROW_DEVICE_INPUT": True,
+                         "note": "the resident clouds are read where they lie; without the flag an upload copies them first (48 B/pt more "
+                                 "traffic per cloud: see `copying_upload` for that step time)"},
         "results": {"AC": [float(x) for x in res["ac"]], "COM": [float(x) for x in res["com"]], "CD": float(res["cd"]),
                     "MME_est": float(res["mme_est"]), "MME_gt": float(res["mme_gt"]), "AWD": float(res["awd"]),
                     "SCS": float(res["scs"]), "W_voxels": int(res["n_w"]), "MME_valid": res["mme_valid"]},
     }
+
+    if xcheck:
+        line["cross_checks"] = xcheck
 
     # ---- roofline of the dominant kernel: HIP events on the library's own stream, one extra (untimed) step ----
     if not args.no_roofline:

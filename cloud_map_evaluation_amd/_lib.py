@@ -14,6 +14,10 @@ ME_SLOT_EST = 0
 ME_SLOT_GT = 1
 ME_GATE_LE_UNSQUARED = 0
 ME_GATE_LT_SQUARED = 1
+ME_FLAG_BORROW_DEVICE_INPUT = 1
+ME_FLAG_MORTON_ORDER = 2
+ME_SUITE_OVERLAP = 1
+ME_SUITE_DEVICE_INPUT = 2
 
 # every symbol include/mapeval_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -24,7 +28,7 @@ SYMBOLS = [
     "me_transform_cloud",
     "me_set_normals", "me_get_normals", "me_estimate_normals", "me_gicp_covariances", "me_get_covariances", "me_icp_lsq_sums",
     "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats", "me_nn_partial_sums", "me_nn_sigma_sums", "me_nn_finalize", "me_chamfer",
-    "me_mme", "me_voxel_gaussians", "me_awd_scs", "me_w2_batch", "me_scs_table", "me_run_suite",
+    "me_mme", "me_voxel_gaussians", "me_awd_scs", "me_w2_batch", "me_scs_table", "me_run_suite", "me_run_suite_from", "me_mme_fetch",
     "me_timers_enable", "me_timers_reset", "me_timer_get",
 ]
 
@@ -187,6 +191,8 @@ def load():
     L.me_awd_scs.argtypes = [vp, C.c_double, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                              C.POINTER(C.c_double), dp]
     L.me_run_suite.argtypes = [vp, C.POINTER(SuiteParams), C.POINTER(SuiteOut)]
+    L.me_run_suite_from.argtypes = [vp, dp, C.c_int64, dp, C.c_int64, dp, C.POINTER(SuiteParams), C.c_int, C.POINTER(SuiteOut)]
+    L.me_mme_fetch.argtypes = [vp, C.c_int, dp, dp]
     L.me_w2_batch.argtypes = [vp, dp, dp, ip, dp, dp, ip, C.c_int64, dp]
     L.me_scs_table.argtypes = [vp, ip, dp, C.c_int64, C.c_int, C.POINTER(C.c_double)]
     L.me_timers_enable.argtypes = [vp, C.c_int]
@@ -194,7 +200,7 @@ def load():
     L.me_timer_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for f in ("me_voxel_downsample", "me_transform_cloud", "me_set_slab", "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_points_covered", "me_nn_patch", "me_nn_fetch", "me_slab_points", "me_set_mme_result", "me_set_nn_result", "me_voxel_partials", "me_set_shard", "me_upload_cloud", "me_upload_cloud_device", "me_download_cloud", "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats",
               "me_nn_partial_sums", "me_nn_sigma_sums", "me_chamfer", "me_mme", "me_voxel_gaussians", "me_awd_scs",
-              "me_run_suite", "me_w2_batch", "me_scs_table", "me_timers_enable", "me_timers_reset", "me_timer_get"):
+              "me_run_suite", "me_run_suite_from", "me_mme_fetch", "me_w2_batch", "me_scs_table", "me_timers_enable", "me_timers_reset", "me_timer_get"):
         getattr(L, f).restype = C.c_int
     _lib = L
     return L

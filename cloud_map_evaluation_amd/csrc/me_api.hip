@@ -1,6 +1,5 @@
 // me_api.hip — the extern "C" surface declared in include/mapeval_hip.h (context, timers, call sequencing).
 #include <cmath>
-#include <chrono>
 #include <cstring>
 
 #include "me_internal.hpp"
@@ -82,11 +81,19 @@ int mail_post(me_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
 }
 
 int mail_sync(me_ctx *ctx) {
-    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    for (const auto &m : ctx->mail_pending) std::memcpy(m.host, ctx->mail_h + m.off, m.bytes);
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    // (a failed synchronisation delivers nothing, but the queue is emptied all the same: its entries point at the caller's locals)
+    if (e == hipSuccess)
+        for (const auto &m : ctx->mail_pending) std::memcpy(m.host, ctx->mail_h + m.off, m.bytes);
     ctx->mail_pending.clear();
     ctx->mail_used = 0;
+    ME_CHECK(ctx, e);
     return ME_OK;
+}
+
+void mail_drop(me_ctx *ctx) {
+    ctx->mail_pending.clear();
+    ctx->mail_used = 0;
 }
 }  // namespace me
 
@@ -94,12 +101,10 @@ extern "C" {
 
 int me_version(void) { return 100; }
 
-static int stream_priority_for(const char *lane) {
-    const char *e = std::getenv("ME_STREAM_PRIO");
-    const std::string who = e ? e : "main";
+static int stream_priority_for(bool main_lane) {
     int least = 0, greatest = 0;
     (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
-    return who == lane ? greatest : least;  // (numerically lower = higher priority)
+    return main_lane ? greatest : least;  // (numerically lower = higher priority)
 }
 
 me_ctx *me_create(int device, int flags) {
@@ -122,10 +127,11 @@ me_ctx *me_create(int device, int flags) {
     me_ctx *ctx = new me_ctx();
     ctx->device = device;
     ctx->borrow_device_input = (flags & ME_FLAG_BORROW_DEVICE_INPUT) != 0;
+    ctx->morton_order = (flags & ME_FLAG_MORTON_ORDER) != 0;
     // The primary context's stream gets the highest dispatch priority, a twin's the lowest: when both lanes have kernels
     // queued, the main lane's (MME, 1-NN: the step's critical path) are dispatched first and the second lane's index / voxel
-    // kernels fill in — 54.9 -> 53.4 ms per bench step (round 3, three runs each).  ME_STREAM_PRIO=none|twin: measurement knob.
-    e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, stream_priority_for("main"));
+    // kernels fill in — 54.9 -> 53.4 ms per bench step (round 3, three runs each; the other two assignments measured slower).
+    e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, stream_priority_for(true));
     if (e != hipSuccess) {
         g_create_error = std::string("me_create: hipStreamCreate: ") + hipGetErrorString(e);
         delete ctx;
@@ -150,8 +156,9 @@ me_ctx *me_twin(me_ctx *ctx) {
     t->shard_rank = ctx->shard_rank;
     t->shard_world = ctx->shard_world;
     t->borrow_device_input = ctx->borrow_device_input;
+    t->morton_order = ctx->morton_order;
     t->slab = ctx->slab;
-    if (hipStreamCreateWithPriority(&t->stream, hipStreamNonBlocking, stream_priority_for("twin")) != hipSuccess) {
+    if (hipStreamCreateWithPriority(&t->stream, hipStreamNonBlocking, stream_priority_for(false)) != hipSuccess) {
         delete t;
         ctx->fail(ME_ERR_HIP, "me_twin: hipStreamCreate failed");
         return nullptr;
@@ -358,6 +365,11 @@ int me_mme(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, u
     return rc;
 }
 
+int me_mme_fetch(me_ctx *ctx, int slot, double *entropies, uint8_t *valid) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::mme_fetch(ctx, slot, entropies, valid);
+}
+
 int me_voxel_gaussians(me_ctx *ctx, int slot, double voxel_size, int32_t *keys, int32_t *npts, double *mu, double *sigma,
                        double *entropy, int64_t *n_voxels) {
     if (!ctx) return ME_ERR_ARG;
@@ -498,57 +510,6 @@ int me_w2_batch(me_ctx *ctx, const double *mu1, const double *sigma1, const int3
 int me_scs_table(me_ctx *ctx, const int32_t *keys, const double *w, int64_t n, int scs_radius, double *scs) {
     if (!ctx) return ME_ERR_ARG;
     return me::scs_table(ctx, keys, w, n, scs_radius, scs);
-}
-
-int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out) {
-    if (!ctx) return ME_ERR_ARG;
-    if (!p || !out) return ctx->fail(ME_ERR_ARG, "me_run_suite: NULL argument");
-    if (ctx->shard_world != 1 || ctx->slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_run_suite is single-GPU; drive the partial calls when sharded");
-    std::memset(out, 0, sizeof(*out));
-    // stage_ms: host wall clock per stage (every stage below ends with a stream synchronisation)
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
-    // MME first, as MapEval::process (map_eval.cpp:52-66)
-    if (p->evaluate_mme) {
-        double s = 0;
-        int64_t nv = 0;
-        auto t0 = now();
-        ME_TRY(me_mme(ctx, ME_SLOT_EST, p->nn_radius, 10, nullptr, nullptr, &s, &nv));  // k >= 10 (:1675)
-        out->stage_ms[4] = ms_since(t0);
-        out->mme_est = nv > 0 ? s / (double) nv : 0.0;
-        out->mme_est_valid = nv;
-        if (p->evaluate_gt_mme) {
-            t0 = now();
-            ME_TRY(me_mme(ctx, ME_SLOT_GT, p->nn_radius, 5, nullptr, nullptr, &s, &nv));  // k >= 5 (:1458)
-            out->stage_ms[5] = ms_since(t0);
-            out->mme_gt = nv > 0 ? s / (double) nv : 0.0;
-            out->mme_gt_valid = nv;
-        }
-    }
-    // AC / COM both directions (:1213-1242) + full CD (:1398-1431) from the same two searches
-    auto t0 = now();
-    ME_TRY(me::nn_search(ctx, ME_SLOT_EST, ME_SLOT_GT));
-    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    out->stage_ms[1] = ms_since(t0);
-    t0 = now();
-    ME_TRY(me_nn_stats(ctx, ME_SLOT_EST, p->icp_max_distance, p->gate_mode, p->trunc, &out->est_gt));
-    out->stage_ms[3] = ms_since(t0);
-    t0 = now();
-    ME_TRY(me::nn_search(ctx, ME_SLOT_GT, ME_SLOT_EST));
-    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    out->stage_ms[2] = ms_since(t0);
-    t0 = now();
-    ME_TRY(me_nn_stats(ctx, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &out->gt_est));
-    out->stage_ms[3] += ms_since(t0);
-    out->full_chamfer = out->est_gt.mean_nn_dist + out->gt_est.mean_nn_dist;
-    // AWD / SCS (:85, :240-390)
-    int64_t n_rows = 0;
-    t0 = now();
-    ME_TRY(me_awd_scs(ctx, p->vmd_voxel_size, p->min_pts > 0 ? p->min_pts : 100, p->scs_radius > 0 ? p->scs_radius : 5, nullptr,
-                      nullptr, &n_rows, &out->awd, &out->scs, nullptr));
-    out->stage_ms[6] = ms_since(t0);
-    out->n_w_voxels = n_rows;
-    return ME_OK;
 }
 
 int me_timers_enable(me_ctx *ctx, int on) {

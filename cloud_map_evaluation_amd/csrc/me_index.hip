@@ -535,6 +535,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
     c.have_normals = c.have_cov = false;
     c.slab = ctx->slab;
     c.n_unres = 0;
+    c.sort_pairs_hint = false;  // (a new cloud: the dense-cloud fallback of the packed sort is decided again, cloud_build_index)
     c.slab_identity = true;  // (the filtered slab upload below clears it; a stale `false` would make me_slab_points read an old slab_orig)
     bool bbox_ready = false;
     // prefiltered: slab mode, but the caller guarantees that every point lies inside [reg_lo, reg_hi) (the halo exchange
@@ -623,8 +624,11 @@ int cloud_finish(me_ctx *ctx, int slot, bool bbox_ready) {
     if (!bbox_ready)  // (an upload from a device buffer has produced the partials in its single pass, k_ingest)
         hipLaunchKernelGGL(k_bbox, dim3(nb), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, ctx->red.as<double>());
     std::vector<double> part((size_t) nb * 6);
-    ME_TRY(mail_post(ctx, part.data(), ctx->red.p, part.size() * sizeof(double)));
-    ME_TRY(mail_sync(ctx));
+    {
+        MailGuard mg(ctx);
+        ME_TRY(mail_post(ctx, part.data(), ctx->red.p, part.size() * sizeof(double)));
+        ME_TRY(mg.sync());
+    }
     for (int d = 0; d < 3; ++d) {
         double lo = INFINITY, hi = -INFINITY;
         for (unsigned int b = 0; b < nb; ++b) {
@@ -707,7 +711,9 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     c.fine_h = std::ldexp(cell_h, -c.shift);
     c.index_valid = false;
     c.mme_have = false;  // (the sorted order changes)
+#ifdef ME_AB
     c.mme_feat_valid = false;
+#endif
     c.nn_ref_slot = -1;
     ctx->cloud[1 - slot].nn_ref_slot = -1;
 
@@ -718,17 +724,17 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     ME_CHECK(ctx, perm.ensure((size_t) n * 4));
     ME_CHECK(ctx, c.codes.ensure((size_t) n * 8));
     ME_CHECK(ctx, c.sp.ensure((size_t) n * sizeof(SPoint)));
-    // ME_SORT_DEPTH: levels below the search cell that the order (and therefore the choice of the 1-NN grid) may use
-    static const int sort_depth = std::getenv("ME_SORT_DEPTH") ? std::atoi(std::getenv("ME_SORT_DEPTH")) : 2;
-    // ME_HILBERT=0: points sorted along the Z curve (the first version) for A/B measurements
-    static const int hilbert = std::getenv("ME_HILBERT") ? std::atoi(std::getenv("ME_HILBERT")) : 1;
+    // levels below the search cell that the order (and therefore the choice of the 1-NN grid) may use
+    constexpr int sort_depth = ME_TUNE_SORT_DEPTH;
+    // ME_FLAG_MORTON_ORDER: points sorted along the Z curve (the first version) — tests / A-B measurements
+    const int hilbert = ctx->morton_order ? 0 : 1;
     // Keys-only sort when key and index fit one 64-bit word (round 4, k_morton): 3 (21 - min_level) key bits + ceil(log2 n) index
     // bits.  A 50 M-point cloud at a 0.1 m cell in a 200 m scene needs 33 + 3 depth + 26: depth 1 fits, depth 2 does not.  The depth
     // is lowered to make it fit — and if the 1-NN grid then lands on the finest sorted level (a dense cloud, which might have chosen
     // a finer one had it been sorted), the index is rebuilt with the pair sort at the full depth and the slot remembers it.
     int idx_bits = 1;
     while ((1LL << idx_bits) < n) ++idx_bits;
-    static const int pack_allowed = std::getenv("ME_SORT_PACK") ? std::atoi(std::getenv("ME_SORT_PACK")) : 1;
+    constexpr int pack_allowed = ME_TUNE_SORT_PACK;
     int sort_min_level = std::max(0, c.shift - std::max(0, sort_depth));
     int pack_bits = 0;
     if (pack_allowed && !c.sort_pairs_hint) {
@@ -778,8 +784,11 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
         hipLaunchKernelGGL(k_level_hist, dim3((unsigned int) std::min<long long>(1024, (n + 255) / 256)), dim3(256), 0,
                            ctx->stream, c.codes.as<unsigned long long>(), n, d_hist);
         unsigned long long h_hist[32];
-        ME_TRY(mail_post(ctx, h_hist, d_hist, sizeof(h_hist)));
-        ME_TRY(mail_sync(ctx));
+        {
+            MailGuard mg(ctx);
+            ME_TRY(mail_post(ctx, h_hist, d_hist, sizeof(h_hist)));
+            ME_TRY(mg.sync());
+        }
         long long acc = 1;
         for (int k = kMortonBits; k >= 0; --k) {  // level k: cell edge fine_h * 2^k
             if (k < kMortonBits) acc += (long long) h_hist[k];
@@ -788,7 +797,7 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
         // 1-NN grid: the finest level whose occupied cells hold >= 6 points on average (27-cell stencil ~ a few
         // hundred candidates per query at most, yet a guaranteed radius of one cell edge resolves almost all queries)
         int nn_shift = kMortonBits - 1;
-        static const double nn_occ = std::getenv("ME_NN_OCC") ? std::atof(std::getenv("ME_NN_OCC")) : 6.0;  // tuning knob (measured: 6 beats 12 and 3 on the bench scene)
+        constexpr double nn_occ = ME_TUNE_NN_OCC;
         for (int k = sort_min_level; k < kMortonBits; ++k)  // (levels below sort_min_level are not sorted: counts meaningless)
             if ((double) n / (double) c.level_unique[k] >= nn_occ) {
                 nn_shift = k;

@@ -17,7 +17,6 @@ namespace me {
 constexpr int kFan = 8;        // children per octree node
 constexpr int kMaxLevels = 17; // octree levels above the leaf cells (taken-masks: 2 x 64 bits)
 constexpr int kMortonBits = 21;
-constexpr unsigned int kXcdChunk = 128;  // virtual blocks per XCD chunk (see xcd_virtual_block)
 
 struct DevBuf {
     void *p = nullptr;
@@ -175,13 +174,14 @@ struct Cloud {
     bool vox_merged = false;  // the table is the cross-rank merge of partials (me_voxel_merge_device): complete on every rank
     DevBuf mme_ent, mme_val;  // last me_mme of this cloud, sorted order: entropy (0 where invalid), validity byte
     bool mme_have = false;
-    // matrix-pipe MME (me_mme7.hip): digit features of the sorted points, per radius-grid cell padded to 16-candidate chunks
+#ifdef ME_AB  // measurement build only (profiles/ab/me_mme7.hip): digit features of the matrix-pipe MME kernel
     DevBuf mme_feat;        // [n_chunks][80 columns][16 candidates] signed bytes
     DevBuf mme_cell_chunk;  // uint32[n_cells + 1] first chunk of every cell
     bool mme_feat_valid = false, mme_feat_usable = false;
     double mme_feat_radius = 0;
     long long mme_fx_origin[3] = {0, 0, 0};
     int mme_fx_scale = 0;
+#endif
     DevBuf vox_tmp;    // build scratch (segment starts when they outgrow the shared scratch)
     DevBuf vox_key;    // uint64[V] packed key
     DevBuf vox_n;      // int32[V]
@@ -235,6 +235,7 @@ struct me_ctx {
     size_t host_pinned_bytes = 0;
     int shard_rank = 0, shard_world = 1;
     bool borrow_device_input = false;   // me_create flag ME_FLAG_BORROW_DEVICE_INPUT
+    bool morton_order = false;          // me_create flag ME_FLAG_MORTON_ORDER: points sorted along the Z curve instead of the Hilbert curve
     me::SlabView slab{-1, 0, 0, 0, 0};  // applied to the next uploads
     // instrumentation
     bool timers_on = false;
@@ -248,6 +249,8 @@ struct me_ctx {
     long long nn_fallback = 0, nn_queries = 0;  // counted only while timers are on
     me::DevBuf nn_far;                           // queries whose octree walk k_nn1 handed over to k_nn_far
     me::DevBuf nn_flags, nn_list_a, nn_list_b;   // 1-NN cascade: unresolved flags of the fine-grid pass, their ordered list, ping-pong
+    me::DevBuf mme_keep_e, mme_keep_v;           // me_run_suite_from: the map's per-point MME result across its transform (mme_carry_*)
+    long long mme_keep_n = -1;
     me::DevBuf nn1_dbg_buf;                      // octree-walk counters (nodes opened, leaves scanned, points, max per query)
     unsigned long long *nn1_dbg() {
         if (!nn1_dbg_buf.p) {
@@ -299,20 +302,52 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
     ~TimerScope() { end(); }
 };
 
-// chunk size of the XCD-aware block order (ME_XCD_CHUNK overrides; a huge value = one contiguous piece per XCD)
-inline unsigned int xcd_chunk_setting() {
-    static const unsigned int v = [] {
-        const char *e = std::getenv("ME_XCD_CHUNK");
-        const long x = e ? std::atol(e) : (long) kXcdChunk;
-        return (unsigned int) (x > 0 ? x : kXcdChunk);
-    }();
-    return v;
-}
+// ---- tuning constants.  Compile-time only: the library reads NOTHING from the environment (a drop-in must not change its behaviour
+// with the caller's environment).  Measurement builds override them on the command line (make EXTRA=-DME_TUNE_...=v); the values
+// below are the measured optima (profiles/EXPERIMENTS.md, profiles/README.md "measurement knobs").
+#ifndef ME_TUNE_XCD_CHUNK
+#define ME_TUNE_XCD_CHUNK 128     // virtual blocks per XCD chunk (xcd_virtual_block); a huge value = one contiguous piece per XCD
+#endif
+#ifndef ME_TUNE_SORT_DEPTH
+#define ME_TUNE_SORT_DEPTH 2      // Morton levels below the search cell that the sort order (and the choice of the 1-NN grid) may use
+#endif
+#ifndef ME_TUNE_SORT_PACK
+#define ME_TUNE_SORT_PACK 1       // keys-only sort of packed (key, index) words when they fit 64 bits (0: always the pair sort)
+#endif
+#ifndef ME_TUNE_NN_OCC
+#define ME_TUNE_NN_OCC 6.0        // points per occupied cell the 1-NN grid level is chosen for (6 beats 3 and 12 on the bench scene)
+#endif
+#ifndef ME_TUNE_MME_LEADER_ORIGIN
+#define ME_TUNE_MME_LEADER_ORIGIN 1  // k_mme3: moments accumulated about the round leader's point (staged once per candidate) instead of each lane's own query
+#endif
+#ifndef ME_TUNE_NN1_FAR_CAP
+#define ME_TUNE_NN1_FAR_CAP 64    // octree steps after which k_nn1 hands a walk over to k_nn_far (0 = never)
+#endif
+#ifndef ME_TUNE_NN_FAR_LEAF
+#define ME_TUNE_NN_FAR_LEAF 1024  // points a node may hold for k_nn_far to scan it whole instead of descending further
+#endif
+inline unsigned int xcd_chunk_setting() { return (unsigned int) ME_TUNE_XCD_CHUNK; }
 
 // ---- me_api.hip: small results to the host without a blit kernel (see me_ctx::mail_h) ----
 constexpr size_t kMailBytes = 128 * 1024;
 int mail_post(me_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);  // asynchronous on ctx->stream
 int mail_sync(me_ctx *ctx);                                                     // hipStreamSynchronize + delivery of what was posted
+void mail_drop(me_ctx *ctx);                                                    // forget what was posted (nothing is delivered)
+// The host destinations of mail_post are usually LOCALS of the posting function: if it returns before its mail_sync (a failed
+// allocation or launch in between), the queued entries must not survive it — the next mail_sync on the context would copy into a
+// dead stack frame.  A MailGuard in scope between the first mail_post and the mail_sync drops them on every early return.
+struct MailGuard {
+    me_ctx *c;
+    bool armed = true;
+    explicit MailGuard(me_ctx *ctx) : c(ctx) {}
+    int sync() {
+        armed = false;
+        return mail_sync(c);
+    }
+    ~MailGuard() {
+        if (armed) mail_drop(c);
+    }
+};
 
 // ---- me_prims.hip (rocPRIM-backed primitives) ----
 int sort_pairs_u64_u32(me_ctx *ctx, const unsigned long long *k_in, unsigned long long *k_out,
@@ -351,14 +386,18 @@ int get_covariances(me_ctx *ctx, int slot, double *cov_host);
 int rotate_attributes(me_ctx *ctx, int slot, const double *T);
 int icp_lsq_sums(me_ctx *ctx, int qslot, int mode, double max_distance, me_icp_lsq *out);
 
-// ---- me_mme7.hip (round 4's matrix-pipe MME kernel: measurement builds only, -DME_AB) ----
+#ifdef ME_AB  // ---- profiles/ab/me_mme7.hip (round 4's matrix-pipe MME kernel: measurement build only) ----
 int mme7_prepare(me_ctx *ctx, Cloud &c, double radius, bool *usable);
 int mme7_launch(me_ctx *ctx, Cloud &c, long long b, long long e, unsigned int nb, double radius, int min_k, double *ent_s,
                 unsigned char *valid_s, double *part_sum, long long *part_cnt);
+#endif
 
 // ---- me_mme.hip ----
 int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, uint8_t *valid, double *sum_H,
             long long *n_valid);
+int mme_fetch(me_ctx *ctx, int slot, double *entropies, uint8_t *valid);
+int mme_carry_out(me_ctx *ctx, int slot);  // park the slot's per-point MME result in cloud order (before a transform re-indexes it)
+int mme_carry_in(me_ctx *ctx, int slot);   // ... and put it back in the new sorted order
 
 // ---- me_dist.hip (multi-GPU pieces) ----
 int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, const double *cuts_host, int world, double halo,
@@ -642,7 +681,8 @@ template <int H = 1, bool CULL = false, int R = kGroupR, bool MLP = false>
 __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, int cz, const GridView &g, int cell_lim,
                                                  int lane, int2 *tab, GroupBox &box, int *n_keys_out = nullptr,
                                                  unsigned int *rows = nullptr, unsigned short *tcell = nullptr,
-                                                 unsigned int *tabc = nullptr, const unsigned int *cell_aux = nullptr) {
+                                                 unsigned int *tabc = nullptr, const unsigned int *cell_aux = nullptr,
+                                                 int *leader_out = nullptr) {
     const unsigned long long pm = __ballot(pending);  // caller guarantees pm != 0
 #ifdef ME_LEADER_FIRST
     const int leader = __ffsll((long long) pm) - 1;
@@ -678,6 +718,7 @@ __device__ __forceinline__ bool wave_group_table(bool pending, int cx, int cy, i
     }
 #endif
 #endif
+    if (leader_out) *leader_out = leader;
     const int lx = readlane_i(cx, leader), ly = readlane_i(cy, leader), lz = readlane_i(cz, leader);
     const int ex = cx - lx, ey = cy - ly, ez = cz - lz;
     const bool in = pending && ex >= -R && ex <= R && ey >= -R && ey <= R && ez >= -R && ez <= R;

@@ -296,262 +296,9 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
   }
 }
 
-#ifdef ME_AB
-// ------------------------------------------------------------------------------------------------------------
-// k_nn_grid_mfma (round 3, MEASURED AND NOT ADOPTED: 18.5 ms per step against k_nn_grid's 12.8, results identical;
-// profiles/EXPERIMENTS.md "Round 3") — k_nn_grid with the ranking on the matrix pipe.  Same wave, same run table, same staging, same
-// exact epilogue; only the loop that ranked every candidate with three FP32 FMAs per lane (25 VALU instructions per group of
-// four candidates and 64 queries) is replaced: r = |p'|^2 - 2 p'.q' is the K = 4 contraction (p'x, p'y, p'z, |p'|^2).(ax, ay,
-// az, 1), one v_mfma_f32_16x16x4_f32 per 16 candidates x 16 queries, four per block for the wave's four query groups; a lane
-// then owns one group of four stream-consecutive candidates per block and query group: one min + one three-smallest update.
-// The result is the same exact minimum (the ranking only SELECTS the two groups the fp64 epilogue evaluates; the
-// third-rank gap check guards it as before; the MFMA is an exact fmaf chain, its error is inside rank_tol like the VALU
-// chain's).
-// ------------------------------------------------------------------------------------------------------------
-typedef float nn_f32x4 __attribute__((ext_vector_type(4)));
-template <int WAVES>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-k_nn_grid_mfma(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
-          GridView g,
-          FrameView fr, SlabView slab, double *__restrict__ d2_out, int *__restrict__ idx_out,
-          unsigned int *__restrict__ list, unsigned int *__restrict__ list_count, unsigned int xcd_chunk) {
-    const int lane = threadIdx.x & 63;
-    const unsigned int vb = xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);  // gridDim.x is a multiple of 8
-    const long long i = q_begin + (long long) vb * blockDim.x + threadIdx.x;
-    bool active = i < q_end;
-    const int cell_bits = kMortonBits - g.shift;
-    const int cell_lim = 1 << cell_bits;
-    const double cell_h = ldexp(fr.fine_h, g.shift);
-
-    double qx = 0, qy = 0, qz = 0;
-    int mcx = 0, mcy = 0, mcz = 0;  // the query's cell in the REFERENCE cloud's grid
-    bool in_grid = false;
-    if (active) {
-        const SPoint q = qsp[i];
-        qx = q.x;
-        qy = q.y;
-        qz = q.z;
-        if (!slab_owned(slab, qx, qy, qz)) {  // halo point: a reference for others, not a query of this rank
-            d2_out[i] = -1.0;                 // skip marker for the statistics kernels
-            idx_out[i] = -1;
-            active = false;
-        }
-    }
-    if (active) {
-        const double fx = fine_coord(qx, fr.ox, fr.fine_h), fy = fine_coord(qy, fr.oy, fr.fine_h),
-                     fz = fine_coord(qz, fr.oz, fr.fine_h);
-        const double lim = 2097151.0;
-        in_grid = fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx <= lim && fy <= lim && fz <= lim;
-        if (in_grid) {
-            mcx = (int) ((unsigned int) fx >> g.shift);
-            mcy = (int) ((unsigned int) fy >> g.shift);
-            mcz = (int) ((unsigned int) fz >> g.shift);
-        }
-    }
-    // MFMA layout of the ranking (round 3): lane (s = lane / 16, j = lane % 16) ranks, for each of the wave's four query groups
-    // g (queries 16 g + j), the candidates 4 s .. 4 s + 3 of every 16-candidate block: b1[g] <= b2[g] <= b3[g] are the three
-    // smallest GROUP ranks this slice has seen for that query, j1[g] / j2[g] the positions of the groups behind the two
-    // smallest.  The four slices are merged at the end; lane 16 g + j keeps group g's result (its own query's).
-    float b1[4], b2[4], b3[4];
-    int j1[4], j2[4];
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        b1[gq] = b2[gq] = b3[gq] = INFINITY;
-        j1[gq] = j2[gq] = -1;
-    }
-    const int sl = lane >> 4, qj = lane & 15;
-    bool done = !active || !in_grid;
-
-    // Ranking.  argmin_p |p - q|^2 = argmin_p (|p|^2 - 2 p.q).  With the candidates shifted to a wave-local origin o (the
-    // corner of the round's cell box, |p - o| and |q - o| < 8 cells) the rank
-    //     r = fma(p'x, ax, fma(p'y, ay, fma(p'z, az, |p'|^2))),   p' = p - o,  a = -2 (q - o)
-    // is accurate enough in FP32 to ORDER candidates down to ~1e-6 (cell edge 0.1 m) of squared distance: p' and |p'|^2
-    // are computed in fp64 ONCE per candidate when its run is staged and stored as one float4, so a candidate costs one
-    // 16-byte broadcast LDS read and 3 fp32 FMAs per lane (the fp64 variant of this loop was bound by LDS bandwidth:
-    // 32 bytes per candidate broadcast to 64 lanes).  The loop keeps the two best GROUPS of <= 4 stream-consecutive
-    // candidates (rank + position) and the third-best rank.  The epilogue evaluates both groups EXACTLY in fp64
-    // ((dx*dx + dy*dy) + dz*dz, the CPU path's value; ties -> smallest original index, as the CPU path) — every
-    // candidate outside them ranks at least b3, so the exact minimum over the two groups is the answer whenever
-    // b3 - b1 exceeds twice the rank error (rank_tol).  The few lanes where it does not (about 0.05 %: three near-equal
-    // neighbours, or duplicates spread over three groups) go to the octree kernel, which is exact.
-    // bias = 0 for the lanes of the current round's group, +inf for the others: a lane ranks candidates in exactly one
-    // round (one origin), never sees a candidate twice, and the loop needs no exec juggling for the predicate.
-    float ax = 0, ay = 0, az = 0, bias = INFINITY;
-    // rank error: the cell box spans <= 7 cells per axis, so |p'| <= 12 h, |a| <= 24 h, every term of r is below ~150 h^2
-    // and carries a few 2^-24 relative: E < 1.2e-4 h^2 in the worst case (typically 10x less); the check uses 2E with margin
-    const float rank_tol = (float) (1e-3 * cell_h * cell_h);
-    // (b1 <= b2 <= b3 are the three smallest ranks seen: the new second is the median of {b1, b2, m}, the new third the
-    // median of {b2, b3, m} — one v_med3_f32 each; fminf/fmaxf chains cost three times as many instructions, most of them
-    // NaN canonicalisations of values that are never NaN)
-    auto note = [&](float &c1, float &c2, float &c3, int &p1, int &p2, float m, int j) {
-        const bool lt1 = m < c1, lt2 = m < c2;
-        c3 = __builtin_amdgcn_fmed3f(c2, c3, m);
-        c2 = __builtin_amdgcn_fmed3f(c1, c2, m);
-        const int jn = lt2 ? j : p2;  // (two selects, no branch)
-        p2 = lt1 ? p1 : jn;
-        c1 = lt1 ? m : c1;
-        p1 = lt1 ? j : p1;
-    };
-    float bq[4] = {0.f, 0.f, 0.f, 0.f}, gbias[4] = {INFINITY, INFINITY, INFINITY, INFINITY};  // per query group: B operand, bias
-    // Candidate delivery.  A run (the points of one cell) is copied into a wave-private LDS tile with ONE coalesced vector
-    // load per 64 points and read back with wave-uniform (broadcast) ds_reads, four candidates per group.  The first
-    // version fetched the candidates with scalar loads (s_load, candidate in SGPRs): the scalar cache misses on this
-    // stream (rocprofv3 SQC counters: 75 % of the requests), so every group of four paid an L2 round trip that 8 waves
-    // per SIMD could not hide (68 % VALU issue).
-    __shared__ float4 s_tile[4][64];  // (doubles as the row masks of the adjacency cull while a round's table is built)
-    float4 *tile = s_tile[threadIdx.x >> 6];
-    double ox = 0, oy = 0, oz = 0;  // the round's local origin (wave-uniform)
-    // A run is padded to a multiple of four with records of rank +inf: no scalar tail loop (with 6-point cells most runs end
-    // in a partial group, and a lone candidate costs a whole note()).
-    // (Measured and rejected: candidates stored in pairs and ranked two at a time with v_pk_fma_f32 — 19 instead of 25
-    // instructions per group of four, yet 13.8 ms against 13.0: the packed FMA does not issue faster than two plain ones.)
-    // A operand of block b: feature (lane / 16) of candidate 16 b + lane % 16 (rows in stream order: result register r of
-    // slice s is candidate 16 b + 4 s + r, i.e. a lane holds one GROUP of four stream-consecutive candidates per block)
-    const float *tile_a = reinterpret_cast<const float *>(tile) + qj * 4 + sl;
-    auto stream_run = [&](int cs, int ce) {
-        for (int base = cs; base < ce; base += 64) {
-            const int n = min(64, ce - base), n4 = (n + 15) & ~15;  // padded to whole 16-candidate blocks (rank +inf)
-            if (lane < n4) {
-                float4 rec = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
-                if (lane < n) {
-                    const SPoint p = rsp[base + lane];
-                    const double px = p.x - ox, py = p.y - oy, pz = p.z - oz;
-                    rec = make_float4((float) px, (float) py, (float) pz, (float) fma(pz, pz, fma(py, py, px * px)));
-                }
-                tile[lane] = rec;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // one v_mfma_f32_16x16x4_f32 ranks 16 candidates against the 16 queries of a group: r = (p'x, p'y, p'z, |p'|^2).(ax, ay, az, 1)
-            // (an exact fmaf chain); the lane's four results are one group of four: min (med3 with -inf: ranks are never NaN) + note
-            for (int jb = 0; jb < n4; jb += 16) {
-                const float a_op = tile_a[jb * 4];
-                const int pos = base + jb + 4 * sl;
-                const nn_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                // (two MFMAs in flight, not four: eight result registers instead of sixteen)
-#pragma unroll
-                for (int gh = 0; gh < 4; gh += 2) {
-                    const nn_f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, bq[gh], zero, 0, 0, 0);
-                    const nn_f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, bq[gh + 1], zero, 0, 0, 0);
-                    const float m0 = __builtin_amdgcn_fmed3f(-INFINITY, d0[0], __builtin_amdgcn_fmed3f(-INFINITY, d0[1], __builtin_amdgcn_fmed3f(-INFINITY, d0[2], d0[3])));
-                    note(b1[gh], b2[gh], b3[gh], j1[gh], j2[gh], m0 + gbias[gh], pos);
-                    const float m1 = __builtin_amdgcn_fmed3f(-INFINITY, d1[0], __builtin_amdgcn_fmed3f(-INFINITY, d1[1], __builtin_amdgcn_fmed3f(-INFINITY, d1[2], d1[3])));
-                    note(b1[gh + 1], b2[gh + 1], b3[gh + 1], j1[gh + 1], j2[gh + 1], m1 + gbias[gh + 1], pos);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
-        }
-    };
-    // (the candidate set of a round is a superset of the lane's own 3x3x3 block; extra candidates only help)
-    __shared__ int2 s_tab[4][kGroupTab + 1];
-    int2 *tab = s_tab[threadIdx.x >> 6];
-    while (__ballot(!done)) {
-        GroupBox bx;
-        int nk = 0;
-        // (cull: a run adjacent to no lane of the group is in nobody's 3x3x3 block, so nobody's resolution test needs it)
-        const bool in = wave_group_table<1, true>(!done, mcx, mcy, mcz, g, cell_lim, lane, tab, bx, &nk,
-                                                  reinterpret_cast<unsigned int *>(tile));
-        ox = uniform_f64(fr.ox + (double) bx.x0 * cell_h);  // (scalar registers: wave-uniform)
-        oy = uniform_f64(fr.oy + (double) bx.y0 * cell_h);
-        oz = uniform_f64(fr.oz + (double) bx.z0 * cell_h);
-        if (in) {
-            ax = (float) (-2.0 * (qx - ox));
-            ay = (float) (-2.0 * (qy - oy));
-            az = (float) (-2.0 * (qz - oz));
-        }
-        bias = in ? 0.0f : INFINITY;
-        // the B operand of query group g: row (lane / 16) of (a, 1) of the query in lane 16 g + lane % 16; its bias likewise
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int src = 16 * gq + qj;
-            const float sx = __shfl(ax, src, 64), sy = __shfl(ay, src, 64), sz = __shfl(az, src, 64);
-            bq[gq] = sl == 0 ? sx : (sl == 1 ? sy : (sl == 2 ? sz : 1.0f));
-            gbias[gq] = __shfl(bias, src, 64);
-        }
-        wave_for_each_run<true>(tab, nk, lane, [&](int cs, int ce, int) { stream_run(cs, ce); });
-        if (in) done = true;
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    // merge the four slices of every query group (lanes l, l^16, l^32, l^48 hold the same query's partial rankings): the
-    // partner's two best groups go through note(), its third rank can only lower the third; then lane 16 g + j takes group g
-    float fb1 = INFINITY, fb3 = INFINITY;
-    int fj1 = -1, fj2 = -1;
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-#pragma unroll
-        for (int stage = 0; stage < 2; ++stage) {
-            float o1, o2, o3;
-            int q1, q2;
-            const int x = stage == 0 ? 16 : 32;  // (once per wave: plain ds_bpermute exchanges)
-            o1 = __shfl_xor(b1[gq], x, 64);
-            o2 = __shfl_xor(b2[gq], x, 64);
-            o3 = __shfl_xor(b3[gq], x, 64);
-            q1 = __shfl_xor(j1[gq], x, 64);
-            q2 = __shfl_xor(j2[gq], x, 64);
-            note(b1[gq], b2[gq], b3[gq], j1[gq], j2[gq], o1, q1);
-            note(b1[gq], b2[gq], b3[gq], j1[gq], j2[gq], o2, q2);
-            b3[gq] = __builtin_amdgcn_fmed3f(-INFINITY, b3[gq], o3);  // min (o3 >= o2, which is in already)
-        }
-        if (sl == gq) {
-            fb1 = b1[gq];
-            fb3 = b3[gq];
-            fj1 = j1[gq];
-            fj2 = j2[gq];
-        }
-    }
-    const float b1s = fb1, b3s = fb3;
-    const int j1s = fj1, j2s = fj2;
-
-    bool unresolved = false;
-    if (active) {
-        unresolved = true;
-        // exact distances of the two best groups (positions past a group's run belong to cells outside the candidate set:
-        // real reference points all the same, so a closer one among them is a better answer, not an error)
-        double best_x = INFINITY;
-        long long best_i = 0x7fffffffffffffffLL;
-        auto exact_group = [&](int jg) {
-            if (jg < 0) return;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const long long pos = (long long) jg + t;
-                if (pos < nr) {
-                    const SPoint p = rsp[pos];
-                    const double e = dist2_exact(qx, qy, qz, p.x, p.y, p.z);
-                    if (e < best_x || (e == best_x && p.idx < best_i)) {
-                        best_x = e;
-                        best_i = p.idx;
-                    }
-                }
-            }
-        };
-        exact_group(j1s);
-        exact_group(j2s);
-        const bool ranking_safe = b3s - b1s > rank_tol;
-        if (in_grid && j1s >= 0 && ranking_safe) {
-            // distance from q to the faces of the 3x3x3 cell block around its cell (>= one cell edge... minus where
-            // q sits in its cell); anything outside the block is at least that far away
-            const double lox = fr.ox + (double) (mcx - 1) * cell_h, hix = fr.ox + (double) (mcx + 2) * cell_h;
-            const double loy = fr.oy + (double) (mcy - 1) * cell_h, hiy = fr.oy + (double) (mcy + 2) * cell_h;
-            const double loz = fr.oz + (double) (mcz - 1) * cell_h, hiz = fr.oz + (double) (mcz + 2) * cell_h;
-            double gmin = fmin(fmin(qx - lox, hix - qx), fmin(fmin(qy - loy, hiy - qy), fmin(qz - loz, hiz - qz)));
-            gmin *= (1.0 - 1e-9);  // rounding slack of the cell assignment
-            unresolved = !(gmin > 0.0 && best_x < gmin * gmin);
-        }
-        d2_out[i] = best_x;  // final if resolved, initial bound otherwise
-        idx_out[i] = (j1s >= 0) ? (int) best_i : -1;
-    }
-    // wave-aggregated append of the unresolved lanes
-    const unsigned long long um = __ballot(unresolved);
-    if (um) {
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(list_count, (unsigned int) __popcll(um));
-        base = (unsigned int) readlane_i((int) base, 0);
-        if (unresolved) list[base + (unsigned int) __popcll(um & ((1ULL << lane) - 1ULL))] = (unsigned int) (i - q_begin);
-    }
-}
-#endif  // ME_AB
+#ifdef ME_AB  // measurement build only (make -C profiles/ab): the matrix-pipe ranking that was measured and not adopted
+#include "me_nn_kernels_ab.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // General path: nearest-first walk of the sparse octree (see the header).  `list` == nullptr: every query of
@@ -1212,16 +959,10 @@ __global__ void k_nn_patch(const unsigned int *__restrict__ list, long long m, c
     d2[i] = fmin(d2[i], d2_new[t]);
 }
 
-// steps after which k_nn1 hands a walk over to k_nn_far (ME_NN1_FAR_CAP; 0 = never: the first version's behaviour)
-static int nn1_far_cap() {
-    static const int v = std::getenv("ME_NN1_FAR_CAP") ? std::atoi(std::getenv("ME_NN1_FAR_CAP")) : 64;
-    return v <= 0 ? 0x7fffffff : v;
-}
-// points a node may hold for k_nn_far to scan it whole instead of descending further (ME_NN_FAR_LEAF)
-static int nn_far_leaf() {
-    static const int v = std::getenv("ME_NN_FAR_LEAF") ? std::atoi(std::getenv("ME_NN_FAR_LEAF")) : 1024;
-    return v < 1 ? 1 : v;
-}
+// steps after which k_nn1 hands a walk over to k_nn_far (0 = never: the first version's behaviour)
+static constexpr int nn1_far_cap() { return ME_TUNE_NN1_FAR_CAP <= 0 ? 0x7fffffff : ME_TUNE_NN1_FAR_CAP; }
+// points a node may hold for k_nn_far to scan it whole instead of descending further
+static constexpr int nn_far_leaf() { return ME_TUNE_NN_FAR_LEAF < 1 ? 1 : ME_TUNE_NN_FAR_LEAF; }
 constexpr unsigned int kFarGrid = 1024;  // blocks of four wavefronts striding over the far list (empty list: immediate return)
 static size_t nn1_cache_bytes(const OctView &oct) { return (size_t) (kNn1Block / 8) * (size_t) (oct.n_levels + 1) * (8 + 9) * 4; }
 
@@ -1268,18 +1009,8 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         unsigned int *cnt_a = two_pass ? d_cnt + 2 : d_cnt;
         {
             TimerScope ts(ctx, "nn_grid");
-#ifdef ME_AB  // A/B build: ME_NN_GRID_V=2 runs round 3's MFMA ranking, ME_NN_GRID_WAVES its occupancy
-            static const int grid_v = std::getenv("ME_NN_GRID_V") ? std::atoi(std::getenv("ME_NN_GRID_V")) : 1;
-            static const int grid_w = std::getenv("ME_NN_GRID_WAVES") ? std::atoi(std::getenv("ME_NN_GRID_WAVES")) : 8;
-            if (grid_v == 2 && grid_w < 8)
-                hipLaunchKernelGGL((k_nn_grid_mfma<5>), dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
-                                   r.n, r.nn_grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt,
-                                   xcd_chunk_setting());
-            else if (grid_v == 2)
-                hipLaunchKernelGGL((k_nn_grid_mfma<8>), dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
-                                   r.n, r.nn_grid, fr, q.slab, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt,
-                                   xcd_chunk_setting());
-            else
+#ifdef ME_AB
+#include "me_nn_dispatch_ab.inc"
 #endif
             {
                 hipLaunchKernelGGL((k_nn_grid<false>), dim3(nb), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(),
@@ -1453,9 +1184,12 @@ int nn_partial(me_ctx *ctx, int qslot, double gate, int gate_mode, const double 
     }
     double hd[kStatD];
     long long hi[kStatI];
-    ME_TRY(mail_post(ctx, hd, pd + (size_t) nb * kStatD, sizeof(hd)));
-    ME_TRY(mail_post(ctx, hi, pi + (size_t) nb * kStatI, sizeof(hi)));
-    ME_TRY(mail_sync(ctx));
+    {
+        MailGuard mg(ctx);  // (hd / hi are locals)
+        ME_TRY(mail_post(ctx, hd, pd + (size_t) nb * kStatD, sizeof(hd)));
+        ME_TRY(mail_post(ctx, hi, pi + (size_t) nb * kStatI, sizeof(hi)));
+        ME_TRY(mg.sync());
+    }
     out->n_query = e - b;
     out->n_corr = hi[0];
     for (int k = 0; k < 5; ++k) {
@@ -1486,8 +1220,11 @@ int nn_sigma(me_ctx *ctx, int qslot, double gate, int gate_mode, const double me
         hipLaunchKernelGGL(k_nn_sigma, dim3(nb), dim3(256), 0, ctx->stream, q.nn_d2.as<double>(), b, e, sp, m, pd);
         hipLaunchKernelGGL(k_final_sum_d, dim3(5), dim3(256), 0, ctx->stream, pd, nb, 5, pd + (size_t) nb * 5);
     }
-    ME_TRY(mail_post(ctx, sigma_num, pd + (size_t) nb * 5, 5 * 8));
-    ME_TRY(mail_sync(ctx));
+    {
+        MailGuard mg(ctx);
+        ME_TRY(mail_post(ctx, sigma_num, pd + (size_t) nb * 5, 5 * 8));
+        ME_TRY(mg.sync());
+    }
     return ME_OK;
 }
 

@@ -1,0 +1,278 @@
+// me_suite.hip — the whole hot path in ONE call: what MapEval::process() runs between "clouds loaded" and "results written"
+// (map_eval.cpp:52-85: computeMME :56, calculateMetricsWithInitialMatrix :76, calculateVMD :85).
+//
+// me_run_suite        the stages back to back on the context's stream, clouds already uploaded (round 1).
+// me_run_suite_from   the same stages starting from the two RAW clouds (host or device pointers), scheduled on TWO lanes: the
+//                     calling thread drives `ctx`, an internal host thread drives me_twin(ctx) — the schedule that bench.py
+//                     measured from Python through round 4 (dist._Lane), now behind the C ABI so that a C++ caller (the bundled
+//                     host, the INTEGRATION.md section B patch of the reference's own process()) gets it with one call from its
+//                     one thread.  Same kernels, same call order per product, results bit-identical to the sequential call.
+//
+//   main lane (ctx, highest stream priority)            second lane (twin, lowest priority)
+//   ---------------------------------------            ----------------------------------------------------------------
+//   upload + index the map                              [host input: wait until the map has crossed the link]
+//   MME of the map            (VALU-bound)              upload + index the ground truth     (HBM-bound, under the MME)
+//   [T: transform + re-index the map, :1206]            voxel Gaussians of the ground truth
+//   wait: ground truth indexed                          wait: map final
+//   MME of the ground truth                             voxel Gaussians of the map
+//   1-NN map -> ground truth + partial sums             1-NN ground truth -> map + partial sums
+//   join; sigma passes; AWD / CDF / SCS
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "me_internal.hpp"
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+inline double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+bool is_identity(const double *T) {
+    if (!T) return true;
+    for (int i = 0; i < 16; ++i)
+        if (T[i] != ((i % 5 == 0) ? 1.0 : 0.0)) return false;
+    return true;
+}
+
+// the second lane of me_run_suite_from
+struct SuiteLane {
+    me_ctx *t = nullptr;  // the twin context
+    const me_suite_params *p = nullptr;
+    const double *gt = nullptr;
+    long long n_gt = 0;
+    bool gt_on_device = false, upload_gt = false, wait_for_link = false;
+    std::mutex m;
+    std::condition_variable cv;
+    bool est_on_device = false;  // main -> lane: the map's H2D copy is over (the link is free)
+    bool est_final = false;      // main -> lane: the map is indexed in its final pose
+    bool gt_ready = false;       // lane -> main: the ground truth is indexed (or the lane has failed)
+    bool aborted = false;        // main -> lane: stop at the next wait
+    std::atomic<int> rc{ME_OK};
+    me_nn_partial back{};        // ground truth -> map partial sums
+    std::thread th;
+
+    void set(bool SuiteLane::*flag) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            this->*flag = true;
+        }
+        cv.notify_all();
+    }
+    // false: aborted
+    bool wait(bool SuiteLane::*flag) {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return this->*flag || aborted; });
+        return !aborted;
+    }
+    void run() {
+        rc = body();
+        set(&SuiteLane::gt_ready);  // (a failed lane must not leave the main lane waiting)
+    }
+    int body() {
+        if (hipSetDevice(t->device) != hipSuccess) return t->fail(ME_ERR_HIP, "me_run_suite_from: hipSetDevice failed on the second lane");
+        if (upload_gt) {
+            // clouds that start in HOST memory share the PCIe link: one after the other, the ground truth crosses it under the
+            // map's MME kernel.  Device-resident clouds: both lanes start at once.
+            if (wait_for_link && !wait(&SuiteLane::est_on_device)) return ME_OK;
+            ME_TRY(me::cloud_upload(t, ME_SLOT_GT, gt, gt_on_device, n_gt, nullptr, p->nn_radius));
+        }
+        set(&SuiteLane::gt_ready);
+        ME_TRY(me::voxel_build(t, ME_SLOT_GT, p->vmd_voxel_size, false));
+        if (!wait(&SuiteLane::est_final)) return ME_OK;
+        ME_TRY(me::voxel_build(t, ME_SLOT_EST, p->vmd_voxel_size, false));
+        ME_TRY(me::nn_search(t, ME_SLOT_GT, ME_SLOT_EST));
+        ME_TRY(me::nn_partial(t, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &back));
+        return ME_OK;
+    }
+    void abort_and_join() {
+        {
+            std::lock_guard<std::mutex> g(m);
+            aborted = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
+int finish_stats(me_ctx *ctx, const me_suite_params *p, const me_nn_partial &pe, const me_nn_partial &pg, me_suite_out *out) {
+    // second pass: sigma needs the mean of every threshold (map_eval.cpp:1132-1138)
+    double mean[5], sig[5];
+    for (int k = 0; k < 5; ++k) mean[k] = pe.sum_d[k] / (double) pe.n_corr;
+    ME_TRY(me::nn_sigma(ctx, ME_SLOT_EST, p->icp_max_distance, p->gate_mode, mean, sig));
+    me_nn_finalize(&pe, sig, ctx->cloud[ME_SLOT_EST].n, &out->est_gt);
+    for (int k = 0; k < 5; ++k) mean[k] = pg.sum_d[k] / (double) pg.n_corr;
+    ME_TRY(me::nn_sigma(ctx, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, mean, sig));
+    me_nn_finalize(&pg, sig, ctx->cloud[ME_SLOT_GT].n, &out->gt_est);
+    out->full_chamfer = out->est_gt.mean_nn_dist + out->gt_est.mean_nn_dist;  // computeChamferDistance (:1429)
+    return ME_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out) {
+    if (!ctx) return ME_ERR_ARG;
+    if (!p || !out) return ctx->fail(ME_ERR_ARG, "me_run_suite: NULL argument");
+    if (ctx->shard_world != 1 || ctx->slab.axis >= 0) return ctx->fail(ME_ERR_STATE, "me_run_suite is single-GPU; drive the partial calls when sharded");
+    std::memset(out, 0, sizeof(*out));
+    const auto t_all = Clock::now();
+    // stage_ms: host wall clock per stage (every stage below ends with a stream synchronisation)
+    // MME first, as MapEval::process (map_eval.cpp:52-66)
+    if (p->evaluate_mme) {
+        double s = 0;
+        int64_t nv = 0;
+        auto t0 = Clock::now();
+        ME_TRY(me_mme(ctx, ME_SLOT_EST, p->nn_radius, 10, nullptr, nullptr, &s, &nv));  // k >= 10 (:1675)
+        out->stage_ms[4] = ms_since(t0);
+        out->mme_est = nv > 0 ? s / (double) nv : 0.0;
+        out->mme_est_valid = nv;
+        if (p->evaluate_gt_mme) {
+            t0 = Clock::now();
+            ME_TRY(me_mme(ctx, ME_SLOT_GT, p->nn_radius, 5, nullptr, nullptr, &s, &nv));  // k >= 5 (:1458)
+            out->stage_ms[5] = ms_since(t0);
+            out->mme_gt = nv > 0 ? s / (double) nv : 0.0;
+            out->mme_gt_valid = nv;
+        }
+    }
+    // AC / COM both directions (:1213-1242) + full CD (:1398-1431) from the same two searches
+    auto t0 = Clock::now();
+    ME_TRY(me::nn_search(ctx, ME_SLOT_EST, ME_SLOT_GT));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    out->stage_ms[1] = ms_since(t0);
+    t0 = Clock::now();
+    ME_TRY(me_nn_stats(ctx, ME_SLOT_EST, p->icp_max_distance, p->gate_mode, p->trunc, &out->est_gt));
+    out->stage_ms[3] = ms_since(t0);
+    t0 = Clock::now();
+    ME_TRY(me::nn_search(ctx, ME_SLOT_GT, ME_SLOT_EST));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    out->stage_ms[2] = ms_since(t0);
+    t0 = Clock::now();
+    ME_TRY(me_nn_stats(ctx, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &out->gt_est));
+    out->stage_ms[3] += ms_since(t0);
+    out->full_chamfer = out->est_gt.mean_nn_dist + out->gt_est.mean_nn_dist;
+    // AWD / SCS (:85, :240-390)
+    int64_t n_rows = 0;
+    t0 = Clock::now();
+    ME_TRY(me_awd_scs(ctx, p->vmd_voxel_size, p->min_pts > 0 ? p->min_pts : 100, p->scs_radius > 0 ? p->scs_radius : 5, nullptr,
+                      nullptr, &n_rows, &out->awd, &out->scs, nullptr));
+    out->stage_ms[6] = ms_since(t0);
+    out->n_w_voxels = n_rows;
+    out->stage_ms[7] = ms_since(t_all);
+    return ME_OK;
+}
+
+int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const double *gt, int64_t n_gt, const double *T,
+                      const me_suite_params *p, int flags, me_suite_out *out) {
+    if (!ctx) return ME_ERR_ARG;
+    if (!p || !out) return ctx->fail(ME_ERR_ARG, "me_run_suite_from: NULL argument");
+    if (ctx->is_twin) return ctx->fail(ME_ERR_ARG, "me_run_suite_from: call it on the primary context");
+    if (ctx->shard_world != 1 || ctx->slab.axis >= 0)
+        return ctx->fail(ME_ERR_STATE, "me_run_suite_from is single-GPU; drive the partial calls when sharded");
+    if ((est == nullptr) != (gt == nullptr)) return ctx->fail(ME_ERR_ARG, "me_run_suite_from: pass both clouds, or neither (clouds already uploaded)");
+    const bool upload = est != nullptr;
+    if (!upload && (!ctx->cloud[ME_SLOT_EST].uploaded || !ctx->cloud[ME_SLOT_GT].uploaded))
+        return ctx->fail(ME_ERR_STATE, "me_run_suite_from: no clouds passed and none uploaded");
+    const bool on_device = (flags & ME_SUITE_DEVICE_INPUT) != 0;
+    const bool overlap = (flags & ME_SUITE_OVERLAP) != 0;
+    const bool moved = !is_identity(T);  // the map is evaluated for MME as loaded and transformed afterwards (:56 then :1206)
+    std::memset(out, 0, sizeof(*out));
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    const auto t_all = Clock::now();
+
+    SuiteLane lane;
+    if (overlap) {
+        lane.t = me_twin(ctx);
+        if (!lane.t) return ME_ERR_HIP;  // (me_twin has set the message)
+        lane.p = p;
+        lane.gt = gt;
+        lane.n_gt = n_gt;
+        lane.gt_on_device = on_device;
+        lane.upload_gt = upload;
+        lane.wait_for_link = upload && !on_device;
+        lane.th = std::thread([&lane] { lane.run(); });
+    }
+    // everything the main lane does; on failure the second lane is stopped and joined before returning
+    auto main_lane = [&]() -> int {
+        auto t0 = Clock::now();
+        if (upload) {
+            ME_TRY(me::cloud_upload(ctx, ME_SLOT_EST, est, on_device, n_est, nullptr, p->nn_radius));
+            if (overlap) lane.set(&SuiteLane::est_on_device);
+            if (!overlap) ME_TRY(me::cloud_upload(ctx, ME_SLOT_GT, gt, on_device, n_gt, nullptr, p->nn_radius));
+        } else if (overlap) {
+            lane.set(&SuiteLane::est_on_device);
+        }
+        out->stage_ms[0] = ms_since(t0);
+        if (overlap && !moved) lane.set(&SuiteLane::est_final);
+        if (p->evaluate_mme) {
+            double s = 0;
+            long long nv = 0;
+            t0 = Clock::now();
+            ME_TRY(me::mme_run(ctx, ME_SLOT_EST, p->nn_radius, 10, nullptr, nullptr, &s, &nv));  // k >= 10 (:1675)
+            out->stage_ms[4] = ms_since(t0);
+            out->mme_est = nv > 0 ? s / (double) nv : 0.0;
+            out->mme_est_valid = nv;
+        }
+        if (moved) {  // *map_3d_ = map_3d_->Transform(initial_matrix) (:1206), after the MME of the map as loaded (:56)
+            t0 = Clock::now();
+            if (p->evaluate_mme) ME_TRY(me::mme_carry_out(ctx, ME_SLOT_EST));
+            ME_TRY(me::cloud_transform(ctx, ME_SLOT_EST, T));
+            if (p->evaluate_mme) ME_TRY(me::mme_carry_in(ctx, ME_SLOT_EST));
+            out->stage_ms[0] += ms_since(t0);
+            if (overlap) lane.set(&SuiteLane::est_final);
+        }
+        if (overlap) {
+            lane.wait(&SuiteLane::gt_ready);
+            if (lane.rc.load() != ME_OK) return lane.rc.load();
+        }
+        if (p->evaluate_mme && p->evaluate_gt_mme) {
+            double s = 0;
+            long long nv = 0;
+            t0 = Clock::now();
+            ME_TRY(me::mme_run(ctx, ME_SLOT_GT, p->nn_radius, 5, nullptr, nullptr, &s, &nv));  // k >= 5 (:1458)
+            out->stage_ms[5] = ms_since(t0);
+            out->mme_gt = nv > 0 ? s / (double) nv : 0.0;
+            out->mme_gt_valid = nv;
+        }
+        // AC / COM both directions (:1213-1242) + full CD (:1398-1431) from the same two searches
+        me_nn_partial pe{}, pg{};
+        t0 = Clock::now();
+        ME_TRY(me::nn_search(ctx, ME_SLOT_EST, ME_SLOT_GT));
+        ME_TRY(me::nn_partial(ctx, ME_SLOT_EST, p->icp_max_distance, p->gate_mode, p->trunc, &pe));
+        out->stage_ms[1] = ms_since(t0);
+        t0 = Clock::now();
+        if (overlap) {
+            lane.th.join();  // the second lane has searched the other direction meanwhile (and built both voxel tables)
+            if (lane.rc.load() != ME_OK) return lane.rc.load();
+            pg = lane.back;
+        } else {
+            ME_TRY(me::nn_search(ctx, ME_SLOT_GT, ME_SLOT_EST));
+            ME_TRY(me::nn_partial(ctx, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &pg));
+        }
+        out->stage_ms[2] = ms_since(t0);
+        t0 = Clock::now();
+        ME_TRY(finish_stats(ctx, p, pe, pg, out));
+        out->stage_ms[3] = ms_since(t0);
+        // AWD / CDF / SCS (:85, :240-390); the voxel tables are cached on the clouds when the second lane built them
+        int64_t n_rows = 0;
+        t0 = Clock::now();
+        ME_TRY(me_awd_scs(ctx, p->vmd_voxel_size, p->min_pts > 0 ? p->min_pts : 100, p->scs_radius > 0 ? p->scs_radius : 5, nullptr,
+                          nullptr, &n_rows, &out->awd, &out->scs, nullptr));
+        out->stage_ms[6] = ms_since(t0);
+        out->n_w_voxels = n_rows;
+        return ME_OK;
+    };
+    const int rc = main_lane();
+    if (overlap) {
+        if (lane.th.joinable()) lane.abort_and_join();
+        if (rc != ME_OK && rc == lane.rc.load() && lane.t) ctx->err = lane.t->err;  // the second lane's failure: its message
+    }
+    out->stage_ms[7] = ms_since(t_all);
+    return rc;
+}
+
+}  // extern "C"

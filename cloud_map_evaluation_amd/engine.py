@@ -63,11 +63,12 @@ def _addr(a) -> int:
 
 
 class Engine:
-    def __init__(self, device: int = 0, borrow_device_input: bool = False):
+    def __init__(self, device: int = 0, borrow_device_input: bool = False, morton_order: bool = False):
         """borrow_device_input: ME_FLAG_BORROW_DEVICE_INPUT — cuda tensors uploaded without a transform are read where they lie
-        (no copy); the Engine keeps a reference to them until the slot's next upload, the caller must not modify them meanwhile."""
+        (no copy); the Engine keeps a reference to them until the slot's next upload, the caller must not modify them meanwhile.
+        morton_order: ME_FLAG_MORTON_ORDER — Z curve instead of the Hilbert curve (tests / measurements)."""
         self._L = _lib.load()
-        self._ctx = self._L.me_create(int(device), 1 if borrow_device_input else 0)
+        self._ctx = self._L.me_create(int(device), (1 if borrow_device_input else 0) | (2 if morton_order else 0))
         self._held = {}  # slot -> the array / tensor of its last upload (borrowed device inputs must outlive their use)
         if not self._ctx:
             raise MapEvalError(self._L.me_last_error(None).decode())
@@ -522,6 +523,12 @@ class Engine:
 
     # ---- whole suite ----
     def run_suite(self, p: Param, gate_mode: int = ME_GATE_LE_UNSQUARED) -> _lib.SuiteOut:
+        sp = self._suite_params(p, gate_mode)
+        out = _lib.SuiteOut()
+        self._ck(self._L.me_run_suite(self._ctx, C.byref(sp), C.byref(out)))
+        return out
+
+    def _suite_params(self, p: Param, gate_mode: int) -> _lib.SuiteParams:
         sp = _lib.SuiteParams()
         sp.icp_max_distance = p.icp_max_distance_
         sp.gate_mode = gate_mode
@@ -533,9 +540,65 @@ class Engine:
         sp.evaluate_gt_mme = int(p.evaluate_gt_mme_)
         sp.min_pts = 100
         sp.scs_radius = 5
+        return sp
+
+    def run_suite_from(self, est, gt, p: Param, overlap: bool = True, gate_mode: int = ME_GATE_LE_UNSQUARED) -> _lib.SuiteOut:
+        """me_run_suite_from: the whole pass of MapEval::process (map_eval.cpp:52-85) from the two raw clouds in ONE library call —
+        uploads, index builds, MME x2 (the map as loaded), p.initial_matrix_ (:1206), both 1-NN directions + statistics, voxel
+        Gaussians, AWD / CDF / SCS; overlap: the library's internal second lane (ME_SUITE_OVERLAP).  est / gt: (N,3) float64 numpy
+        arrays or torch tensors (both host or both cuda); None, None: the clouds already uploaded."""
+        flags = _lib.ME_SUITE_OVERLAP if overlap else 0
+        ne = ng = 0
+        if est is not None:
+            on_dev = []
+            arrs = []
+            for a in (est, gt):
+                if isinstance(a, np.ndarray):
+                    a = np.ascontiguousarray(a, dtype=np.float64)
+                    on_dev.append(False)
+                else:
+                    import torch
+
+                    if a.dtype != torch.float64 or not a.is_contiguous():
+                        a = a.to(torch.float64).contiguous()
+                    on_dev.append(bool(a.is_cuda))
+                    if a.is_cuda:
+                        torch.cuda.current_stream(a.device).synchronize()  # producer stream -> library stream hand-over
+                if a.ndim != 2 or a.shape[1] != 3:
+                    raise ValueError("expected (N,3) arrays")
+                arrs.append(a)
+            if on_dev[0] != on_dev[1]:
+                raise ValueError("run_suite_from: both clouds in host memory, or both on the device")
+            est, gt = arrs
+            if on_dev[0]:
+                flags |= _lib.ME_SUITE_DEVICE_INPUT
+            ne, ng = int(est.shape[0]), int(gt.shape[0])
+            self._held[ME_SLOT_EST], self._held[ME_SLOT_GT] = est, gt
+        Tm = np.ascontiguousarray(p.initial_matrix_, dtype=np.float64).reshape(16)
+        sp = self._suite_params(p, gate_mode)
         out = _lib.SuiteOut()
-        self._ck(self._L.me_run_suite(self._ctx, C.byref(sp), C.byref(out)))
+        self._ck(self._L.me_run_suite_from(self._ctx, _addr(est), ne, _addr(gt), ng, _addr(Tm), C.byref(sp), flags, C.byref(out)))
         return out
+
+    @staticmethod
+    def suite_dict(o: _lib.SuiteOut) -> dict:
+        """A SuiteOut as the dict dist.suite_step returns (same keys, same numbers)."""
+        def d(s):
+            f = lambda x: np.array(list(x), dtype=np.float64)
+            return dict(n_corr=int(s.n_corr), number=f(s.number), mean=f(s.mean), rmse=f(s.rmse), fitness=f(s.fitness),
+                        sigma=f(s.sigma), mean_nn=float(s.mean_nn_dist))
+        eg, ge = d(o.est_gt), d(o.gt_est)
+        return dict(est_gt=eg, gt_est=ge, ac=eg["rmse"], com=eg["fitness"], cd=float(o.full_chamfer), mme_est=float(o.mme_est),
+                    mme_gt=float(o.mme_gt), mme_valid=int(o.mme_est_valid), awd=float(o.awd), scs=float(o.scs), n_w=int(o.n_w_voxels),
+                    n_est=int(o.est_gt.n_src), n_gt=int(o.gt_est.n_src), stage_ms=[float(x) for x in o.stage_ms])
+
+    def mme_fetch(self, slot: int):
+        """me_mme_fetch: (entropies[N], valid[N]) of the slot's last MME pass, cloud order."""
+        n = self.size(slot)
+        ent = np.zeros(n, np.float64)
+        val = np.zeros(n, np.uint8)
+        self._ck(self._L.me_mme_fetch(self._ctx, slot, _addr(ent), _addr(val)))
+        return ent, val
 
     # ---- instrumentation ----
     def timers_enable(self, on: bool = True):

@@ -219,6 +219,17 @@ int MapEval::process() {
         return fail(std::string("GPU engine unavailable: ") + me_last_error(nullptr));
     }
     me_timers_enable(ctx_, 1);
+    // The initial-matrix evaluation on one GPU is ONE library call (processOneCall: me_run_suite_from): without down-sampling it
+    // starts from the host clouds as they were read — the uploads are part of the call's two-lane schedule.
+    const bool one_call = param_.evaluate_using_initial_ && !comm_;
+    if (one_call && !(param_.downsample_size > 0)) {
+        file_result << std::fixed << std::setprecision(15) << "Estimated-Ground Truth point count: " << map_3d_->size() << " / "
+                    << gt_3d_->size() << std::endl;
+        if (param_.enable_debug)
+            std::cout << "INFO: Loaded point clouds: " << map_3d_->size() << " points (Map), " << gt_3d_->size()
+                      << " points (Ground Truth)." << std::endl;
+        return processOneCall(true, tic_toc.toc());
+    }
     if (me_upload_cloud(ctx_, ME_SLOT_GT, gt_3d_->points_.data(), (int64_t) gt_3d_->size(), nullptr, param_.nn_radius_) != ME_OK ||
         me_upload_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data(), (int64_t) map_3d_->size(), nullptr, param_.nn_radius_) != ME_OK)
         return fail(me_last_error(ctx_));
@@ -246,6 +257,7 @@ int MapEval::process() {
         std::cout << "INFO: Loaded point clouds: " << map_3d_->size() << " points (Map), " << gt_3d_->size()
                   << " points (Ground Truth)." << std::endl;
     if (comm_) return processDist(tic_toc.toc());  // num_gpus > 1 (map_eval_dist.cpp)
+    if (one_call) return processOneCall(false, tic_toc.toc());  // (the down-sampled clouds are resident)
     t1 = tic_toc.toc();
     // The reference computes MME on the map as loaded (:56) and transforms it afterwards, inside
     // calculateMetricsWithInitialMatrix (:1206): same order here (me_transform_cloud below), skipped for an identity matrix.
@@ -573,6 +585,91 @@ bool MapEval::renderEntropy(int slot, std::vector<double> &xyz, std::vector<doub
         return false;
     }
     return true;
+}
+
+// MapEval::process()'s metric phase (map_eval.cpp:52-85: computeMME :56, calculateMetricsWithInitialMatrix :76, calculateVMD :85)
+// as ONE call into the library, made from this one thread (process() is single-threaded, :4): me_run_suite_from runs the stages
+// on two lanes (its second lane is a thread inside the library, csrc/me_suite.hip).  The reference's member functions keep their
+// roles below as CONSUMERS of what the call left on the device: entropies / colour maps, result vectors, the voxel files.
+int MapEval::processOneCall(bool from_host, double t_loaded) {
+    t1 = t_loaded;
+    TicToc clock;
+    me_suite_params sp{};
+    sp.icp_max_distance = param_.icp_max_distance_;
+    sp.gate_mode = ME_GATE_LE_UNSQUARED;  // d2 <= icp_max_distance (:1219, sic)
+    for (int k = 0; k < 5; ++k) sp.trunc[k] = param_.trunc_dist_[k];
+    sp.nn_radius = param_.nn_radius_;
+    sp.vmd_voxel_size = param_.vmd_voxel_size_;
+    sp.evaluate_mme = param_.evaluate_mme_ ? 1 : 0;
+    sp.evaluate_gt_mme = param_.evaluate_gt_mme_ ? 1 : 0;
+    sp.min_pts = 100;
+    sp.scs_radius = 5;
+    me_suite_out so;
+    const double *T = param_.initial_matrix_.data();
+    bool identity = true;
+    for (int i = 0; i < 16; ++i) identity = identity && (T[i] == ((i % 5 == 0) ? 1.0 : 0.0));
+    const int rc = from_host ? me_run_suite_from(ctx_, map_3d_->points_.data(), (int64_t) map_3d_->size(), gt_3d_->points_.data(),
+                                                 (int64_t) gt_3d_->size(), T, &sp, ME_SUITE_OVERLAP, &so)
+                             : me_run_suite_from(ctx_, nullptr, 0, nullptr, 0, T, &sp, ME_SUITE_OVERLAP, &so);
+    if (rc != ME_OK) return fail(me_last_error(ctx_));
+    const double suite_ms = clock.toc();
+    std::cout << std::fixed << std::setprecision(3) << "INFO: metric phase, one me_run_suite_from call (two lanes): " << suite_ms
+              << " ms for " << map_3d_->size() << " + " << gt_3d_->size() << " points [index " << so.stage_ms[0] << ", mme " << so.stage_ms[4]
+              << " + " << so.stage_ms[5] << ", nn " << so.stage_ms[1] << " + " << so.stage_ms[2] << ", stats " << so.stage_ms[3]
+              << ", awd/scs " << so.stage_ms[6] << "]" << std::endl;
+    std::cout.unsetf(std::ios::floatfield);
+    std::cout << std::setprecision(6);
+    // ---- computeMME's members (:149-189) ----
+    if (param_.evaluate_mme_) {
+        mme_est = so.mme_est;
+        mme_gt = so.mme_gt;
+        if (param_.save_immediate_result_) {  // the per-point arrays are fetched only when something is written from them
+            est_entropies.assign(map_3d_->size(), 0.0);
+            valid_entropy_points.assign(map_3d_->size(), 0);
+            if (me_mme_fetch(ctx_, ME_SLOT_EST, est_entropies.data(), valid_entropy_points.data()) != ME_OK) return fail(me_last_error(ctx_));
+        }
+        if (!renderEntropy(ME_SLOT_EST, map_entropy_xyz, map_entropy_rgb, param_.save_immediate_result_)) return -1;
+        if (!identity && param_.save_immediate_result_) {
+            // map_3d_entropy is built from the map AS LOADED (:179, before :1206): the colours above are those of the untransformed
+            // map's entropies, the coordinates are taken from the host's copy, which is still untransformed here
+            size_t k = 0;
+            for (size_t i = 0; i < valid_entropy_points.size() && 3 * k + 2 < map_entropy_xyz.size(); ++i)
+                if (valid_entropy_points[i]) {
+                    for (int d = 0; d < 3; ++d) map_entropy_xyz[3 * k + d] = map_3d_->points_[3 * i + d];
+                    ++k;
+                }
+        }
+        const int64_t nv = so.mme_est_valid;
+        if (param_.enable_debug)
+            std::cout << "TBB MME Valid_points " << nv * 100.0 / (double) map_3d_->size() << "% " << nv << " " << map_3d_->size() << std::endl;
+        if (nv * 100.0 / (double) map_3d_->size() < 0.6) std::cerr << "valid points is too small, please check the input point cloud" << std::endl;
+        if (param_.evaluate_gt_mme_) {
+            if (param_.save_immediate_result_) {
+                gt_entropies.assign(gt_3d_->size(), 0.0);
+                if (me_mme_fetch(ctx_, ME_SLOT_GT, gt_entropies.data(), nullptr) != ME_OK) return fail(me_last_error(ctx_));
+            }
+            if (!renderEntropy(ME_SLOT_GT, gt_entropy_xyz, gt_entropy_rgb, param_.save_immediate_result_)) return -1;
+            std::cout << "MME EST-GT: " << mme_est << " " << mme_gt << std::endl;
+        } else {
+            std::cout << "MME EST: " << mme_est << std::endl;
+        }
+        if (param_.save_immediate_result_) saveMmeResults();
+    }
+    t2 = t1 + so.stage_ms[0] + so.stage_ms[4] + so.stage_ms[5];
+    // ---- calculateMetricsWithInitialMatrix's members (:1204-1260) ----
+    if (param_.enable_debug) std::cout << "INFO: Using initial matrix without registration." << std::endl;
+    if (!identity && me_download_cloud(ctx_, ME_SLOT_EST, map_3d_->points_.data()) != ME_OK)  // *map_3d_ = map_3d_->Transform(..) (:1206)
+        return fail(me_last_error(ctx_));
+    finishInitialMatrixMetrics(so.est_gt, so.gt_est, so.stage_ms[1] / 1000.0);
+    t_fcd += so.stage_ms[2] / 1000.0;  // the gt -> est search is what the full Chamfer distance adds (:1194)
+    t5 = t4 = t3 = t2 + so.stage_ms[1] + so.stage_ms[2] + so.stage_ms[3];
+    // ---- calculateVMD (:240-390): the voxel tables are cached on the clouds, AWD / CDF / SCS are O(voxels) ----
+    calculateVMD();
+    if (!last_error.empty()) return -1;
+    if (param_.enable_debug) std::cout << "INFO: VMD calculation completed." << std::endl;
+    if (param_.save_immediate_result_) saveRegistrationResults();
+    if (param_.enable_debug) std::cout << "INFO: Results saved successfully." << std::endl;
+    return 0;
 }
 
 void MapEval::computeMME(PointCloud &cloud, PointCloud &gt) {

@@ -63,6 +63,7 @@ public:
     ~MapEval();
 
     int process();                                         // map_eval.cpp:4-102
+    int processOneCall(bool from_host, double t_loaded);   // its metric phase (:52-85) as one me_run_suite_from call
     void computeMME(PointCloud &cloud, PointCloud &gt);    // map_eval.cpp:149-189
     void calculateMetricsWithInitialMatrix();              // map_eval.cpp:1204-1260
     void finishInitialMatrixMetrics(const me_nn_stats_out &eg, const me_nn_stats_out &ge, double t_acc_s);  // its tail (:1238-1259)

@@ -67,13 +67,17 @@ typedef struct me_nn_stats_out {
 } me_nn_stats_out;
 
 /* ---- lifetime ---------------------------------------------------------------------------------------------- */
-/* device: HIP device ordinal (one context per GPU).  flags: 0, or ME_FLAG_BORROW_DEVICE_INPUT.  NULL on failure. */
+/* device: HIP device ordinal (one context per GPU).  flags: 0, or an OR of the ME_FLAG_* below.  NULL on failure.
+ * The library reads nothing from the environment: every behaviour switch is a flag here or a compile-time constant. */
 me_ctx *me_create(int device, int flags);
 /* ME_FLAG_BORROW_DEVICE_INPUT: me_upload_cloud_device / me_upload_slab_device without a transform (T NULL or the identity) read the
  * caller's device buffer WHERE IT LIES instead of copying it: the caller keeps it valid and unchanged until the slot's next upload
  * (or me_destroy).  Saves one 48-byte-per-point pass per cloud; calls that modify the cloud in place (me_transform_cloud,
  * me_voxel_downsample) switch to a private copy first.  No reference counterpart (Open3D owns its points_). */
 #define ME_FLAG_BORROW_DEVICE_INPUT 1
+/* ME_FLAG_MORTON_ORDER: sort the points along the Z (Morton) curve instead of the Hilbert curve.  An implementation detail of the index
+ * — counts identical, fp results equal to rounding (tests/test_gpu_order.py) — kept as a test / measurement switch. */
+#define ME_FLAG_MORTON_ORDER 2
 void me_destroy(me_ctx *ctx);
 const char *me_last_error(me_ctx *ctx); /* ctx may be NULL: returns the last me_create error */
 int me_version(void);
@@ -295,6 +299,9 @@ int me_chamfer(me_ctx *ctx, double *cd);
  * sum_H / n_valid (0 when n_valid == 0, :1720-1724). */
 int me_mme(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, uint8_t *valid, double *sum_H,
            int64_t *n_valid);
+/* The per-point arrays of the slot's LAST MME pass (me_mme, me_run_suite, me_run_suite_from), as me_mme returns them: what
+ * est_entropies / valid_entropy_points / gt_entropies hold after computeMME (map_eval.cpp:149-189).  Either may be NULL. */
+int me_mme_fetch(me_ctx *ctx, int slot, double *entropies, uint8_t *valid);
 
 /* ---- voxel Gaussians: VoxelCalculator::buildVoxelMap + computeVoxelEntropy (voxel_calculator.cpp:21-56,97-113) */
 /* Output rows are in ascending (ix,iy,iz) order.  sigma is AS STORED by the reference after buildVoxelMap, i.e.
@@ -344,10 +351,32 @@ typedef struct me_suite_out {
     double awd, scs;        /* vmd / scs_overall */
     int64_t n_w_voxels;
     double stage_ms[8];     /* host wall clock per stage (each ends with a stream sync): [1] nn est->gt, [2] nn gt->est,
-                             * [3] statistics, [4] mme est, [5] mme gt, [6] voxel Gaussians + AWD + CDF + SCS; [0], [7] unused (0) */
+                             * [3] statistics, [4] mme est, [5] mme gt, [6] voxel Gaussians + AWD + CDF + SCS, [7] the whole call;
+                             * [0]: me_run_suite_from only (upload + index) */
 } me_suite_out;
 
 int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out);
+
+/* The same pass STARTING FROM THE TWO RAW CLOUDS — one call for everything MapEval::process() does between VoxelDownSample
+ * (map_eval.cpp:38-39) and the result writers: upload + index of both clouds, computeMME(map_3d_, gt_3d_) (:56) on the map AS
+ * LOADED, *map_3d_ = map_3d_->Transform(T) (:1206; T row-major 4x4, NULL or the identity = none), both 1-NN directions with the
+ * AC / COM / CD statistics (:76), voxel Gaussians, AWD, CDF, SCS (:85).  The caller stays single-threaded (as process() is, :4).
+ *   est / gt           double[n][3] — host memory, or device memory with ME_SUITE_DEVICE_INPUT; both NULL = run on the clouds
+ *                      already uploaded to the two slots (e.g. after me_voxel_downsample).
+ *   ME_SUITE_OVERLAP   two lanes: the calling thread drives `ctx`, an internal thread drives me_twin(ctx) on its own low-priority
+ *                      stream — the ground truth is uploaded / indexed and both voxel tables are built UNDER the map's VALU-bound
+ *                      MME kernel, and each lane searches one 1-NN direction (schedule: csrc/me_suite.hip).  Same kernels on the
+ *                      same data: every result is bit-identical to the call without the flag and to me_run_suite.
+ * Afterwards the per-point products are on the device as after the separate calls: me_mme_fetch, me_nn_fetch,
+ * me_render_entropy / me_render_distance, me_awd_scs(rows, w_sorted) (cached tables), me_download_cloud (the transformed map).
+ * stage_ms: wall clock of the calling thread per stage — [0] upload + index (+ transform) of the map (without ME_SUITE_OVERLAP: of
+ * both clouds), [1] 1-NN map -> ground truth + partial sums, [2] the other direction (with ME_SUITE_OVERLAP: the wait for the second
+ * lane), [3] sigma passes, [4] MME map, [5] MME ground truth, [6] AWD + CDF + SCS (+ voxel tables without the second lane),
+ * [7] the whole call. */
+#define ME_SUITE_OVERLAP 1
+#define ME_SUITE_DEVICE_INPUT 2
+int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const double *gt, int64_t n_gt, const double *T_rowmajor4x4,
+                      const me_suite_params *p, int flags, me_suite_out *out);
 
 /* ---- instrumentation (bench.py roofline leg) ------------------------------------------------------------- */
 /* Average device time (ms, HIP events on the context's stream) and launch count of a named kernel family since

@@ -1,4 +1,4 @@
-// Host-side check of cloud_map_evaluation_amd/csrc/me_mme_fx.hpp (the integer arithmetic of the matrix-pipe MME kernel):
+// Host-side check of profiles/ab/me_mme_fx.hpp (the integer arithmetic of the matrix-pipe MME kernel):
 // digit features -> column sums over an accepted subset (what v_mfma_i32_16x16x64_i8 accumulates) -> moments about the query,
 // against (a) exact __int128 arithmetic on the same fixed-point coordinates and (b) the fp64 sums the vector kernel forms.
 // Built and run by tests/test_mme_fx_cpu.py (g++, no GPU).
@@ -8,7 +8,7 @@
 #include <random>
 #include <vector>
 
-#include "../../cloud_map_evaluation_amd/csrc/me_mme_fx.hpp"
+#include "../../profiles/ab/me_mme_fx.hpp"
 
 using namespace me::fx;
 

@@ -1,4 +1,4 @@
-"""The order the points are sorted in (Hilbert curve by default, Z curve with ME_HILBERT=0) is an implementation detail of the
+"""The order the points are sorted in (Hilbert curve by default, Z curve with ME_FLAG_MORTON_ORDER) is an implementation detail of the
 index: every count must be identical under both, every floating-point result equal to rounding (a query's neighbours are
 accumulated cell by cell in the same raster order, the points of one cell in the order of the sort)."""
 import json
@@ -20,7 +20,7 @@ from cloud_map_evaluation_amd import synth
 from cloud_map_evaluation_amd.engine import Engine, Param
 dev = torch.device("cuda", 0)
 est, gt = synth.multisession_pair(600_000, density=2500.0, seed=7, device=dev)
-with Engine(0) as eng:
+with Engine(0, morton_order=(sys.argv[1] == "z")) as eng:
     eng.upload(0, est, cell_size=0.1)
     eng.upload(1, gt, cell_size=0.1)
     out = eng.run_suite(Param(icp_max_distance_=1.0, nn_radius_=0.1, vmd_voxel_size_=3.0))
@@ -34,15 +34,14 @@ print(json.dumps({"num_eg": list(out.est_gt.number), "num_ge": list(out.gt_est.n
 """ % ROOT
 
 
-def _run(hilbert: str) -> dict:
-    env = dict(os.environ, ME_HILBERT=hilbert)
-    r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env, timeout=600)
+def _run(curve: str) -> dict:
+    r = subprocess.run([sys.executable, "-c", SCRIPT, curve], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def test_results_do_not_depend_on_the_curve_the_points_are_sorted_along():
-    h, z = _run("1"), _run("0")
+    h, z = _run("h"), _run("z")
     for k in ("num_eg", "num_ge", "n_corr", "mme_valid", "idx_sum", "valid_sum", "nv"):
         assert h[k] == z[k], k  # counts, neighbour indices, validity flags: identical
     assert h["d2_sum"] == z["d2_sum"] or abs(h["d2_sum"] - z["d2_sum"]) <= 1e-12 * abs(z["d2_sum"])  # (sum order of the test only)

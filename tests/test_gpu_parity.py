@@ -312,7 +312,11 @@ def test_sharded_partials_sum_to_the_whole(eng, cube):
     np.testing.assert_allclose(tot_d[:5] / whole.n_corr, whole.mean, rtol=1e-12)
     assert mme_c == wm[3]
     np.testing.assert_allclose(mme_s, wm[4], rtol=1e-12)
-    assert np.array_equal(ent, wm[1])  # every point's entropy computed by exactly one shard
+    # every point's entropy is computed by exactly one shard.  Since round 5 the moments are accumulated about the point of the
+    # wavefront's group leader (me_mme.hip): a shard boundary shifts which 64 points share a wavefront, so the same entropy comes out
+    # of differently rounded sums — equal to ~1e-13, the flags identical
+    assert np.array_equal(ent != 0.0, wm[1] != 0.0)
+    np.testing.assert_allclose(ent, wm[1], rtol=0, atol=1e-11)
 
 
 def test_device_sqrt_is_correctly_rounded(eng):

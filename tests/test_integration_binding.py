@@ -48,7 +48,8 @@ def test_binding_blocks_use_only_the_public_abi():
         l.split("//")[0] for l in b["process"].splitlines() if not l.lstrip().startswith("//"))))
     called.discard("me_ok")
     header = open(os.path.join(ROOT, "include", "mapeval_hip.h")).read()
-    assert {"me_create", "me_upload_cloud", "me_mme", "me_transform_cloud", "me_nn1", "me_nn_stats", "me_awd_scs"} <= called
+    # round 5: the initial-matrix path is ONE call (me_run_suite_from) + fetches of what it left on the device
+    assert {"me_create", "me_run_suite_from", "me_mme_fetch", "me_nn_fetch", "me_upload_cloud", "me_mme", "me_awd_scs"} <= called
     for f in called:
         assert re.search(r"\b%s\(" % f, header), f"{f} is not declared in include/mapeval_hip.h"
 

@@ -1,4 +1,4 @@
-"""The integer arithmetic of the matrix-pipe MME kernel (cloud_map_evaluation_amd/csrc/me_mme_fx.hpp) on the host: digit features
+"""The integer arithmetic of the matrix-pipe MME kernel (profiles/ab/me_mme_fx.hpp) on the host: digit features
 -> column sums (what v_mfma_i32_16x16x64_i8 accumulates) -> moments about the query, against exact __int128 arithmetic and the
 fp64 sums of the vector kernel.  The same header is compiled into the device code; no GPU needed here."""
 import os
