@@ -42,6 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VECTOR_PEAK_TFLOPS = 157.3 / 2.0  # fp64 vector FMA at half the guide's FP32 vector rate (157.3 TFLOP/s spec): 78.6
 # algorithmic (compulsory) bytes per unit of work
 BYTES_PER_NN_QUERY = 60.0   # 24 B query + 24 B reference point + 12 B result (M = N)
 BYTES_PER_MME_QUERY = 33.0  # 24 B point + 8 B entropy + 1 B valid
@@ -400,6 +401,7 @@ def main():
             ms, cnt = eng.timer(name)
             if cnt:
                 fam[name] = (ms, cnt)
+        mme_pairs = eng.timer("mme_pairs")[1]
         nn_fallback = eng.timer("nn_fallback_queries")[1]
         nn_total = eng.timer("nn_queries")[1]
         eng.timers_enable(False)
@@ -444,6 +446,18 @@ def main():
                                              "frac": BYTES_PER_NN_QUERY * (n_e + n_g) * shard / fam["nn_grid"][1] / (fam["nn_grid"][0] / fam["nn_grid"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "traffic": (json.load(open(tpath)).get("nn_grid") if (os.path.exists(tpath) and traffic is not None) else None)}
                                             if "nn_grid" in fam else None),
+                                # The roofline that BINDS the dominant kernel: k_mme3 is bound by fp64 vector issue, not
+                                # by HBM.  Useful work = accepted (query, neighbour) pairs x 9 fp64 lane-instructions (3 v_add_f64 + 6
+                                # v_fma_f64: sum u, sum u u^T) = 15 flop per pair; peak = the fp64 vector rate, half of the guide's FP32
+                                # vector figure (157.3 TFLOP/s / 2 = 78.6: 16 lanes x 2 flop per SIMD and clock, 1024 SIMDs, 2.4 GHz).
+                                # The rest of the launch is the SIMT cost of 64 queries sharing one candidate stream: every accepted
+                                # trip is executed by the whole wavefront (lane efficiency), plus the FP32 pre-test of every candidate.
+                                "valu": ({"kernel": "mme", "accepted_pairs_per_step": int(mme_pairs), "flop_per_pair": 15,
+                                          "achieved": 15.0 * mme_pairs / (fam["mme"][0] * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": 15.0 * mme_pairs / (fam["mme"][0] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                          "pairs_per_query": mme_pairs / max(1.0, (n_e + (n_g if evaluate_gt_mme else 0)) * shard),
+                                          "ps_per_pair": fam["mme"][0] * 1e-3 / max(1, mme_pairs) * 1e12}
+                                         if ("mme" in fam and mme_pairs) else None),
                                 "nn_fallback_fraction": (nn_fallback / nn_total) if nn_total else None,
                                 "queries_per_s": {"nn": (n_e + n_g) * shard / ((fam.get("nn1", (0, 0))[0] + fam.get("nn_far", (0, 0))[0] + fam.get("nn_grid", (0, 0))[0] + fam.get("nn_grid2", (0, 0))[0]) * 1e-3)
                                                   if ("nn1" in fam or "nn_grid" in fam) else None,
@@ -490,6 +504,15 @@ def main():
             line["cpu_baseline"]["reference_run"] = cpu_baseline_reference(args, P, evaluate_gt_mme)
         except Exception as e:  # (a checker, never the product: its absence or failure does not fail the bench)
             line["cpu_baseline"]["reference_run"] = {"error": str(e)[:200]}
+        if args.cpu_baseline == "full":
+            try:  # ... and on a 5 M + 5 M pair WITHOUT the GT-MME (its serial loop, map_eval.cpp:1451, is what makes 50 M impractical): the
+                #     reference's scaling with tree depth
+                r5 = cpu_baseline_reference(args, P, False, n=5_000_000)
+                if r5 is not None:
+                    r5["note"] = "evaluate_gt_mme: false (the serial GT-MME loop left out); same code, 5x the points of reference_run"
+                line["cpu_baseline"]["reference_run_5m"] = r5
+            except Exception as e:
+                line["cpu_baseline"]["reference_run_5m"] = {"error": str(e)[:200]}
 
     eng.close()
     if world > 1:

@@ -18,6 +18,7 @@ ME_FLAG_BORROW_DEVICE_INPUT = 1
 ME_FLAG_MORTON_ORDER = 2
 ME_SUITE_OVERLAP = 1
 ME_SUITE_DEVICE_INPUT = 2
+ME_SUITE_PIN_HOST_INPUT = 4
 
 # every symbol include/mapeval_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [

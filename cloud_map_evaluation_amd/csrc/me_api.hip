@@ -59,6 +59,21 @@ __global__ void __launch_bounds__(64) k_mail(const unsigned char *__restrict__ s
     }
 }
 
+// Copies between caller (host) memory and the device, in one place.  copy_h2d is asynchronous on the context's stream for pinned
+// sources and returns when a pageable source may be reused (the runtime stages it); copy_d2h returns when dst holds the data.
+int copy_h2d(me_ctx *ctx, void *dst_device, const void *src_host, size_t bytes) {
+    if (bytes == 0) return ME_OK;
+    ME_CHECK(ctx, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ME_OK;
+}
+
+int copy_d2h(me_ctx *ctx, void *dst_host, const void *src_device, size_t bytes) {
+    if (bytes == 0) return ME_OK;
+    ME_CHECK(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
 int mail_post(me_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
     if (bytes == 0) return ME_OK;
     if (!ctx->mail_h) {
@@ -69,10 +84,7 @@ int mail_post(me_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
         ctx->mail_d = static_cast<unsigned char *>(d);
     }
     const size_t off = (ctx->mail_used + 15) & ~(size_t) 15;
-    if (off + bytes > kMailBytes) {  // (too big for the mailbox: the ordinary copy)
-        ME_CHECK(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        return ME_OK;
-    }
+    if (off + bytes > kMailBytes) return copy_d2h(ctx, host_dst, dev_src, bytes);  // (too big for the mailbox: the staged copy, at once)
     hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, static_cast<const unsigned char *>(dev_src), ctx->mail_d + off,
                        (unsigned int) bytes);
     ctx->mail_pending.push_back({host_dst, off, bytes});
@@ -229,7 +241,7 @@ int me_download_cloud(me_ctx *ctx, int slot, double *xyz_host) {
     me::Cloud &c = ctx->cloud[slot];
     if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "cloud not uploaded");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
-    ME_CHECK(ctx, hipMemcpyAsync(xyz_host, c.xyz.p, (size_t) c.n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(me::copy_d2h(ctx, xyz_host, c.xyz.p, (size_t) c.n * 24));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ME_OK;
 }
@@ -524,6 +536,7 @@ int me_timers_reset(me_ctx *ctx) {
     ctx->timers_collect();
     ctx->timers.clear();
     ctx->nn_fallback = ctx->nn_queries = 0;
+    ctx->mme_pairs = 0;
     if (ctx->nn1_dbg_buf.p) (void) hipMemsetAsync(ctx->nn1_dbg_buf.p, 0, 128, ctx->stream);
     return ME_OK;
 }
@@ -538,6 +551,11 @@ int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launc
         if (launches) *launches = v;
         return ME_OK;
     }
+    if (std::strcmp(name, "mme_pairs") == 0) {  // accepted (query, neighbour) pairs of the MME launches since the last reset
+        if (total_ms) *total_ms = 0.0;
+        if (launches) *launches = ctx->mme_pairs;
+        return ME_OK;
+    }
     if (std::strncmp(name, "nn1_", 4) == 0 && std::strlen(name) > 4) {
         // counters of the octree walk since the last reset (collected while timers are on): nodes opened, leaf cells scanned,
         // points scanned, the longest chain (opened + scanned) of one query
@@ -549,7 +567,7 @@ int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launc
                 unsigned long long v = 0;
                 if (ctx->nn1_dbg_buf.p) {
                     (void) hipDeviceSynchronize();
-                    (void) hipMemcpy(&v, ctx->nn1_dbg_buf.as<unsigned long long>() + k, 8, hipMemcpyDeviceToHost);
+                    (void) me::copy_d2h(ctx, &v, ctx->nn1_dbg_buf.as<unsigned long long>() + k, 8);
                 }
                 if (total_ms) *total_ms = 0.0;
                 if (launches) *launches = (int64_t) v;

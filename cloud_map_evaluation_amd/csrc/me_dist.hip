@@ -115,7 +115,7 @@ int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, cons
     hipLaunchKernelGGL(k_split_totals, dim3((unsigned int) world), dim3(256), 0, ctx->stream, cnt.as<unsigned int>(), n_units,
                        ctx->tmp[2].as<unsigned long long>());
     std::vector<unsigned long long> tot64((size_t) world);
-    ME_CHECK(ctx, hipMemcpyAsync(tot64.data(), ctx->tmp[2].p, (size_t) world * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, tot64.data(), ctx->tmp[2].p, (size_t) world * 8));
     ME_TRY(exclusive_scan_u32(ctx, cnt.as<unsigned int>(), off.as<unsigned int>(), n_cnt));
     // destination k's segment starts at off[k * n_units]; the total is off[last] + cnt[last]: one small kernel collects the
     // world + 1 numbers, ONE copy brings them to the host (world separate 4-byte copies cost ~10 us each)
@@ -123,7 +123,7 @@ int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, cons
     hipLaunchKernelGGL(k_split_segments, dim3(1), dim3(kMaxWorld + 1), 0, ctx->stream, off.as<unsigned int>(), cnt.as<unsigned int>(),
                        n_units, world, ctx->red.as<unsigned int>());
     std::vector<unsigned int> seg((size_t) world + 1);
-    ME_CHECK(ctx, hipMemcpyAsync(seg.data(), ctx->red.p, (size_t) (world + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, seg.data(), ctx->red.p, (size_t) (world + 1) * 4));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     long long total = 0;
     for (int k = 0; k < world; ++k) {
@@ -296,9 +296,9 @@ int voxel_merge(me_ctx *ctx, int slot, double voxel_size, const double *rows_dev
         ME_TRY(exclusive_scan_u32(ctx, flags, pos, m));
         unsigned int last_pos = 0, last_flag = 0;
         unsigned long long last_key = 0;
-        ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos + (m - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-        ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags + (m - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-        ME_CHECK(ctx, hipMemcpyAsync(&last_key, kout.as<unsigned long long>() + (m - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+        ME_TRY(copy_d2h(ctx, &last_pos, pos + (m - 1), 4));
+        ME_TRY(copy_d2h(ctx, &last_flag, flags + (m - 1), 4));
+        ME_TRY(copy_d2h(ctx, &last_key, kout.as<unsigned long long>() + (m - 1), 8));
         ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const long long segs = (long long) last_pos + last_flag;
         const bool pad = last_key == kRowSentinel;
@@ -317,7 +317,7 @@ int voxel_merge(me_ctx *ctx, int slot, double voxel_size, const double *rows_dev
             long long m_end = m;
             if (pad) {
                 unsigned int s = 0;
-                ME_CHECK(ctx, hipMemcpyAsync(&s, seg_start + V, 4, hipMemcpyDeviceToHost, ctx->stream));
+                ME_TRY(copy_d2h(ctx, &s, seg_start + V, 4));
                 ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
                 m_end = s;
             }

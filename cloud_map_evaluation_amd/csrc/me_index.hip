@@ -535,7 +535,6 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
     c.have_normals = c.have_cov = false;
     c.slab = ctx->slab;
     c.n_unres = 0;
-    c.sort_pairs_hint = false;  // (a new cloud: the dense-cloud fallback of the packed sort is decided again, cloud_build_index)
     c.slab_identity = true;  // (the filtered slab upload below clears it; a stale `false` would make me_slab_points read an old slab_orig)
     bool bbox_ready = false;
     // prefiltered: slab mode, but the caller guarantees that every point lies inside [reg_lo, reg_hi) (the halo exchange
@@ -561,7 +560,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
         bbox_ready = true;
     } else if (ctx->slab.axis < 0) {
         ME_CHECK(ctx, c.xyz.ensure((size_t) n * 3 * sizeof(double)));
-        ME_CHECK(ctx, hipMemcpyAsync(c.xyz.p, src, (size_t) n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        ME_TRY(copy_h2d(ctx, c.xyz.p, src, (size_t) n * 3 * sizeof(double)));
         if (T) {
             Mat4 m;
             std::memcpy(m.m, T, sizeof(m.m));
@@ -576,7 +575,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
         const double *in = src;
         if (!src_on_device) {
             ME_CHECK(ctx, stage.ensure((size_t) n * 3 * sizeof(double)));
-            ME_CHECK(ctx, hipMemcpyAsync(stage.p, src, (size_t) n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            ME_TRY(copy_h2d(ctx, stage.p, src, (size_t) n * 3 * sizeof(double)));
             in = stage.as<double>();
         }
         Mat4 m{};
@@ -586,8 +585,8 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
                            flags.as<unsigned int>());
         ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), n));
         unsigned int last_pos = 0, last_flag = 0;
-        ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-        ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ME_TRY(copy_d2h(ctx, &last_pos, pos.as<unsigned int>() + (n - 1), 4));
+        ME_TRY(copy_d2h(ctx, &last_flag, flags.as<unsigned int>() + (n - 1), 4));
         ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         const long long kept = (long long) last_pos + last_flag;
         ME_CHECK(ctx, c.xyz.ensure((size_t) std::max<long long>(kept, 1) * 3 * sizeof(double)));
@@ -686,6 +685,7 @@ int transform_points_device(me_ctx *ctx, double *xyz_device, long long n, const 
 
 int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     Cloud &c = ctx->cloud[slot];
+    ME_TRACE_POINT(ctx, slot == 0 ? "cloud_build_index(est): enter" : "cloud_build_index(gt): enter");
     if (!c.uploaded) return ctx->fail(ME_ERR_STATE, "cloud not uploaded");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     c.cell_size_req = cell_size;
@@ -737,7 +737,11 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     constexpr int pack_allowed = ME_TUNE_SORT_PACK;
     int sort_min_level = std::max(0, c.shift - std::max(0, sort_depth));
     int pack_bits = 0;
-    if (pack_allowed && !c.sort_pairs_hint) {
+    // (the hint of an earlier build of this slot holds for the SAME cloud shape only — point count, cell size, lattice depth, e.g. the
+    // same cloud uploaded again — so that one dense cloud does not leave every later cloud of the slot on the slower pair sort)
+    const bool pairs_hinted = c.sort_pairs_hint && c.hint_n == n && c.hint_shift == c.shift && c.hint_cell_h == cell_h;
+    if (!pairs_hinted) c.sort_pairs_hint = false;
+    if (pack_allowed && !pairs_hinted) {
         // (the depth is cut to 1 at most: at depth 0 the finest sorted level is the search cell itself, which holds its 6 points
         // in any cloud worth indexing — the rebuild below would be certain)
         const int lvl_max = std::max(sort_min_level, c.shift - std::min(std::max(0, sort_depth), 1));
@@ -807,6 +811,9 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
             // the finest sorted level holds >= 6 points per cell: with the full depth a finer one might have been chosen.  Build
             // again with the pair sort (and start with it next time this slot is indexed).
             c.sort_pairs_hint = true;
+            c.hint_n = n;
+            c.hint_shift = c.shift;
+            c.hint_cell_h = cell_h;
             ts.end();
             return cloud_build_index(ctx, slot, c.cell_size_req);
         }
@@ -876,7 +883,15 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
         }
     }
     ME_CHECK(ctx, hipGetLastError());
+    // The index is COMPLETE on the device when this returns ("every call is synchronous on return", mapeval_hip.h).  Through round 4
+    // the cell tables and the octree — everything queued after the level histogram's host read — were still in flight here: harmless
+    // on one stream, a data race for two lanes (me_twin): the other lane's k_mme3 / k_nn_grid started on ITS stream while this one's
+    // k_hash_insert was still filling the table they probe.  Python's hand-over latency hid it; the C++ lanes of me_run_suite_from
+    // (microseconds) did not: the second evaluation of a process (fresh buffers holding stale bytes instead of the previous,
+    // identical table) spun in hash_lookup for minutes at 50 M points (profiles/EXPERIMENTS.md "Round 5").
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     c.index_valid = true;
+    ME_TRACE_POINT(ctx, "cloud_build_index: done (host side)");
     return ME_OK;
 }
 
@@ -903,8 +918,8 @@ int slab_points(me_ctx *ctx, int slot, int64_t *orig_index, uint8_t *owned, long
     hipLaunchKernelGGL(k_slab_points, dim3(grid_for(c.n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), c.n, c.slab,
                        c.slab_identity ? (const int *) nullptr : c.slab_orig.as<int>(), orig_index ? oi.as<long long>() : nullptr,
                        owned ? ow.as<unsigned char>() : nullptr);
-    if (orig_index) ME_CHECK(ctx, hipMemcpyAsync(orig_index, oi.p, (size_t) c.n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (owned) ME_CHECK(ctx, hipMemcpyAsync(owned, ow.p, (size_t) c.n, hipMemcpyDeviceToHost, ctx->stream));
+    if (orig_index) ME_TRY(copy_d2h(ctx, orig_index, oi.p, (size_t) c.n * 8));
+    if (owned) ME_TRY(copy_d2h(ctx, owned, ow.p, (size_t) c.n));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ME_OK;
 }

@@ -33,6 +33,11 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, b);
         if (e == hipSuccess) bytes = b;
         else p = nullptr;
+#ifdef ME_POISON_ALLOC  // debug builds (make EXTRA=-DME_POISON_ALLOC): fresh device memory is filled with a pattern, so that a kernel
+        // which reads a buffer before anything wrote it shows at once (hipMalloc hands out zeroed pages in a fresh process and
+        // recycled, dirty ones after a hipFree: such a bug appears only when a second context is created in a long-lived process)
+        if (e == hipSuccess) (void) hipMemset(p, 0xCD, b);
+#endif
         return e;
     }
     void release() {
@@ -130,6 +135,9 @@ struct FrameView {
 
 struct Cloud {
     bool sort_pairs_hint = false;  // the keys-only sort had to cut the sort depth and the cloud was dense: use the pair sort (me_index.hip)
+    long long hint_n = 0;          // ... for a cloud of this shape only (same count, lattice depth and cell edge)
+    int hint_shift = 0;
+    double hint_cell_h = 0;
     long long n = 0;        // points held (slab mode: owned + halo)
     long long n_total = 0;  // points the caller passed to the upload
     SlabView slab{-1, 0, 0, 0, 0};
@@ -247,6 +255,8 @@ struct me_ctx {
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
     long long nn_fallback = 0, nn_queries = 0;  // counted only while timers are on
+    long long mme_pairs = 0;                     // accepted (query, neighbour) pairs of the MME launches since the last reset (timers on)
+    me::DevBuf mme_pairs_buf;
     me::DevBuf nn_far;                           // queries whose octree walk k_nn1 handed over to k_nn_far
     me::DevBuf nn_flags, nn_list_a, nn_list_b;   // 1-NN cascade: unresolved flags of the fine-grid pass, their ordered list, ping-pong
     me::DevBuf mme_keep_e, mme_keep_v;           // me_run_suite_from: the map's per-point MME result across its transform (mme_carry_*)
@@ -281,6 +291,19 @@ struct me_ctx {
             return (ctx)->fail(ME_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__) + " at " + \
                                                __FILE__ + ":" + std::to_string(__LINE__));              \
     } while (0)
+
+#ifdef ME_TRACE  // debug builds: wall-clock marks on stderr (which lane, where) — to locate a stall from outside
+#include <chrono>
+#define ME_TRACE_POINT(ctx, what)                                                                                              \
+    do {                                                                                                                       \
+        std::fprintf(stderr, "[me %.3f %s] %s\n",                                                                              \
+                     std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(),                \
+                     (ctx)->is_twin ? "twin" : "main", what);                                                                   \
+        std::fflush(stderr);                                                                                                   \
+    } while (0)
+#else
+#define ME_TRACE_POINT(ctx, what) do { } while (0)
+#endif
 
 #define ME_TRY(expr)              \
     do {                          \
@@ -320,6 +343,9 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
 #ifndef ME_TUNE_MME_LEADER_ORIGIN
 #define ME_TUNE_MME_LEADER_ORIGIN 1  // k_mme3: moments accumulated about the round leader's point (staged once per candidate) instead of each lane's own query
 #endif
+#ifndef ME_TUNE_NN_SGPR_MASKS
+#define ME_TUNE_NN_SGPR_MASKS 1   // k_nn_grid: compare masks in scalar register pairs (written-out VOP3 encodings) instead of vcc
+#endif
 #ifndef ME_TUNE_NN1_FAR_CAP
 #define ME_TUNE_NN1_FAR_CAP 64    // octree steps after which k_nn1 hands a walk over to k_nn_far (0 = never)
 #endif
@@ -328,6 +354,9 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
 #endif
 inline unsigned int xcd_chunk_setting() { return (unsigned int) ME_TUNE_XCD_CHUNK; }
 
+// ---- me_api.hip: copies between caller (host) memory and the device ----
+int copy_h2d(me_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);  // ordered on ctx->stream
+int copy_d2h(me_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);  // returns when dst holds the data
 // ---- me_api.hip: small results to the host without a blit kernel (see me_ctx::mail_h) ----
 constexpr size_t kMailBytes = 128 * 1024;
 int mail_post(me_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);  // asynchronous on ctx->stream

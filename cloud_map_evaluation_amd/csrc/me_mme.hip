@@ -48,6 +48,25 @@ __device__ __forceinline__ double half2_sum_d(double v) {
 __device__ unsigned long long g_mme_stat[8];
 #endif
 
+// one staged candidate of k_mme3's wave-private LDS tile (48 bytes: every member 16-byte aligned for ds_read_b128)
+struct alignas(16) MmeTileRec {
+    float4 f;    // (p'x, p'y, p'z, |p'|^2) in FP32, p' = p - o
+    double2 xy;  // u = p - o in fp64
+    double z;
+    double pad;
+};
+static_assert(sizeof(MmeTileRec) == 48, "tile record layout");
+// LDS load through a 32-bit LDS byte address held in a vector register
+template <class T>
+__device__ __forceinline__ T lds_load(unsigned int addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const __attribute__((address_space(3))) T *>((size_t) addr);
+#else
+    (void) addr;  // (host pass of the single-source compile: never called)
+    return T{};
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_mme3 — the wave-shared candidate streams of k_mme with (a) an FP32 pre-test, (b) the per-run adjacency cull and
 // (c) candidates delivered through a wave-private LDS tile instead of scalar fetches.
@@ -78,11 +97,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
 k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
        GridView g, FrameView fr, SlabView slab, double r2, int min_k, double *__restrict__ ent_s,
        unsigned char *__restrict__ valid_s, double *__restrict__ part_sum, long long *__restrict__ part_cnt,
-       unsigned int xcd_chunk, int dbg, double cell_h, float thr_lo, float thr_hi) {
+       unsigned int xcd_chunk, int dbg, double cell_h, float thr_lo, float thr_hi, unsigned long long *__restrict__ part_pairs) {
+    // part_pairs (instrumentation, NULL in product runs): per block, the accepted (query, neighbour) pairs — what bench.py's
+    // roofline.valu divides by the fp64 vector peak
     // cell_h = edge of a radius-grid cell; thr_lo / thr_hi = r^2 -+ E in FP32 (E = 2^-12 cell_h^2): kernel arguments, i.e.
     // scalar registers for the whole kernel (computed in the kernel they lived in VGPRs and were spilled around the loop).
     // dbg: profiling switches (profiles/README.md) — 1: no candidate streaming at all, 2: pre-test only, nothing accepted.
-    static_assert(TILE * 16 >= kGroupRows * 4, "the row masks of the cull alias the FP32 tile");
+    static_assert(TILE * 16 >= kGroupRows * 4, "the row masks of the cull alias the tile");
     const unsigned int vb = xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);
     const unsigned int loc = vb * blockDim.x + threadIdx.x;
     bool active = i_begin + (long long) loc < i_end;
@@ -107,16 +128,30 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
     bool done = !active;
 
     __shared__ int2 s_tab[4][kGroupTab + 1];
+#if ME_TUNE_MME_LEADER_ORIGIN
+    // One 48-byte record per staged candidate — the FP32 record, (ux, uy), uz — read back with a VECTOR-register address and
+    // immediate offsets (round 5): with three arrays indexed by the (scalar) loop counter the compiler rebuilt every LDS address
+    // with a v_mov from a scalar register, three vector instructions per accepted candidate that did no arithmetic.
+    __shared__ MmeTileRec s_rec[4][TILE];
+#else
     __shared__ float4 s_tf[4][TILE];     // FP32 records of the staged run (the cull's row masks while the table is built)
     __shared__ double2 s_txy[4][TILE];   // its fp64 coordinates: (x, y) as one 16-byte record, z apart — two LDS reads per
     __shared__ double s_tz[4][TILE];     // accepted candidate instead of three (a ds_read_b64 costs a SIMD 8.7 issue cycles)
+#endif
     const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));  // scalar: the wave's LDS bases stay out of VGPRs
     int2 *tab = s_tab[wv];
+#if ME_TUNE_MME_LEADER_ORIGIN
+    MmeTileRec *trec = s_rec[wv];
+    float4 *tf = reinterpret_cast<float4 *>(trec);  // (the cull's row masks alias the tile while the table is built)
+    const unsigned int trec_lds = (unsigned int) (size_t) trec;  // LDS byte address of the wave's tile (flat -> local: the low 32 bits)
+#else
     float4 *tf = s_tf[wv];
     double2 *txy = s_txy[wv];
     double *tdz = s_tz[wv];
+#endif
     const int lane = threadIdx.x & 63;
 
+    unsigned int wave_pairs = 0;  // (scalar: instrumentation only)
     double det_keep = 0.0;  // determinant of the neighbourhood covariance (valid when have_det)
     bool have_det = false;  // the query has at least min_k neighbours
     // A lane accumulates in exactly ONE round (the one whose group it belongs to), so the moments live inside the round:
@@ -162,6 +197,38 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
 #ifdef ME_MME_STATS
         int st_cand = 0;
 #endif
+#if ME_TUNE_MME_LEADER_ORIGIN
+        auto test = [&](const float4 &c, unsigned int ra, int gj) {  // ra: LDS address of the tile record, gj: the candidate's position in `sp`
+            const float u = fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
+            const bool hi = u < t_hi;
+            const unsigned long long mh = __ballot(hi);
+            if (mh) {  // some lane may hold this candidate inside its radius
+                bool acc = u < t_lo;
+                // (both compares land in scalar register pairs: the band test is scalar work, no VALU instruction)
+                if (__builtin_expect(mh != __ballot(acc), 0)) {  // a lane in the band: its exact test decides
+                    asm volatile("; band: exact test" ::: "memory");     // (keeps the compiler from evaluating it always)
+                    const SPoint pe = sp[gj];  // (the tile holds u = p - o: the exact test needs p itself; a few candidates in a thousand)
+                    const double ex = pe.x - qx, ey = pe.y - qy, ez = pe.z - qz;
+                    const double d2 = (ex * ex + ey * ey) + ez * ez;
+                    acc = acc || (hi && d2 < r2);                        // strict, nanoflann RadiusResultSet [upstream]
+                }
+                if (acc) {
+                    const double2 pxy = lds_load<double2>(ra + 16);
+                    const double dx = pxy.x, dy = pxy.y, dz = lds_load<double>(ra + 32);  // u = p - o, staged
+                    ++k;
+                    s1x += dx;
+                    s1y += dy;
+                    s1z += dz;
+                    sxx = fma(dx, dx, sxx);
+                    sxy = fma(dx, dy, sxy);
+                    sxz = fma(dx, dz, sxz);
+                    syy = fma(dy, dy, syy);
+                    syz = fma(dy, dz, syz);
+                    szz = fma(dz, dz, szz);
+                }
+            }
+        };
+#else
         auto test = [&](const float4 &c, int j, int gj) {  // j: slot in the tile, gj: the candidate's position in `sp`
             const float u = fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
             const bool hi = u < t_hi;
@@ -201,6 +268,7 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 }
             }
         };
+#endif
         if (dbg != 1) wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) {
             for (int base = cs; base < ce; base += TILE) {
                 const int n = min(TILE, ce - base);
@@ -213,11 +281,12 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                     const float fx = (float) px, fy = (float) py, fz = (float) pz;
                     // |p'|^2 of the ROUNDED coordinates (the error bound is stated for them), rounded once
                     const double w = ((double) fx * (double) fx + (double) fy * (double) fy) + (double) fz * (double) fz;
-                    tf[lane] = make_float4(fx, fy, fz, (float) w);
 #if ME_TUNE_MME_LEADER_ORIGIN
-                    txy[lane] = make_double2(px, py);
-                    tdz[lane] = pz;
+                    trec[lane].f = make_float4(fx, fy, fz, (float) w);
+                    trec[lane].xy = make_double2(px, py);
+                    trec[lane].z = pz;
 #else
+                    tf[lane] = make_float4(fx, fy, fz, (float) w);
                     txy[lane] = make_double2(p.x, p.y);
                     tdz[lane] = p.z;
 #endif
@@ -227,6 +296,23 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 int j = 0;
                 // (two records in flight, not four: eight registers fewer is what keeps this kernel at 64 VGPRs without
                 // spilling inside the run loop — the spills of the four-deep version were 3.2x the kernel's useful HBM traffic)
+#if ME_TUNE_MME_LEADER_ORIGIN
+                unsigned int ra = trec_lds;
+                asm volatile("" : "+v"(ra));  // the record address lives in a VECTOR register: reads below use it + an immediate
+                for (; j + 2 <= n; j += 2) {
+                    const float4 c0 = lds_load<float4>(ra), c1 = lds_load<float4>(ra + (unsigned int) sizeof(MmeTileRec));
+                    test(c0, ra, base + j);
+                    test(c1, ra + (unsigned int) sizeof(MmeTileRec), base + j + 1);
+                    ra += 2u * (unsigned int) sizeof(MmeTileRec);
+                    asm volatile("" : "+v"(ra));
+                }
+                for (; j < n; ++j) {
+                    const float4 c0 = lds_load<float4>(ra);
+                    test(c0, ra, base + j);
+                    ra += (unsigned int) sizeof(MmeTileRec);
+                    asm volatile("" : "+v"(ra));
+                }
+#else
 #if ME_MME_DEPTH == 2
                 for (; j + 2 <= n; j += 2) {
                     const float4 c0 = tf[j], c1 = tf[j + 1];
@@ -238,6 +324,7 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                     const float4 c0 = tf[j];
                     test(c0, j, base + j);
                 }
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
             }
@@ -261,6 +348,11 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
             ++st_round;
         }
 #endif
+        if (part_pairs) {  // (wave-uniform branch)
+            int ka = in ? k - 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) ka += __shfl_xor(ka, o, 64);
+            wave_pairs += (unsigned int) __builtin_amdgcn_readfirstlane(ka);
+        }
         if (in) {
             done = true;
             const int kk = k - 1;  // drop the query itself (map_eval.cpp:1672-1673)
@@ -319,6 +411,20 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
         part_sum[blockIdx.x] = bs;
         part_cnt[blockIdx.x] = bc;
     }
+    if (part_pairs) {
+        __shared__ unsigned int smp[4];
+        if (lane == 0) smp[wv] = wave_pairs;
+        __syncthreads();
+        if (threadIdx.x == 0) part_pairs[blockIdx.x] = (unsigned long long) smp[0] + smp[1] + smp[2] + smp[3];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sum_u64(const unsigned long long *__restrict__ v, long long n, unsigned long long *__restrict__ out) {
+    long long s = 0;
+    for (long long i = threadIdx.x; i < n; i += 256) s += (long long) v[i];
+    __shared__ long long sm[4];
+    const long long r = block_sum_256_ll(s, sm);
+    if (threadIdx.x == 0) *out += (unsigned long long) r;
 }
 
 #ifdef ME_AB  // measurement build only (make -C profiles/ab): the variants that were measured and not adopted live in profiles/ab/
@@ -371,8 +477,8 @@ static int mme_unpermute_to_host(me_ctx *ctx, Cloud &c, long long b, long long e
         hipLaunchKernelGGL(k_mme_unpermute, dim3((unsigned int) ((e - b + 255) / 256)), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), b, e,
                            c.mme_ent.as<double>(), c.mme_val.as<unsigned char>(), entropies ? eo.as<double>() : nullptr,
                            valid ? vo.as<unsigned char>() : nullptr);
-    if (entropies) ME_CHECK(ctx, hipMemcpyAsync(entropies, eo.p, (size_t) n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (valid) ME_CHECK(ctx, hipMemcpyAsync(valid, vo.p, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+    if (entropies) ME_TRY(copy_d2h(ctx, entropies, eo.p, (size_t) n * 8));
+    if (valid) ME_TRY(copy_d2h(ctx, valid, vo.p, (size_t) n));
     return ME_OK;
 }
 
@@ -441,6 +547,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
         if (n_valid) *n_valid = 0;
         return ME_OK;
     }
+    ME_TRACE_POINT(ctx, "mme_run: enter");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     // the 27-cell stencil is exact only when cell edge >= radius; rebuild when it is not, or when the cells are
     // needlessly coarse (more candidates per query than necessary)
@@ -458,6 +565,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     ME_CHECK(ctx, val_s.ensure((size_t) n));
     const unsigned int nb = (unsigned int) std::max<long long>(8, ((e - b + 255) / 256 + 7) / 8 * 8);
     constexpr int kStage = 256;
+    ME_TRACE_POINT(ctx, "mme_run: buffers ensured");
     ME_CHECK(ctx, ctx->red.ensure((size_t) (nb + kStage + 1) * 16 + 64));
     double *ps = ctx->red.as<double>();
     long long *pc = reinterpret_cast<long long *>(ps + nb);
@@ -470,18 +578,41 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
         const FrameView fr{c.origin[0], c.origin[1], c.origin[2], c.fine_h};
         const float band = (float) (0x1p-12 * c.cell_h * c.cell_h);  // E, see k_mme3
         const float thr_lo = (float) r2 - band, thr_hi = (float) r2 + band;
+        // instrumentation (timers on): accepted pairs per block -> ctx->mme_pairs (me_timer_get "mme_pairs")
+        unsigned long long *d_pairs = nullptr;
+#ifndef ME_NO_PAIR_COUNT
+        if (ctx->timers_on) {
+            ME_CHECK(ctx, ctx->mme_pairs_buf.ensure((size_t) (nb + 2) * 8));
+            d_pairs = ctx->mme_pairs_buf.as<unsigned long long>() + 2;
+        }
+#endif
         TimerScope ts(ctx, "mme");
 #define ME_LAUNCH_MME3(T, W, DBG)                                                                                             \
     hipLaunchKernelGGL((k_mme3<T, W>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),                                \
                        c.codes.as<unsigned long long>(), b, e, c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(),             \
-                       val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), DBG, c.cell_h, thr_lo, thr_hi)
+                       val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), DBG, c.cell_h, thr_lo, thr_hi, d_pairs)
 #ifdef ME_AB
 #include "me_mme_dispatch_ab.inc"
 #else
         ME_LAUNCH_MME3(32, 8, 0);
 #endif
 #undef ME_LAUNCH_MME3
+        ts.end();
+        ME_TRACE_POINT(ctx, "mme_run: k_mme3 queued");
+        if (d_pairs) {
+            unsigned long long *tot = ctx->mme_pairs_buf.as<unsigned long long>();
+            ME_CHECK(ctx, hipMemsetAsync(tot, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(k_sum_u64, dim3(1), dim3(256), 0, ctx->stream, d_pairs, (long long) nb, tot);
+            unsigned long long h = 0;
+            {
+                MailGuard mg(ctx);
+                ME_TRY(mail_post(ctx, &h, tot, 8));
+                ME_TRY(mg.sync());
+            }
+            ctx->mme_pairs += (long long) h;
+        }
     }
+    ME_TRACE_POINT(ctx, "mme_run: kernel launched");
     const long long chunk = ((long long) nb + kStage - 1) / kStage;
     hipLaunchKernelGGL(k_mme_final, dim3(kStage), dim3(256), 0, ctx->stream, ps, pc, (long long) nb, chunk, ps2, pc2);
     hipLaunchKernelGGL(k_mme_final, dim3(1), dim3(256), 0, ctx->stream, ps2, pc2, (long long) kStage, (long long) kStage, outs, outc);
@@ -495,6 +626,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
         ME_TRY(mail_post(ctx, &hc, outc, 8));
         ME_TRY(mg.sync());
     }
+    ME_TRACE_POINT(ctx, "mme_run: synced");
     ME_CHECK(ctx, hipGetLastError());
 #ifdef ME_MME_STATS
     {

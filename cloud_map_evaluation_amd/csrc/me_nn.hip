@@ -171,6 +171,25 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     // (b1 <= b2 <= b3 are the three smallest ranks seen: the new second is the median of {b1, b2, m}, the new third the
     // median of {b2, b3, m} — one v_med3_f32 each; fminf/fmaxf chains cost three times as many instructions, most of them
     // NaN canonicalisations of values that are never NaN)
+#if ME_TUNE_NN_SGPR_MASKS
+    // The two compare masks go to SCALAR register pairs and the selects read them from there (VOP3 encodings, written out: the
+    // compiler puts both masks through vcc).  A v_cndmask_b32 that takes its mask from vcc right after the v_cmp that wrote it
+    // costs ~11 issue cycles on gfx950, 4.2 with the mask in an SGPR pair (profiles/r04_issue_rates.txt) — four of them per
+    // group of four candidates; b1 needs no select at all (ranks are never NaN: a plain minimum).
+    auto note = [&](float m, int j) {
+        m += bias;
+        unsigned long long lt1, lt2;
+        asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(lt1) : "v"(m), "v"(b1));
+        asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(lt2) : "v"(m), "v"(b2));
+        b3 = __builtin_amdgcn_fmed3f(b2, b3, m);
+        b2 = __builtin_amdgcn_fmed3f(b1, b2, m);
+        int jn;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(jn) : "v"(j2), "v"(j), "s"(lt2));   // lt2 ? j : j2
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(j2) : "v"(jn), "v"(j1), "s"(lt1));  // lt1 ? j1 : jn
+        asm("v_min_f32_e32 %0, %1, %2" : "=v"(b1) : "v"(b1), "v"(m));                     // lt1 ? m : b1
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(j1) : "v"(j1), "v"(j), "s"(lt1));   // lt1 ? j : j1
+    };
+#else
     auto note = [&](float m, int j) {
         m += bias;
         const bool lt1 = m < b1, lt2 = m < b2;
@@ -181,6 +200,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         b1 = lt1 ? m : b1;
         j1 = lt1 ? j : j1;
     };
+#endif
     // Candidate delivery.  A run (the points of one cell) is copied into a wave-private LDS tile with ONE coalesced vector
     // load per 64 points and read back with wave-uniform (broadcast) ds_reads, four candidates per group.  The first
     // version fetched the candidates with scalar loads (s_load, candidate in SGPRs): the scalar cache misses on this
@@ -975,6 +995,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         return ctx->fail(ME_ERR_STATE, "me_nn1: upload both clouds first");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     q.nn_ref_slot = rslot;
+    ME_TRACE_POINT(ctx, "nn_search: enter");
     q.n_unres = 0;
     if (q.n == 0) return ME_OK;  // empty slab: nothing to query
     ME_CHECK(ctx, q.nn_d2.ensure((size_t) q.n * 8));
@@ -1061,7 +1082,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         }
         if (ctx->timers_on) {  // fallback share, for the bench report
             unsigned int h = 0;
-            ME_CHECK(ctx, hipMemcpyAsync(&h, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+            ME_TRY(copy_d2h(ctx, &h, d_cnt, 4));
             ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             ctx->nn_fallback += h;
             ctx->nn_queries += e - b;
@@ -1073,7 +1094,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
         hipLaunchKernelGGL(k_nn_collect_unresolved, dim3((unsigned int) ((q.n + 255) / 256)), dim3(256), 0, ctx->stream,
                            q.sp.as<SPoint>(), q.n, q.slab, q.nn_d2.as<double>(), q.nn_unres.as<unsigned int>(), d_cnt);
         unsigned int h = 0;
-        ME_CHECK(ctx, hipMemcpyAsync(&h, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ME_TRY(copy_d2h(ctx, &h, d_cnt, 4));
         ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         q.n_unres = h;
     }
@@ -1157,13 +1178,14 @@ int nn_fetch(me_ctx *ctx, int qslot, int32_t *idx, double *d2) {
     if (e > b)
         hipLaunchKernelGGL(k_nn_unpermute, dim3((unsigned int) ((e - b + 255) / 256)), dim3(256), 0, ctx->stream,
                            q.sp.as<SPoint>(), b, e, q.nn_d2.as<double>(), q.nn_idx.as<int>(), od.as<double>(), oi.as<int>());
-    if (d2) ME_CHECK(ctx, hipMemcpyAsync(d2, od.p, (size_t) q.n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (idx) ME_CHECK(ctx, hipMemcpyAsync(idx, oi.p, (size_t) q.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (d2) ME_TRY(copy_d2h(ctx, d2, od.p, (size_t) q.n * 8));
+    if (idx) ME_TRY(copy_d2h(ctx, idx, oi.p, (size_t) q.n * 4));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ME_OK;
 }
 
 int nn_partial(me_ctx *ctx, int qslot, double gate, int gate_mode, const double trunc[5], me_nn_partial *out) {
+    ME_TRACE_POINT(ctx, "nn_partial: enter");
     if (qslot < 0 || qslot > 1 || !out || !trunc) return ctx->fail(ME_ERR_ARG, "me_nn_partial_sums: bad argument");
     Cloud &q = ctx->cloud[qslot];
     if (q.nn_ref_slot < 0) return ctx->fail(ME_ERR_STATE, "no NN result for this slot (call me_nn1 first)");
@@ -1292,8 +1314,8 @@ int icp_p2p_sums(me_ctx *ctx, int qslot, double max_distance, me_icp_sums *out) 
     }
     double hd[kIcpD];
     long long hc = 0;
-    ME_CHECK(ctx, hipMemcpyAsync(hd, pd + (size_t) nb * kIcpD, sizeof(hd), hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&hc, pc + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, hd, pd + (size_t) nb * kIcpD, sizeof(hd)));
+    ME_TRY(copy_d2h(ctx, &hc, pc + nb, 8));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     out->n_corr = hc;
     out->n_source = q.n;  // (the whole source cloud, also under me_set_shard: fitness = all-reduced n_corr / n_source)

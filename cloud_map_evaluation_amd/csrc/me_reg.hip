@@ -500,7 +500,7 @@ int set_normals(me_ctx *ctx, int slot, const double *normals_host) {
     Cloud &c = ctx->cloud[slot];
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     ME_CHECK(ctx, c.normals.ensure((size_t) c.n * 24));
-    ME_CHECK(ctx, hipMemcpyAsync(c.normals.p, normals_host, (size_t) c.n * 24, hipMemcpyHostToDevice, ctx->stream));
+    ME_TRY(copy_h2d(ctx, c.normals.p, normals_host, (size_t) c.n * 24));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     c.have_normals = true;
     c.have_cov = false;
@@ -513,7 +513,7 @@ int get_normals(me_ctx *ctx, int slot, double *normals_host) {
     if (!c.have_normals) return ctx->fail(ME_ERR_STATE, "me_get_normals: the cloud has no normals");
     if (!normals_host) return ctx->fail(ME_ERR_ARG, "me_get_normals: normals is NULL");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
-    ME_CHECK(ctx, hipMemcpyAsync(normals_host, c.normals.p, (size_t) c.n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, normals_host, c.normals.p, (size_t) c.n * 24));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ME_OK;
 }
@@ -544,10 +544,10 @@ int estimate_normals(me_ctx *ctx, int slot, int knn, double *normals_host, int32
     }
     ME_CHECK(ctx, hipGetLastError());
     if (normals_host)
-        ME_CHECK(ctx, hipMemcpyAsync(normals_host, c.normals.p, (size_t) n * 24, hipMemcpyDeviceToHost, ctx->stream));
+        ME_TRY(copy_d2h(ctx, normals_host, c.normals.p, (size_t) n * 24));
     if (knn_idx_host) {
-        ME_CHECK(ctx, hipMemcpyAsync(knn_idx_host, d_idx, (size_t) n * knn * 4, hipMemcpyDeviceToHost, ctx->stream));
-        ME_CHECK(ctx, hipMemcpyAsync(knn_d2_host, d_d2, (size_t) n * knn * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ME_TRY(copy_d2h(ctx, knn_idx_host, d_idx, (size_t) n * knn * 4));
+        ME_TRY(copy_d2h(ctx, knn_d2_host, d_d2, (size_t) n * knn * 8));
     }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     c.have_normals = true;
@@ -569,7 +569,7 @@ int gicp_covariances(me_ctx *ctx, int slot, double epsilon, double *cov_host) {
         hipLaunchKernelGGL(k_gicp_cov, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.normals.as<double>(), n, epsilon,
                            c.cov.as<double>());
     }
-    if (cov_host) ME_CHECK(ctx, hipMemcpyAsync(cov_host, c.cov.p, (size_t) n * 72, hipMemcpyDeviceToHost, ctx->stream));
+    if (cov_host) ME_TRY(copy_d2h(ctx, cov_host, c.cov.p, (size_t) n * 72));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
     c.have_cov = true;
@@ -582,7 +582,7 @@ int get_covariances(me_ctx *ctx, int slot, double *cov_host) {
     if (!c.have_cov) return ctx->fail(ME_ERR_STATE, "me_get_covariances: the cloud has no covariances");
     if (!cov_host) return ctx->fail(ME_ERR_ARG, "me_get_covariances: cov is NULL");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
-    ME_CHECK(ctx, hipMemcpyAsync(cov_host, c.cov.p, (size_t) c.n * 72, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, cov_host, c.cov.p, (size_t) c.n * 72));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ME_OK;
 }
@@ -636,8 +636,8 @@ int icp_lsq_sums(me_ctx *ctx, int qslot, int mode, double max_distance, me_icp_l
     }
     double hd[kLsqD];
     long long hc = 0;
-    ME_CHECK(ctx, hipMemcpyAsync(hd, pd + (size_t) nb * kLsqD, sizeof(hd), hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&hc, pc + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, hd, pd + (size_t) nb * kLsqD, sizeof(hd)));
+    ME_TRY(copy_d2h(ctx, &hc, pc + nb, 8));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
     out->n_corr = hc;

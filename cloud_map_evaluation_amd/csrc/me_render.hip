@@ -118,8 +118,8 @@ int render_distance(me_ctx *ctx, int qslot, double dis, double gate, int gate_mo
     const double g = (gate < 0) ? -1.0 : (gate_mode == ME_GATE_LT_SQUARED ? gate * gate : gate);
     hipLaunchKernelGGL(k_render_distance, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), q.nn_d2.as<double>(), n,
                        dis, g, gate_mode == ME_GATE_LT_SQUARED ? 1 : 0, col.as<double>(), inlier ? inl.as<unsigned char>() : nullptr);
-    ME_CHECK(ctx, hipMemcpyAsync(rgb, col.p, (size_t) n * 24, hipMemcpyDeviceToHost, ctx->stream));
-    if (inlier) ME_CHECK(ctx, hipMemcpyAsync(inlier, inl.p, (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, rgb, col.p, (size_t) n * 24));
+    if (inlier) ME_TRY(copy_d2h(ctx, inlier, inl.p, (size_t) n));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
     return ME_OK;
@@ -141,7 +141,7 @@ int render_entropy(me_ctx *ctx, int slot, double *xyz_out, double *rgb_out, long
     ME_CHECK(ctx, ctx->red.ensure((size_t) nb * 16));
     hipLaunchKernelGGL(k_minmax_nonzero, dim3(nb), dim3(256), 0, ctx->stream, c.mme_ent.as<double>(), n, ctx->red.as<double>());
     std::vector<double> part((size_t) nb * 2);
-    ME_CHECK(ctx, hipMemcpyAsync(part.data(), ctx->red.p, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, part.data(), ctx->red.p, part.size() * 8));
     // --- cloud order + compaction offsets ---
     DevBuf &eo = ctx->tmp[0], &fl = ctx->tmp[1], &ps = ctx->tmp[2];
     ME_CHECK(ctx, eo.ensure((size_t) n * 8));
@@ -151,8 +151,8 @@ int render_entropy(me_ctx *ctx, int slot, double *xyz_out, double *rgb_out, long
                        c.mme_val.as<unsigned char>(), n, eo.as<double>(), fl.as<unsigned int>());
     ME_TRY(exclusive_scan_u32(ctx, fl.as<unsigned int>(), ps.as<unsigned int>(), n));
     unsigned int last_pos = 0, last_flag = 0;
-    ME_CHECK(ctx, hipMemcpyAsync(&last_pos, ps.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&last_flag, fl.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, &last_pos, ps.as<unsigned int>() + (n - 1), 4));
+    ME_TRY(copy_d2h(ctx, &last_flag, fl.as<unsigned int>() + (n - 1), 4));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     double mn = INFINITY, mx = -INFINITY;
     for (int b = 0; b < nb; ++b) {
@@ -173,8 +173,8 @@ int render_entropy(me_ctx *ctx, int slot, double *xyz_out, double *rgb_out, long
     ME_CHECK(ctx, co.ensure((size_t) m * 24));
     hipLaunchKernelGGL(k_render_entropy, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), eo.as<double>(),
                        fl.as<unsigned int>(), ps.as<unsigned int>(), n, min_abs, max_abs, xo.as<double>(), co.as<double>());
-    ME_CHECK(ctx, hipMemcpyAsync(xyz_out, xo.p, (size_t) m * 24, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(rgb_out, co.p, (size_t) m * 24, hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, xyz_out, xo.p, (size_t) m * 24));
+    ME_TRY(copy_d2h(ctx, rgb_out, co.p, (size_t) m * 24));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
     return ME_OK;
@@ -204,8 +204,8 @@ int set_mme_result(me_ctx *ctx, int slot, const double *entropies, const uint8_t
     ME_CHECK(ctx, vo.ensure((size_t) n));
     ME_CHECK(ctx, c.mme_ent.ensure((size_t) n * 8));
     ME_CHECK(ctx, c.mme_val.ensure((size_t) n));
-    ME_CHECK(ctx, hipMemcpyAsync(eo.p, entropies, (size_t) n * 8, hipMemcpyHostToDevice, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(vo.p, valid, (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    ME_TRY(copy_h2d(ctx, eo.p, entropies, (size_t) n * 8));
+    ME_TRY(copy_h2d(ctx, vo.p, valid, (size_t) n));
     hipLaunchKernelGGL(k_permute_in, dim3((unsigned int) ((n + 255) / 256)), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(), n,
                        eo.as<double>(), vo.as<unsigned char>(), c.mme_ent.as<double>(), c.mme_val.as<unsigned char>(), (int *) nullptr);
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -224,7 +224,7 @@ int set_nn_result(me_ctx *ctx, int qslot, int rslot, const double *d2) {
     ME_CHECK(ctx, eo.ensure((size_t) n * 8));
     ME_CHECK(ctx, q.nn_d2.ensure((size_t) n * 8));
     ME_CHECK(ctx, q.nn_idx.ensure((size_t) n * 4));
-    ME_CHECK(ctx, hipMemcpyAsync(eo.p, d2, (size_t) n * 8, hipMemcpyHostToDevice, ctx->stream));
+    ME_TRY(copy_h2d(ctx, eo.p, d2, (size_t) n * 8));
     hipLaunchKernelGGL(k_permute_in, dim3((unsigned int) ((n + 255) / 256)), dim3(256), 0, ctx->stream, q.sp.as<SPoint>(), n,
                        eo.as<double>(), (const unsigned char *) nullptr, q.nn_d2.as<double>(), (unsigned char *) nullptr, q.nn_idx.as<int>());
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));

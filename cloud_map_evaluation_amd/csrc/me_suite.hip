@@ -44,7 +44,8 @@ struct SuiteLane {
     const me_suite_params *p = nullptr;
     const double *gt = nullptr;
     long long n_gt = 0;
-    bool gt_on_device = false, upload_gt = false, wait_for_link = false;
+    bool gt_on_device = false, upload_gt = false, wait_for_link = false, pin_gt = false;
+    bool gt_pinned = false;  // this call page-locked the ground truth's buffer (released by the caller of run())
     std::mutex m;
     std::condition_variable cv;
     bool est_on_device = false;  // main -> lane: the map's H2D copy is over (the link is free)
@@ -77,6 +78,7 @@ struct SuiteLane {
         if (upload_gt) {
             // clouds that start in HOST memory share the PCIe link: one after the other, the ground truth crosses it under the
             // map's MME kernel.  Device-resident clouds: both lanes start at once.
+            if (pin_gt) gt_pinned = hipHostRegister(const_cast<double *>(gt), (size_t) n_gt * 24, hipHostRegisterDefault) == hipSuccess;
             if (wait_for_link && !wait(&SuiteLane::est_on_device)) return ME_OK;
             ME_TRY(me::cloud_upload(t, ME_SLOT_GT, gt, gt_on_device, n_gt, nullptr, p->nn_radius));
         }
@@ -179,6 +181,7 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
         return ctx->fail(ME_ERR_STATE, "me_run_suite_from: no clouds passed and none uploaded");
     const bool on_device = (flags & ME_SUITE_DEVICE_INPUT) != 0;
     const bool overlap = (flags & ME_SUITE_OVERLAP) != 0;
+    const bool pin = upload && !on_device && (flags & ME_SUITE_PIN_HOST_INPUT) != 0;
     const bool moved = !is_identity(T);  // the map is evaluated for MME as loaded and transformed afterwards (:56 then :1206)
     std::memset(out, 0, sizeof(*out));
     ME_CHECK(ctx, hipSetDevice(ctx->device));
@@ -194,12 +197,19 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
         lane.gt_on_device = on_device;
         lane.upload_gt = upload;
         lane.wait_for_link = upload && !on_device;
+        lane.pin_gt = pin;
         lane.th = std::thread([&lane] { lane.run(); });
     }
+    bool est_pinned = false, gt_pinned_here = false;
     // everything the main lane does; on failure the second lane is stopped and joined before returning
     auto main_lane = [&]() -> int {
         auto t0 = Clock::now();
         if (upload) {
+            // ME_SUITE_PIN_HOST_INPUT: page-lock the caller's buffers for the duration of the call (pageable memory crosses PCIe
+            // through the runtime's staging buffers at ~2/3 of the pinned rate); a buffer that is pinned already is left alone
+            if (pin) est_pinned = hipHostRegister(const_cast<double *>(est), (size_t) n_est * 24, hipHostRegisterDefault) == hipSuccess;
+            if (pin && !overlap) gt_pinned_here = hipHostRegister(const_cast<double *>(gt), (size_t) n_gt * 24, hipHostRegisterDefault) == hipSuccess;
+            (void) hipGetLastError();  // (a refused registration is not an error of the call)
             ME_TRY(me::cloud_upload(ctx, ME_SLOT_EST, est, on_device, n_est, nullptr, p->nn_radius));
             if (overlap) lane.set(&SuiteLane::est_on_device);
             if (!overlap) ME_TRY(me::cloud_upload(ctx, ME_SLOT_GT, gt, on_device, n_gt, nullptr, p->nn_radius));
@@ -271,6 +281,8 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
         if (lane.th.joinable()) lane.abort_and_join();
         if (rc != ME_OK && rc == lane.rc.load() && lane.t) ctx->err = lane.t->err;  // the second lane's failure: its message
     }
+    if (est_pinned) (void) hipHostUnregister(const_cast<double *>(est));
+    if (gt_pinned_here || lane.gt_pinned) (void) hipHostUnregister(const_cast<double *>(gt));
     out->stage_ms[7] = ms_since(t_all);
     return rc;
 }

@@ -622,13 +622,13 @@ int w2_batch(me_ctx *ctx, const double *mu1, const double *sigma1, const int32_t
                           (size_t) count * 72, (size_t) count * 4, (size_t) count * 8};
     const void *src[6] = {mu1, sigma1, n1, mu2, sigma2, n2};
     for (int k = 0; k < 7; ++k) ME_CHECK(ctx, b[k].ensure(sz[k]));
-    for (int k = 0; k < 6; ++k) ME_CHECK(ctx, hipMemcpyAsync(b[k].p, src[k], sz[k], hipMemcpyHostToDevice, ctx->stream));
+    for (int k = 0; k < 6; ++k) ME_TRY(copy_h2d(ctx, b[k].p, src[k], sz[k]));
     {
         TimerScope ts(ctx, "w2");
         hipLaunchKernelGGL(k_w2_batch, dim3(grid_for(count)), dim3(256), 0, ctx->stream, b[0].as<double>(), b[1].as<double>(),
                            b[2].as<int>(), b[3].as<double>(), b[4].as<double>(), b[5].as<int>(), count, b[6].as<double>());
     }
-    ME_CHECK(ctx, hipMemcpyAsync(w, b[6].p, sz[6], hipMemcpyDeviceToHost, ctx->stream));
+    ME_TRY(copy_d2h(ctx, w, b[6].p, sz[6]));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
     return ME_OK;
@@ -637,6 +637,7 @@ int w2_batch(me_ctx *ctx, const double *mu1, const double *sigma1, const int32_t
 int scs_table(me_ctx *ctx, const int32_t *keys, const double *w, long long n, int scs_radius, double *scs) {
     if (n < 0 || !scs || (n > 0 && (!keys || !w))) return ctx->fail(ME_ERR_ARG, "me_scs_table: bad argument");
     if (scs_radius < 1 || scs_radius > 10) return ctx->fail(ME_ERR_ARG, "scs_radius must be in [1, 10]");
+    ME_TRACE_POINT(ctx, "awd_scs: enter");
     if (n == 0) {
         *scs = std::nan("");
         return ME_OK;
@@ -651,16 +652,20 @@ int scs_table(me_ctx *ctx, const int32_t *keys, const double *w, long long n, in
     double *d_sum = reinterpret_cast<double *>(ctx->red.as<char>() + 64);
     long long *d_cnt = reinterpret_cast<long long *>(ctx->red.as<char>() + 128);
     ME_CHECK(ctx, hipMemsetAsync(d_err, 0, 4, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(k3.p, keys, (size_t) n * 12, hipMemcpyHostToDevice, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(ww.p, w, (size_t) n * 8, hipMemcpyHostToDevice, ctx->stream));
+    ME_TRY(copy_h2d(ctx, k3.p, keys, (size_t) n * 12));
+    ME_TRY(copy_h2d(ctx, ww.p, w, (size_t) n * 8));
     hipLaunchKernelGGL(k_pack_keys, dim3(grid_for(n)), dim3(256), 0, ctx->stream, k3.as<int>(), n, kk.as<unsigned long long>(), d_err);
     ME_TRY(scs_device(ctx, kk.as<unsigned long long>(), ww.as<double>(), n, scs_radius, d_sum, d_cnt));
     int h_err = 0;
     double h_s = 0;
     long long h_c = 0;
-    ME_CHECK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&h_s, d_sum, 8, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&h_c, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    {
+        MailGuard mg(ctx);  // (one synchronisation for the batch; destinations are locals of this frame)
+        ME_TRY(mail_post(ctx, &h_err, d_err, 4));
+        ME_TRY(mail_post(ctx, &h_s, d_sum, 8));
+        ME_TRY(mail_post(ctx, &h_c, d_cnt, 8));
+        ME_TRY(mg.sync());
+    }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (h_err) return ctx->fail(ME_ERR_ARG, "me_scs_table: voxel index out of range");
     *scs = h_s / (double) h_c;
@@ -685,6 +690,7 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
     }
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     if (!c.index_valid) ME_TRY(cloud_build_index(ctx, slot, c.cell_size_req));
+    ME_TRACE_POINT(ctx, "voxel_build: enter");
     const long long n = c.n;
     const long long nw = (n + 63) / 64;
     const SPoint *sp = c.sp.as<SPoint>();
@@ -701,12 +707,18 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
     }
     ME_TRY(exclusive_scan_u32(ctx, wave_runs, wave_off, nw));
     unsigned int last_off = 0, last_runs = 0;
+    ME_TRACE_POINT(ctx, "voxel_build: count_runs + scan queued");
     int h_err = 0;
-    ME_CHECK(ctx, hipMemcpyAsync(&last_off, wave_off + (nw - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&last_runs, wave_runs + (nw - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    {
+        MailGuard mg(ctx);  // (one synchronisation for the batch; destinations are locals of this frame)
+        ME_TRY(mail_post(ctx, &last_off, wave_off + (nw - 1), 4));
+        ME_TRY(mail_post(ctx, &last_runs, wave_runs + (nw - 1), 4));
+        ME_TRY(mail_post(ctx, &h_err, d_err, 4));
+        ME_TRY(mg.sync());
+    }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (h_err) return ctx->fail(ME_ERR_ARG, "voxel index out of range (|floor(p/voxel_size)| must be < 2^20)");
+    ME_TRACE_POINT(ctx, "voxel_build: run counts read");
     const long long R = (long long) last_off + last_runs;  // run records
     // --- pass 1: (key, n, sum p) per run ---
     DevBuf &kbuf = ctx->tmp[1], &sbuf = ctx->tmp[2], &ibuf = ctx->tmp[3], &mbuf = ctx->tmp[4];  // (tmp[5]: sort/scan scratch)
@@ -730,11 +742,16 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
     ME_TRY(exclusive_scan_u32(ctx, flags, pos, R));
     unsigned int last_pos = 0, last_flag = 0;
     unsigned long long last_key = 0;
-    ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos + (R - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags + (R - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&last_key, skey + (R - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+    {
+        MailGuard mg(ctx);  // (one synchronisation for the batch; destinations are locals of this frame)
+        ME_TRY(mail_post(ctx, &last_pos, pos + (R - 1), 4));
+        ME_TRY(mail_post(ctx, &last_flag, flags + (R - 1), 4));
+        ME_TRY(mail_post(ctx, &last_key, skey + (R - 1), 8));
+        ME_TRY(mg.sync());
+    }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     long long V = (long long) last_pos + last_flag;
+    ME_TRACE_POINT(ctx, "voxel_build: records sorted, voxel count read");
     const bool has_sentinel = c.slab.axis >= 0 && last_key == kVoxSentinel;
     if (has_sentinel) V -= 1;  // the halo points were keyed with the sentinel: their segment (the last one) is dropped
     DevBuf &seg = wbuf;        // wave_runs is dead (wave_off lives in the upper half)
@@ -785,12 +802,12 @@ int voxel_export(me_ctx *ctx, int slot, int32_t *keys, int32_t *npts, double *mu
         ME_CHECK(ctx, ctx->tmp[0].ensure((size_t) V * 12));
         hipLaunchKernelGGL(k_unpack_keys, dim3(grid_for(V)), dim3(256), 0, ctx->stream, c.vox_key.as<unsigned long long>(), V,
                            ctx->tmp[0].as<int>());
-        ME_CHECK(ctx, hipMemcpyAsync(keys, ctx->tmp[0].p, (size_t) V * 12, hipMemcpyDeviceToHost, ctx->stream));
+        ME_TRY(copy_d2h(ctx, keys, ctx->tmp[0].p, (size_t) V * 12));
     }
-    if (npts) ME_CHECK(ctx, hipMemcpyAsync(npts, c.vox_n.p, (size_t) V * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (mu) ME_CHECK(ctx, hipMemcpyAsync(mu, c.vox_mu.p, (size_t) V * 24, hipMemcpyDeviceToHost, ctx->stream));
-    if (sigma) ME_CHECK(ctx, hipMemcpyAsync(sigma, c.vox_sigma.p, (size_t) V * 72, hipMemcpyDeviceToHost, ctx->stream));
-    if (entropy) ME_CHECK(ctx, hipMemcpyAsync(entropy, c.vox_entropy.p, (size_t) V * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (npts) ME_TRY(copy_d2h(ctx, npts, c.vox_n.p, (size_t) V * 4));
+    if (mu) ME_TRY(copy_d2h(ctx, mu, c.vox_mu.p, (size_t) V * 24));
+    if (sigma) ME_TRY(copy_d2h(ctx, sigma, c.vox_sigma.p, (size_t) V * 72));
+    if (entropy) ME_TRY(copy_d2h(ctx, entropy, c.vox_entropy.p, (size_t) V * 8));
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ME_OK;
 }
@@ -822,7 +839,11 @@ int awd_scs(me_ctx *ctx, double voxel_size, int min_pts, int scs_radius, double 
     hipLaunchKernelGGL(k_count_u32, dim3(1), dim3(256), 0, ctx->stream, match.as<unsigned int>(), Ve, d_cnt + 1);
     ME_TRY(exclusive_scan_u32(ctx, match.as<unsigned int>(), mpos.as<unsigned int>(), Ve));
     long long h_cnt[2] = {0, 0};
-    ME_CHECK(ctx, hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
+    {
+        MailGuard mg(ctx);  // (one synchronisation for the batch; destinations are locals of this frame)
+        ME_TRY(mail_post(ctx, h_cnt, d_cnt, 16));
+        ME_TRY(mg.sync());
+    }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const long long n_active = h_cnt[0], M = h_cnt[1];
     if (counts) {  // "Update active/old/new voxel num" (voxel_calculator.cpp:170)
@@ -863,13 +884,17 @@ int awd_scs(me_ctx *ctx, double voxel_size, int min_pts, int scs_radius, double 
     ME_TRY(scs_device(ctx, mkey.as<unsigned long long>(), mw_own.as<double>(), M, scs_radius, d_s2, d_cnt + 3));
     double h_s[2] = {0, 0};
     long long h_c[2] = {0, 0};
-    ME_CHECK(ctx, hipMemcpyAsync(h_s, d_s, 16, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(h_c, d_cnt + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
-    if (rows) ME_CHECK(ctx, hipMemcpyAsync(rows, rows_d.p, (size_t) M * 27 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    {
+        MailGuard mg(ctx);  // (one synchronisation for the batch; destinations are locals of this frame)
+        ME_TRY(mail_post(ctx, h_s, d_s, 16));
+        ME_TRY(mail_post(ctx, h_c, d_cnt + 2, 16));
+        ME_TRY(mg.sync());
+    }
+    if (rows) ME_TRY(copy_d2h(ctx, rows, rows_d.p, (size_t) M * 27 * 8));
     if (w_sorted) {
         ME_CHECK(ctx, ws_d.ensure((size_t) M * 8));
         ME_TRY(sort_keys_f64(ctx, mw_own.as<double>(), ws_d.as<double>(), M));  // std::sort(ws_distances) (:330)
-        ME_CHECK(ctx, hipMemcpyAsync(w_sorted, ws_d.p, (size_t) M * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ME_TRY(copy_d2h(ctx, w_sorted, ws_d.p, (size_t) M * 8));
     }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ME_CHECK(ctx, hipGetLastError());
@@ -908,9 +933,13 @@ int voxel_downsample(me_ctx *ctx, int slot, double voxel_size, long long *n_out)
     ME_TRY(exclusive_scan_u32(ctx, flags.as<unsigned int>(), pos.as<unsigned int>(), n));
     unsigned int last_pos = 0, last_flag = 0;
     int h_err = 0;
-    ME_CHECK(ctx, hipMemcpyAsync(&last_pos, pos.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&last_flag, flags.as<unsigned int>() + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    ME_CHECK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    {
+        MailGuard mg(ctx);  // (one synchronisation for the batch; destinations are locals of this frame)
+        ME_TRY(mail_post(ctx, &last_pos, pos.as<unsigned int>() + (n - 1), 4));
+        ME_TRY(mail_post(ctx, &last_flag, flags.as<unsigned int>() + (n - 1), 4));
+        ME_TRY(mail_post(ctx, &h_err, d_err, 4));
+        ME_TRY(mg.sync());
+    }
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (h_err) return ctx->fail(ME_ERR_ARG, "voxel_size is too small for the cloud extent (more than 2^21 voxels per axis)");
     const long long V = (long long) last_pos + last_flag;

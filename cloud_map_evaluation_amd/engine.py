@@ -542,12 +542,13 @@ class Engine:
         sp.scs_radius = 5
         return sp
 
-    def run_suite_from(self, est, gt, p: Param, overlap: bool = True, gate_mode: int = ME_GATE_LE_UNSQUARED) -> _lib.SuiteOut:
+    def run_suite_from(self, est, gt, p: Param, overlap: bool = True, gate_mode: int = ME_GATE_LE_UNSQUARED,
+                       pin_host_input: bool = False) -> _lib.SuiteOut:
         """me_run_suite_from: the whole pass of MapEval::process (map_eval.cpp:52-85) from the two raw clouds in ONE library call —
         uploads, index builds, MME x2 (the map as loaded), p.initial_matrix_ (:1206), both 1-NN directions + statistics, voxel
         Gaussians, AWD / CDF / SCS; overlap: the library's internal second lane (ME_SUITE_OVERLAP).  est / gt: (N,3) float64 numpy
         arrays or torch tensors (both host or both cuda); None, None: the clouds already uploaded."""
-        flags = _lib.ME_SUITE_OVERLAP if overlap else 0
+        flags = (_lib.ME_SUITE_OVERLAP if overlap else 0) | (_lib.ME_SUITE_PIN_HOST_INPUT if pin_host_input else 0)
         ne = ng = 0
         if est is not None:
             on_dev = []

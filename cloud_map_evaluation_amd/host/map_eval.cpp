@@ -218,7 +218,6 @@ int MapEval::process() {
                     << gt_3d_->size() << std::endl;
         return fail(std::string("GPU engine unavailable: ") + me_last_error(nullptr));
     }
-    me_timers_enable(ctx_, 1);
     // The initial-matrix evaluation on one GPU is ONE library call (processOneCall: me_run_suite_from): without down-sampling it
     // starts from the host clouds as they were read — the uploads are part of the call's two-lane schedule.
     const bool one_call = param_.evaluate_using_initial_ && !comm_;
@@ -591,6 +590,9 @@ bool MapEval::renderEntropy(int slot, std::vector<double> &xyz, std::vector<doub
 // as ONE call into the library, made from this one thread (process() is single-threaded, :4): me_run_suite_from runs the stages
 // on two lanes (its second lane is a thread inside the library, csrc/me_suite.hip).  The reference's member functions keep their
 // roles below as CONSUMERS of what the call left on the device: entropies / colour maps, result vectors, the voxel files.
+// (the clouds are std::vectors: pageable.  The library moves them through its own pinned staging buffers at the link's rate;
+//  ME_SUITE_PIN_HOST_INPUT — page-locking the vectors in place for the call — is the alternative for callers short of host threads)
+static const int kSuiteFlags = ME_SUITE_OVERLAP;
 int MapEval::processOneCall(bool from_host, double t_loaded) {
     t1 = t_loaded;
     TicToc clock;
@@ -609,7 +611,7 @@ int MapEval::processOneCall(bool from_host, double t_loaded) {
     bool identity = true;
     for (int i = 0; i < 16; ++i) identity = identity && (T[i] == ((i % 5 == 0) ? 1.0 : 0.0));
     const int rc = from_host ? me_run_suite_from(ctx_, map_3d_->points_.data(), (int64_t) map_3d_->size(), gt_3d_->points_.data(),
-                                                 (int64_t) gt_3d_->size(), T, &sp, ME_SUITE_OVERLAP, &so)
+                                                 (int64_t) gt_3d_->size(), T, &sp, kSuiteFlags, &so)
                              : me_run_suite_from(ctx_, nullptr, 0, nullptr, 0, T, &sp, ME_SUITE_OVERLAP, &so);
     if (rc != ME_OK) return fail(me_last_error(ctx_));
     const double suite_ms = clock.toc();

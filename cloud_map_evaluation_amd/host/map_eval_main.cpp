@@ -81,6 +81,11 @@ int main(int argc, char **argv) {
         return EXIT_SUCCESS;
     }
     if (argc > 1) config_file = argv[1];
+    // `map_eval config.yaml --repeat N` (measurement aid, single GPU): the evaluation N times in this process — the first run pays the
+    // cold start (runtime and code-object load, every device allocation, the GPU's clocks coming up from idle after the file reads),
+    // the later ones show what the same call costs a long-lived caller (profiles/host_one_call.py)
+    int repeat = 1;
+    if (argc > 3 && std::string(argv[2]) == "--repeat") repeat = std::max(1, std::atoi(argv[3]));
 
     std::cout << "Loading configuration from: " << config_file << "\n";
     Param param;
@@ -100,6 +105,18 @@ int main(int argc, char **argv) {
     const long launcher_pid = (long) getpid();
     if (world > 1) {
         std::cout.flush();
+        // The SIGCHLD handler is installed BEFORE the first fork, blocked until the children are recorded: a child
+        // that dies early is not missed, and SA_RESTART keeps rank 0's blocking system calls (file I/O, the file transport's polling)
+        // from failing with EINTR when ranks exit.
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sa_handler = on_child_exit;
+        sa.sa_flags = SA_NOCLDSTOP | SA_RESTART;
+        sigset_t chld, old_mask;
+        sigemptyset(&chld);
+        sigaddset(&chld, SIGCHLD);
+        sigprocmask(SIG_BLOCK, &chld, &old_mask);
+        sigaction(SIGCHLD, &sa, nullptr);
         for (int r = 1; r < world; ++r) {
             const pid_t pid = fork();
             if (pid < 0) {
@@ -110,6 +127,8 @@ int main(int argc, char **argv) {
             if (pid == 0) {
                 rank = r;
                 children.clear();
+                signal(SIGCHLD, SIG_DFL);
+                sigprocmask(SIG_SETMASK, &old_mask, nullptr);
                 // a rank never outlives the launcher (rank 0): no orphan is left spinning in a collective
                 prctl(PR_SET_PDEATHSIG, SIGKILL);
                 if (getppid() != (pid_t) launcher_pid) _exit(EXIT_FAILURE);
@@ -121,11 +140,7 @@ int main(int argc, char **argv) {
             // ... and the launcher does not outlive a failed rank: RCCL collectives have no timeout, so a rank that exits with an
             // error (GPU fault, out of memory, a failed library call) takes the whole job down instead of hanging it
             g_children = children;
-            struct sigaction sa;
-            std::memset(&sa, 0, sizeof sa);
-            sa.sa_handler = on_child_exit;
-            sa.sa_flags = SA_NOCLDSTOP;
-            sigaction(SIGCHLD, &sa, nullptr);
+            sigprocmask(SIG_SETMASK, &old_mask, nullptr);  // pending SIGCHLDs (children that have died already) are delivered now
         }
     }
     const bool single_device = std::getenv("MAPEVAL_SINGLE_DEVICE") && std::string(std::getenv("MAPEVAL_SINGLE_DEVICE")) == "1";
@@ -160,8 +175,8 @@ int main(int argc, char **argv) {
     if (rank == 0) param.printParam();
     std::cout << "Starting evaluation...\n"
               << "================================================================================\n\n";
-    int rc;
-    {
+    int rc = 0;
+    for (int it = 0; it < (world > 1 ? 1 : repeat) && rc == 0; ++it) {
         MapEval map_eval(param);
         if (comm) map_eval.setComm(comm.get(), forced);
         rc = map_eval.process();

@@ -375,13 +375,17 @@ int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out);
  * [7] the whole call. */
 #define ME_SUITE_OVERLAP 1
 #define ME_SUITE_DEVICE_INPUT 2
+#define ME_SUITE_PIN_HOST_INPUT 4 /* host input: page-lock the caller's two buffers for the duration of the call (hipHostRegister;
+                                   * ~2 ms per 1.2 GB where measured), so that pageable memory — a std::vector, Open3D's points_ —
+                                   * crosses PCIe at the pinned rate (21 instead of 30 ms per 50 M points); already pinned: no-op */
 int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const double *gt, int64_t n_gt, const double *T_rowmajor4x4,
                       const me_suite_params *p, int flags, me_suite_out *out);
 
 /* ---- instrumentation (bench.py roofline leg) ------------------------------------------------------------- */
 /* Average device time (ms, HIP events on the context's stream) and launch count of a named kernel family since
  * the last me_timers_reset: "nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "voxel", "w2", "scs", "slab_filter", "halo_pack".  Enabled by me_timers_enable(1).
- * Counters (total_ms = 0, value in *launches): "nn_queries" / "nn_fallback_queries" (1-NN queries, and those that needed the
+ * Counters (total_ms = 0, value in *launches): "mme_pairs" (accepted (query, neighbour) pairs of the MME launches: the useful work of
+ * the VALU-bound kernel, bench.py's roofline.valu), "nn_queries" / "nn_fallback_queries" (1-NN queries, and those that needed the
  * octree pass), "nn1_opened" / "nn1_scans" / "nn1_points" / "nn1_max_opened" (octree walk: nodes opened, leaf cells and points
  * scanned, the longest chain of one query in the octet walk), "nn1_far" (walks handed over to the wave-per-query kernel). */
 int me_timers_enable(me_ctx *ctx, int on);

@@ -257,8 +257,13 @@ def test_golden_reference_run_through_device_kernels(eng, golden):
     np.testing.assert_allclose(w[::7], ow, rtol=1e-9, atol=1e-12)  # device == oracle on the golden inputs
     keys = np.rint(rows[:, 0:3] / float(golden["voxel_size"])).astype(np.int32)
     scs = eng.scs_table(keys, rows[:, 9], 5)
-    assert abs(scs - float(golden["screenshot_scs"])) < 5e-6       # README screenshot SCS: 0.78121
-    assert abs(rows[:, 9].mean() - float(golden["screenshot_vmd"])) < 5e-6
+    assert abs(scs - float(golden["screenshot_scs"])) < 5e-6       # README screenshot SCS: 0.78121 (from the file's own W column)
+    # ... and the DEVICE's numbers against the screenshot: AWD = the mean of the W the device kernel computed
+    # from the file's mu / Sigma columns (6 printed digits: per-voxel W moves by ~1e-3 relative, the mean by 9e-7), SCS from those W
+    assert abs(float(w.mean()) - float(golden["screenshot_vmd"])) < 5e-6   # screenshot VMD: 0.35303
+    scs_dev = eng.scs_table(keys, w, 5)
+    assert abs(scs_dev - float(golden["screenshot_scs"])) < 3e-5          # (0.781196 from the reprinted inputs)
+    assert abs(rows[:, 9].mean() - float(golden["screenshot_vmd"])) < 5e-6  # (the fixture itself is the screenshot's run)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -473,11 +478,18 @@ def test_index_rebuilds_with_the_pair_sort_when_the_packed_sort_had_to_cut_its_d
         eng.timers_reset()
         eng.upload(1, gt, cell_size=0.1)
         second = eng.timer("sort")[1]
+        eng.timers_reset()
+        eng.upload(1, gt[: 2 ** 19 - 7], cell_size=0.1)  # ANOTHER cloud on the slot: the hint does not stick to it
+        third = eng.timer("sort")[1]
+        eng.timers_reset()
+        eng.upload(1, gt, cell_size=0.1)
+        fourth = eng.timer("sort")[1]
         eng.timers_enable(False)
         eng.upload(0, est, cell_size=0.1)
         idx, d2 = eng.nn1(0, 1)
         m = eng.mme(1, 0.1, 5)
     assert (first, second) == (2, 1), (first, second)
+    assert third == 1 and fourth == 2, (third, fourth)  # (a sparse-enough prefix sorts once, packed; the dense cloud decides again)
     oi, od2 = oracle.nn1(gt, est)
     assert np.array_equal(d2, od2) and np.array_equal(idx, oi)
     om = oracle.mme(gt, 0.1, 5)

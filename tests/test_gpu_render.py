@@ -97,8 +97,8 @@ def test_run_suite_reports_stage_times(eng, pair):
     eng.upload(1, gt, cell_size=0.1)
     out = eng.run_suite(Param(icp_max_distance_=1.0, nn_radius_=0.1, vmd_voxel_size_=3.0))
     st = list(out.stage_ms)
-    assert all(st[k] > 0.0 for k in (1, 2, 3, 4, 5, 6)) and st[0] == 0.0 and st[7] == 0.0
-    assert sum(st) < 5_000.0
+    assert all(st[k] > 0.0 for k in (1, 2, 3, 4, 5, 6)) and st[0] == 0.0  # ([0]: upload + index, me_run_suite_from only)
+    assert st[7] >= sum(st[1:7]) * 0.999 and st[7] < 5_000.0                  # [7]: the whole call
 
 
 def _read_pcd_xyz_rgb(path):

@@ -80,6 +80,11 @@ def test_device_input_and_resident_clouds(eng, pair):
     est, gt = pair
     P = _param()
     host = eng.run_suite_from(est, gt, P, overlap=True)
+    pinned = eng.run_suite_from(est, gt, P, overlap=True, pin_host_input=True)  # ME_SUITE_PIN_HOST_INPUT: registered for the call
+    _same(host, pinned)
+    pinned = eng.run_suite_from(est, gt, P, overlap=False, pin_host_input=True)
+    _same(host, pinned)
+    assert np.isfinite(est).all()  # (still readable: unregistered again)
     dev = torch.device("cuda", 0)
     est_d, gt_d = torch.from_numpy(est).to(dev), torch.from_numpy(gt).to(dev)
     a = eng.run_suite_from(est_d, gt_d, P, overlap=True)
@@ -148,9 +153,9 @@ def test_switches_and_error_paths(eng, pair):
     P.evaluate_mme_ = False
     o = eng.run_suite_from(est, gt, P, overlap=True)
     assert o.mme_est == 0.0 and o.mme_est_valid == 0 and o.awd > 0
-    # a ground truth with a NaN fails on the SECOND lane: the call returns the error (it must not hang or crash)
+    # a ground truth with a non-finite coordinate fails on the SECOND lane: the call returns its error (it must not hang or crash)
     bad = gt.copy()
-    bad[123, 1] = np.nan
+    bad[123, 1] = -np.inf
     with pytest.raises(MapEvalError, match="NaN"):
         eng.run_suite_from(est, bad, _param(), overlap=True)
     # ... and a bad map on the main lane, with the second lane already running
