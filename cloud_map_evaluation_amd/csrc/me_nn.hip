@@ -108,30 +108,32 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     const double cell_h = ldexp(fr.fine_h, g.shift);
     __shared__ float4 s_tile[4][64];  // (doubles as the row masks of the adjacency cull while a round's table is built)
     __shared__ int2 s_tab[4][kGroupTab + 1];
-    const long long n_in = FROM_LIST ? (long long) *in_count : 0;
-  for (long long pos = (long long) vb * blockDim.x + threadIdx.x;; pos += (long long) gridDim.x * blockDim.x) {
-    long long i;
+    // (list positions and the offsets of a pass are 32-bit — a cloud holds < 2^31 points —: the 64-bit forms cost the list pass, whose
+    // loop keeps them alive across a whole round, 12 bytes of scratch per lane)
+    const unsigned int n_in = FROM_LIST ? *in_count : 0u;
+  for (unsigned int pos = vb * blockDim.x + threadIdx.x;; pos += gridDim.x * blockDim.x) {
+    unsigned int qoff;  // the query is qsp[q_begin + qoff] (the 64-bit index is formed where it is used, not carried)
     bool active;
     if (FROM_LIST) {
         if (!__ballot(pos < n_in)) break;  // wave-uniform
         active = pos < n_in;
-        i = q_begin + (active ? (long long) in_list[pos] : 0);
+        qoff = active ? in_list[pos] : 0u;
     } else {
-        i = q_begin + pos;
-        active = i < q_end;
+        qoff = pos;
+        active = q_begin + (long long) qoff < q_end;
     }
 
     double qx = 0, qy = 0, qz = 0;
     int mcx = 0, mcy = 0, mcz = 0;  // the query's cell in the REFERENCE cloud's grid
     bool in_grid = false;
     if (active) {
-        const SPoint q = qsp[i];
+        const SPoint q = qsp[q_begin + (long long) qoff];
         qx = q.x;
         qy = q.y;
         qz = q.z;
         if (!FROM_LIST && !slab_owned(slab, qx, qy, qz)) {  // halo point: a reference for others, not a query of this rank
-            d2_out[i] = -1.0;                 // skip marker for the statistics kernels
-            idx_out[i] = -1;
+            d2_out[q_begin + (long long) qoff] = -1.0;                 // skip marker for the statistics kernels
+            idx_out[q_begin + (long long) qoff] = -1;
             active = false;
         }
     }
@@ -295,12 +297,12 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             gmin *= (1.0 - 1e-9);  // rounding slack of the cell assignment
             unresolved = !(gmin > 0.0 && best_x < gmin * gmin);
         }
-        d2_out[i] = best_x;  // final if resolved, initial bound otherwise
-        idx_out[i] = (j1 >= 0) ? (int) best_i : -1;
+        d2_out[q_begin + (long long) qoff] = best_x;  // final if resolved, initial bound otherwise
+        idx_out[q_begin + (long long) qoff] = (j1 >= 0) ? (int) best_i : -1;
     }
     if (!FROM_LIST && flag_out) {
         // first pass of the cascade: flag the unresolved queries; the ordered list is built by a stream compaction
-        if (i < q_end) flag_out[i - q_begin] = unresolved ? 1 : 0;
+        if (q_begin + (long long) qoff < q_end) flag_out[qoff] = unresolved ? 1 : 0;
     } else {
         // wave-aggregated append of the unresolved lanes
         const unsigned long long um = __ballot(unresolved);
@@ -308,7 +310,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             unsigned int base = 0;
             if (lane == 0) base = atomicAdd(list_count, (unsigned int) __popcll(um));
             base = (unsigned int) readlane_i((int) base, 0);
-            if (unresolved) list[base + (unsigned int) __popcll(um & ((1ULL << lane) - 1ULL))] = (unsigned int) (i - q_begin);
+            if (unresolved) list[base + (unsigned int) __popcll(um & ((1ULL << lane) - 1ULL))] = qoff;
         }
     }
     if (!FROM_LIST) break;
@@ -340,6 +342,10 @@ constexpr int kNn1Block = 64;  // 8 octets per block (one wavefront): 8 x (level
 // (96 VGPRs, five wavefronts per SIMD: at 80 / 72 / 64 registers the compiler spills 19 / 27 / 41 dwords and the launch is slower —
 // 0.86 / 0.93 / 1.00 / 1.40 ms on the bench pair: the kernel is bound by instruction issue, not by the walks in flight)
 constexpr int kNn1Waves = 5;
+// COV / DBG (round 5): the covered-band bound of the cross-rank step and the walk counters of the instrumented runs are compile-time
+// variants — their live values (the band, seven counters) cost the plain walk, the one every 1-NN pass of a product run launches, 24
+// bytes of scratch per lane at 96 VGPRs through round 4.
+template <bool COV, bool DBG>
 __global__ void __launch_bounds__(kNn1Block) __attribute__((amdgpu_waves_per_eu(kNn1Waves, 8)))
 k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const SPoint *__restrict__ rsp, long long nr,
       OctView oct, double *__restrict__ d2_out, int *__restrict__ idx_out, const unsigned int *__restrict__ list,
@@ -366,8 +372,8 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
     const ONode *__restrict__ nodes = oct.nodes;
     const long long n_items = list ? (long long) *list_count : (q_end - q_begin);
     const int sub = threadIdx.x & 7;
-    const unsigned long long t_wave0 = dbg ? wall_clock64() : 0ULL;  // (100 MHz)
-    unsigned long long w_open = 0, w_scan = 0, w_pts = 0;
+    const unsigned long long t_wave0 = DBG ? wall_clock64() : 0ULL;  // (100 MHz)
+    unsigned long long w_open = 0, w_scan = 0, w_pts = 0;  // (DBG only)
     unsigned int w_max = 0;
     static_assert(kNn1Block == 64, "one wavefront per block: the group counter is drawn by lane 0 of the block");
     for (long long g = blockIdx.x;;) {
@@ -383,12 +389,12 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
         const SPoint q = qsp[i];
         const double qx = q.x, qy = q.y, qz = q.z;
         double clo = INFINITY, chi = -INFINITY;  // (empty interval: nothing covered)
-        if (cov && alive) {
+        if (COV && alive) {
             clo = cov[2 * (i - q_begin)];
             chi = cov[2 * (i - q_begin) + 1];
         }
-        unsigned int n_open = 0, n_scan = 0;  // nodes opened / point runs scanned by this octet (profiling counters, `dbg`)
-        unsigned long long n_pts = 0;
+        unsigned int n_open = 0, n_scan = 0;  // nodes opened / point runs scanned by this octet: n_open counts BOTH unless DBG
+        unsigned long long n_pts = 0;         // (DBG only)
         double best = INFINITY;
         long long best_i = 0x7fffffffffffffffLL;
         if (list && alive) {
@@ -408,8 +414,12 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
         // per lane in flight; clamped addresses keep them unconditional)
         auto scan_points = [&](bool go, long long jb, long long je) {
             if (!go) jb = je = 0;
-            n_scan += go ? 1u : 0u;
-            n_pts += (unsigned long long) (je - jb);
+            if (DBG) {
+                n_scan += go ? 1u : 0u;
+                n_pts += (unsigned long long) (je - jb);
+            } else {
+                n_open += go ? 1u : 0u;  // (one step counter for the hand-over to k_nn_far)
+            }
             for (long long j = jb + sub; __ballot(j < je); j += 16) {
                 const long long j1 = j + 8;
                 const long long last = je > 0 ? je - 1 : 0;
@@ -482,7 +492,7 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
                 // every child box also yields an UPPER bound on the answer (some point lies inside it, no farther than
                 // its farthest corner): keeps the depth-first walk from sweeping a wide region on a loose `best`
                 const double ub = octet_min(mine ? box_upper_bound(f, qx, qy, qz) : INFINITY);
-                const double lbd = cov ? box_lower_bound_cov(f, qx, qy, qz, cov_axis, clo, chi) : box_lower_bound(f, qx, qy, qz);
+                const double lbd = COV ? box_lower_bound_cov(f, qx, qy, qz, cov_axis, clo, chi) : box_lower_bound(f, qx, qy, qz);
                 if (go) {
                     bound = fmin(bound, ub);
                     c_lb[lev * 8 + sub] = mine ? __double2float_rd(lbd) : INFINITY;
@@ -577,13 +587,15 @@ k_nn1(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, const 
         if (alive && sub == 0) {
             d2_out[i] = best;
             idx_out[i] = (int) best_i;
-            w_open += n_open;  // (profiling counters: summed per wavefront, see the end of the kernel)
-            w_scan += n_scan;
-            w_pts += n_pts;
-            w_max = max(w_max, n_open + n_scan);
+            if (DBG) {
+                w_open += n_open;  // (profiling counters: summed per wavefront, see the end of the kernel)
+                w_scan += n_scan;
+                w_pts += n_pts;
+                w_max = max(w_max, n_open + n_scan);
+            }
         }
     }  // grid-stride loop over octets
-    if (dbg) {
+    if (DBG && dbg) {
         // me_timer_get "nn1_opened" / "nn1_scans" / "nn1_points" / "nn1_max_opened" (only while timers are on).  ONE atomic per
         // wavefront and counter: an atomic per query — 470 k of them on four addresses, serialised in one L2 channel — cost the
         // instrumented launch 0.8 ms of its 1.65 (round 4; the untimed steps never paid it)
@@ -1068,10 +1080,14 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
             ME_CHECK(ctx, ctx->nn_far.ensure((size_t) (e - b) * 4 + 64));
             {
                 TimerScope ts(ctx, "nn1");
-                hipLaunchKernelGGL(k_nn1, dim3(nbf), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream, q.sp.as<SPoint>(), b, e, r.sp.as<SPoint>(), r.n,
-                                   r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0,
-                                   ctx->timers_on ? ctx->nn1_dbg() : nullptr, ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4,
-                                   (const double *) nullptr, 0);
+#define ME_LAUNCH_NN1(COV_, DBG_, DBGP)                                                                                                  \
+    hipLaunchKernelGGL((k_nn1<COV_, DBG_>), dim3(nbf), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream, q.sp.as<SPoint>(), b, e,        \
+                       r.sp.as<SPoint>(), r.n, r.oct, q.nn_d2.as<double>(), q.nn_idx.as<int>(), q.nn_list.as<unsigned int>(), d_cnt, 0, DBGP, \
+                       ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4, (const double *) nullptr, 0)
+                unsigned long long *dbgp = ctx->timers_on ? ctx->nn1_dbg() : nullptr;
+                if (dbgp) ME_LAUNCH_NN1(false, true, dbgp);
+                else ME_LAUNCH_NN1(false, false, (unsigned long long *) nullptr);
+#undef ME_LAUNCH_NN1
             }
             {
                 TimerScope ts(ctx, "nn_far");
@@ -1138,10 +1154,17 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
         unsigned int *d_cnt = ctx->red.as<unsigned int>();
         ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));  // ([4]: k_nn1's group counter)
         TimerScope ts(ctx, "nn1");
-        hipLaunchKernelGGL(k_nn1, dim3((unsigned int) std::min<long long>((m + 7) / 8, 256 * 4 * kNn1Waves)), dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream,
-                           qs.as<SPoint>(), 0LL, m, r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(), (const unsigned int *) nullptr,
-                           (const unsigned int *) nullptr, bounded ? 1 : 0, ctx->timers_on ? ctx->nn1_dbg() : nullptr,
-                           ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4, cov_device, cov_axis);
+#define ME_LAUNCH_NN1P(COV_, DBG_, DBGP)                                                                                                    \
+    hipLaunchKernelGGL((k_nn1<COV_, DBG_>), dim3((unsigned int) std::min<long long>((m + 7) / 8, 256 * 4 * kNn1Waves)), dim3(kNn1Block),        \
+                       nn1_cache_bytes(r.oct), ctx->stream, qs.as<SPoint>(), 0LL, m, r.sp.as<SPoint>(), r.n, r.oct, d2_device, qi.as<int>(),    \
+                       (const unsigned int *) nullptr, (const unsigned int *) nullptr, bounded ? 1 : 0, DBGP, ctx->nn_far.as<unsigned int>(),   \
+                       d_cnt + 1, nn1_far_cap(), d_cnt + 4, cov_device, cov_axis)
+        unsigned long long *dbgp = ctx->timers_on ? ctx->nn1_dbg() : nullptr;
+        if (cov_device && dbgp) ME_LAUNCH_NN1P(true, true, dbgp);
+        else if (cov_device) ME_LAUNCH_NN1P(true, false, (unsigned long long *) nullptr);
+        else if (dbgp) ME_LAUNCH_NN1P(false, true, dbgp);
+        else ME_LAUNCH_NN1P(false, false, (unsigned long long *) nullptr);
+#undef ME_LAUNCH_NN1P
         hipLaunchKernelGGL(k_nn_far, dim3(kFarGrid), dim3(256), 0, ctx->stream, qs.as<SPoint>(), 0LL, r.sp.as<SPoint>(), r.oct, d2_device,
                            qi.as<int>(), ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn_far_leaf(), ctx->timers_on ? ctx->nn1_dbg() : nullptr, cov_device, cov_axis);
     }

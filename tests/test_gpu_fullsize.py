@@ -62,7 +62,7 @@ def test_c2_5m_pair_cd_ac_com_against_the_whole_oracle():
             t.close()
 
 
-def _full_tree_subsample_check(make_pair, n, voxel, radius=0.1, frac=0.01, seed=5):
+def _full_tree_subsample_check(make_pair, n, voxel, radius=0.1, frac=0.01, seed=5, expect_cascade=False):
     import oracle
     from cloud_map_evaluation_amd.engine import Engine
 
@@ -72,6 +72,9 @@ def _full_tree_subsample_check(make_pair, n, voxel, radius=0.1, frac=0.01, seed=
     est, gt = est_d.cpu().numpy(), gt_d.cpu().numpy()
     rng = np.random.default_rng(seed)
     with Engine(0) as eng:
+        if expect_cascade:
+            eng.timers_enable(True)
+            eng.timers_reset()
         eng.upload(0, est_d, cell_size=radius)
         eng.upload(1, gt_d, cell_size=radius)
         del est_d, gt_d
@@ -93,6 +96,9 @@ def _full_tree_subsample_check(make_pair, n, voxel, radius=0.1, frac=0.01, seed=
             del idx, d2
         for t in trees.values():
             t.close()
+        if expect_cascade:  # the 1-NN passes above went through the multi-level list passes (k_nn_grid<FROM_LIST>), not only the fine grid
+            assert eng.timer("nn_grid2")[1] >= 2, "the dense pair was meant to exercise the 1-NN cascade"
+            eng.timers_enable(False)
         # voxel tables of the WHOLE clouds + AWD / SCS (voxel_calculator.cpp:21-56, map_eval.cpp:240-390)
         og, oe = oracle.VoxelMap(gt, voxel), oracle.VoxelMap(est, voxel)
         for slot, om in ((0, oe), (1, og)):
@@ -123,6 +129,18 @@ def test_c4_50m_multisession_pair_full_suite_against_the_full_tree_oracle():
 
     _full_tree_subsample_check(lambda dev: synth.multisession_pair(50_000_000, 3, density=2500.0, seed=100, device=dev),
                                50_000_000, 3.0)
+
+
+def test_c4_dense_50m_pair_full_suite_against_the_full_tree_oracle():
+    """The reference's DEFAULT regime at full size (missing 4): every shipped config down-samples at
+    downsample_size 0.01 (config/config.yaml:66) ~ 10^4 pts/m^2, ~300 neighbours inside nn_radius.  The 50 M + 50 M multi-session
+    pair at that density: MME of both clouds and both 1-NN directions on a seeded subsample against FULL-size oracle trees — the
+    queries the fine 1-NN grid leaves open go through the list passes over the coarser levels (checked to have run) —, voxel tables
+    of the whole clouds, AWD / CDF / SCS."""
+    from cloud_map_evaluation_amd import synth
+
+    _full_tree_subsample_check(lambda dev: synth.multisession_pair(50_000_000, 3, density=10_000.0, seed=100, device=dev),
+                               50_000_000, 3.0, frac=0.004, expect_cascade=True)
 
 
 def test_c5_100m_tunnel_pair_full_suite_against_the_full_tree_oracle():
