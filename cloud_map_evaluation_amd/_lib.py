@@ -23,7 +23,7 @@ ME_SUITE_PIN_HOST_INPUT = 4
 # every symbol include/mapeval_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "me_create", "me_destroy", "me_twin", "me_last_error", "me_version", "me_set_shard", "me_set_slab",
-    "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_points_covered", "me_nn_patch", "me_nn_fetch", "me_slab_points", "me_set_mme_result", "me_set_nn_result", "me_voxel_partials",
+    "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_points_covered", "me_nn_cross_message", "me_nn_cross_answer", "me_nn_cross_patch", "me_nn_patch", "me_nn_fetch", "me_slab_points", "me_set_mme_result", "me_set_nn_result", "me_voxel_partials",
     "me_transform_points_device", "me_upload_slab_device", "me_halo_pack_device", "me_halo_pack_tagged_device", "me_voxel_partial_rows_device", "me_voxel_merge_device",
     "me_upload_cloud", "me_upload_cloud_device", "me_cloud_size", "me_download_cloud", "me_voxel_downsample",
     "me_transform_cloud",
@@ -142,6 +142,11 @@ def load():
     L.me_nn_points_bounded.argtypes = [vp, C.c_int, dp, C.c_int64, dp]
     L.me_nn_points_covered.argtypes = [vp, C.c_int, dp, C.c_int64, dp, C.c_int, dp]
     L.me_nn_patch.argtypes = [vp, C.c_int, dp, C.c_int64]
+    L.me_nn_cross_message.argtypes = [vp, dp, C.c_int64, C.c_int64, C.c_int64, dp]
+    L.me_nn_cross_answer.argtypes = [vp, dp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, dp, C.c_double, dp]
+    L.me_nn_cross_patch.argtypes = [vp, dp, C.c_int64, C.c_int]
+    for f in ("me_nn_cross_message", "me_nn_cross_answer", "me_nn_cross_patch"):
+        getattr(L, f).restype = C.c_int
     L.me_nn_fetch.argtypes = [vp, C.c_int, ip, dp]
     L.me_slab_points.argtypes = [vp, C.c_int, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.me_set_mme_result.argtypes = [vp, C.c_int, dp, vp]

@@ -468,6 +468,28 @@ int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t co
     return me::nn_patch(ctx, query_slot, d2_device, count);
 }
 
+int me_nn_cross_message(me_ctx *ctx, double *msg_device, int64_t capacity, int64_t n_local_est, int64_t n_local_gt, int64_t counts[2]) {
+    if (!ctx) return ME_ERR_ARG;
+    long long c[2] = {0, 0};
+    const int rc = me::nn_cross_message(ctx, msg_device, capacity, n_local_est, n_local_gt, c);
+    if (counts) {
+        counts[0] = c[0];
+        counts[1] = c[1];
+    }
+    return rc;
+}
+
+int me_nn_cross_answer(me_ctx *ctx, const double *gathered_device, int world, int64_t capacity, int own_rank, int dir_mask, int axis,
+                       const double *cuts, double halo, double *d2_device) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::nn_cross_answer(ctx, gathered_device, world, capacity, own_rank, dir_mask, axis, cuts, halo, d2_device);
+}
+
+int me_nn_cross_patch(me_ctx *ctx, const double *d2_reduced_device, int64_t capacity, int own_rank) {
+    if (!ctx) return ME_ERR_ARG;
+    return me::nn_cross_patch(ctx, d2_reduced_device, capacity, own_rank);
+}
+
 int me_transform_points_device(me_ctx *ctx, double *xyz_device, int64_t n, const double *T) {
     if (!ctx) return ME_ERR_ARG;
     return me::transform_points_device(ctx, xyz_device, n, T);

@@ -402,6 +402,10 @@ int nn_unresolved(me_ctx *ctx, int qslot, double *xyz_device, double *d2_device,
 int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, double *d2_device, bool bounded, int cov_axis = 0,
               const double *cov_device = nullptr);
 int nn_patch(me_ctx *ctx, int qslot, const double *d2_device, long long count);
+int nn_cross_message(me_ctx *ctx, double *msg_device, long long cap, long long n_loc_est, long long n_loc_gt, long long counts[2]);
+int nn_cross_answer(me_ctx *ctx, const double *gathered_device, int world, long long cap, int own_rank, int dir_mask, int axis,
+                    const double *cuts_host, double halo, double *d2_device);
+int nn_cross_patch(me_ctx *ctx, const double *d2_reduced_device, long long cap, int own_rank);
 int icp_p2p_sums(me_ctx *ctx, int qslot, double max_distance, me_icp_sums *out);
 int nn_partial(me_ctx *ctx, int qslot, double gate, int gate_mode, const double trunc[5], me_nn_partial *out);
 int nn_sigma(me_ctx *ctx, int qslot, double gate, int gate_mode, const double mean[5], double sigma_num[5]);

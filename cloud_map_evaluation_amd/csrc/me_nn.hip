@@ -1173,6 +1173,171 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
     return ME_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The cross-rank 1-NN step of a slab run in three library calls (round 5; dist.py and the C++ host drove it with ~60 small
+// tensor operations and two searches + two patches per direction).  One fixed-capacity MESSAGE per rank:
+//   row 0                 [open queries map -> gt, open queries gt -> map, local points of the map, of the ground truth]
+//   rows 1 .. cap         the open queries of the map -> ground-truth search: x, y, z, bound (their best squared distance so far)
+//   rows 1 + cap .. 2 cap the same for ground truth -> map;  unused rows carry the bound -1 (a walk that ends at the root)
+// all-gathered as it is (world x (1 + 2 cap) x 4 doubles), answered in place, min-reduced, patched.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_cross_message(const SPoint *__restrict__ sp0, const unsigned int *__restrict__ list0, const double *__restrict__ d2s0, long long cnt0,
+                                const SPoint *__restrict__ sp1, const unsigned int *__restrict__ list1, const double *__restrict__ d2s1, long long cnt1,
+                                long long cap, double n_loc0, double n_loc1, double *__restrict__ msg) {
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        msg[0] = (double) cnt0;
+        msg[1] = (double) cnt1;
+        msg[2] = n_loc0;
+        msg[3] = n_loc1;
+    }
+    if (t >= 2 * cap) return;
+    const int d = t >= cap ? 1 : 0;
+    const long long k = t - d * cap;
+    const long long cnt = d ? cnt1 : cnt0;
+    double *row = msg + 4 * (1 + t);
+    if (k < cnt) {
+        const unsigned int at = d ? list1[k] : list0[k];
+        const SPoint q = d ? sp1[at] : sp0[at];
+        row[0] = q.x;
+        row[1] = q.y;
+        row[2] = q.z;
+        row[3] = d ? d2s1[at] : d2s0[at];
+    } else {
+        row[0] = row[1] = row[2] = 0.0;
+        row[3] = -1.0;
+    }
+}
+
+struct CrossCuts {
+    double c[66];  // cuts[world + 1]
+};
+// gathered message -> the queries of ONE direction as SPoints, their bounds (own rank / padding: -1) and the band each owner has searched
+__global__ void k_cross_expand(const double *__restrict__ gathered, int world, long long cap, int dir, int own_rank, CrossCuts cuts, double halo,
+                               SPoint *__restrict__ qs, double *__restrict__ bound, double *__restrict__ cov) {
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long) world * cap) return;
+    const int k = (int) (t / cap);
+    const long long j = t - (long long) k * cap;
+    const double *row = gathered + 4 * ((long long) k * (1 + 2 * cap) + 1 + (long long) dir * cap + j);
+    SPoint p;
+    p.x = row[0];
+    p.y = row[1];
+    p.z = row[2];
+    p.idx = t;
+    qs[t] = p;
+    bound[t] = (k == own_rank) ? -1.0 : row[3];
+    cov[2 * t] = cuts.c[k] - halo;       // the owner's slab + halo holds every point of the cloud in this band (me_halo_pack_device)
+    cov[2 * t + 1] = cuts.c[k + 1] + halo;
+}
+// answers back into the (world x (1 + 2 cap)) block: searched slots = min(bound, nearest here), the own rank's slots = its own bounds
+__global__ void k_cross_collect(const double *__restrict__ gathered, const double *__restrict__ ans, int world, long long cap, int dir, int own_rank,
+                                double *__restrict__ d2_out) {
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long) world * cap) return;
+    const int k = (int) (t / cap);
+    const long long j = t - (long long) k * cap;
+    const long long at = (long long) k * (1 + 2 * cap) + 1 + (long long) dir * cap + j;
+    d2_out[at] = (k == own_rank) ? gathered[4 * at + 3] : ans[t];
+}
+__global__ void k_cross_untouched(const double *__restrict__ gathered, int world, long long cap, int dir, double *__restrict__ d2_out) {
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long) world * cap) return;
+    const int k = (int) (t / cap);
+    const long long at = (long long) k * (1 + 2 * cap) + 1 + (long long) dir * cap + (t - (long long) k * cap);
+    d2_out[at] = gathered[4 * at + 3];
+}
+__global__ void k_cross_patch(const unsigned int *__restrict__ list0, long long cnt0, double *__restrict__ d2_0, const unsigned int *__restrict__ list1,
+                              long long cnt1, double *__restrict__ d2_1, const double *__restrict__ mine, long long cap) {
+    const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < cnt0) {
+        const unsigned int i = list0[t];
+        d2_0[i] = fmin(d2_0[i], mine[1 + t]);
+    } else if (t - cnt0 < cnt1) {
+        const long long u = t - cnt0;
+        const unsigned int i = list1[u];
+        d2_1[i] = fmin(d2_1[i], mine[1 + cap + u]);
+    }
+}
+
+int nn_cross_message(me_ctx *ctx, double *msg_device, long long cap, long long n_loc_est, long long n_loc_gt, long long counts[2]) {
+    if (!msg_device || cap < 1 || !counts) return ctx->fail(ME_ERR_ARG, "me_nn_cross_message: bad argument");
+    Cloud &a = ctx->cloud[ME_SLOT_EST], &b = ctx->cloud[ME_SLOT_GT];
+    if (a.nn_ref_slot < 0 || b.nn_ref_slot < 0) return ctx->fail(ME_ERR_STATE, "me_nn_cross_message: search both directions first (me_nn1)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    counts[0] = a.n_unres;
+    counts[1] = b.n_unres;
+    const long long c0 = std::min(a.n_unres, cap), c1 = std::min(b.n_unres, cap);  // (more than cap: the caller's exact-size fallback)
+    hipLaunchKernelGGL(k_cross_message, dim3((unsigned int) ((2 * cap + 255) / 256)), dim3(256), 0, ctx->stream, a.sp.as<SPoint>(),
+                       a.nn_unres.as<unsigned int>(), a.nn_d2.as<double>(), c0, b.sp.as<SPoint>(), b.nn_unres.as<unsigned int>(),
+                       b.nn_d2.as<double>(), c1, cap, (double) n_loc_est, (double) n_loc_gt, msg_device);
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
+int nn_cross_answer(me_ctx *ctx, const double *gathered_device, int world, long long cap, int own_rank, int dir_mask, int axis,
+                    const double *cuts_host, double halo, double *d2_device) {
+    if (!gathered_device || !d2_device || !cuts_host || world < 1 || world > 64 || cap < 1 || own_rank < 0 || own_rank >= world || axis < 0 ||
+        axis > 2)
+        return ctx->fail(ME_ERR_ARG, "me_nn_cross_answer: bad argument");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    CrossCuts cc;
+    for (int k = 0; k <= world; ++k) cc.c[k] = cuts_host[k];
+    const long long m = (long long) world * cap;
+    const unsigned int nb = (unsigned int) ((m + 255) / 256);
+    DevBuf &qs = ctx->tmp[0], &qi = ctx->tmp[1], &bd = ctx->tmp[2], &cv = ctx->tmp[3];
+    ME_CHECK(ctx, qs.ensure((size_t) m * sizeof(SPoint)));
+    ME_CHECK(ctx, qi.ensure((size_t) m * 4));
+    ME_CHECK(ctx, bd.ensure((size_t) m * 8));
+    ME_CHECK(ctx, cv.ensure((size_t) m * 16));
+    ME_CHECK(ctx, ctx->nn_far.ensure((size_t) m * 4 + 64));
+    ME_CHECK(ctx, ctx->red.ensure(64));
+    unsigned int *d_cnt = ctx->red.as<unsigned int>();
+    for (int dir = 0; dir < 2; ++dir) {
+        if (!((dir_mask >> dir) & 1)) {  // nobody else has an open query in this direction: every slot keeps its owner's bound
+            hipLaunchKernelGGL(k_cross_untouched, dim3(nb), dim3(256), 0, ctx->stream, gathered_device, world, cap, dir, d2_device);
+            continue;
+        }
+        Cloud &r = ctx->cloud[dir == 0 ? ME_SLOT_GT : ME_SLOT_EST];  // the queries of the map are answered from the ground truth held here
+        if (!r.uploaded) return ctx->fail(ME_ERR_STATE, "me_nn_cross_answer: reference cloud not uploaded");
+        hipLaunchKernelGGL(k_cross_expand, dim3(nb), dim3(256), 0, ctx->stream, gathered_device, world, cap, dir, own_rank, cc, halo,
+                           qs.as<SPoint>(), bd.as<double>(), cv.as<double>());
+        if (r.n > 0) {
+            ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));
+            TimerScope ts(ctx, "nn1");
+            unsigned long long *dbgp = ctx->timers_on ? ctx->nn1_dbg() : nullptr;
+            const dim3 g1((unsigned int) std::min<long long>((m + 7) / 8, 256 * 4 * kNn1Waves));
+            if (dbgp)
+                hipLaunchKernelGGL((k_nn1<true, true>), g1, dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream, qs.as<SPoint>(), 0LL, m, r.sp.as<SPoint>(),
+                                   r.n, r.oct, bd.as<double>(), qi.as<int>(), (const unsigned int *) nullptr, (const unsigned int *) nullptr, 1, dbgp,
+                                   ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4, cv.as<double>(), axis);
+            else
+                hipLaunchKernelGGL((k_nn1<true, false>), g1, dim3(kNn1Block), nn1_cache_bytes(r.oct), ctx->stream, qs.as<SPoint>(), 0LL, m, r.sp.as<SPoint>(),
+                                   r.n, r.oct, bd.as<double>(), qi.as<int>(), (const unsigned int *) nullptr, (const unsigned int *) nullptr, 1,
+                                   (unsigned long long *) nullptr, ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn1_far_cap(), d_cnt + 4, cv.as<double>(), axis);
+            hipLaunchKernelGGL(k_nn_far, dim3(kFarGrid), dim3(256), 0, ctx->stream, qs.as<SPoint>(), 0LL, r.sp.as<SPoint>(), r.oct, bd.as<double>(),
+                               qi.as<int>(), ctx->nn_far.as<unsigned int>(), d_cnt + 1, nn_far_leaf(), dbgp, cv.as<double>(), axis);
+        }
+        hipLaunchKernelGGL(k_cross_collect, dim3(nb), dim3(256), 0, ctx->stream, gathered_device, bd.as<double>(), world, cap, dir, own_rank, d2_device);
+    }
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ME_CHECK(ctx, hipGetLastError());
+    return ME_OK;
+}
+
+int nn_cross_patch(me_ctx *ctx, const double *d2_reduced_device, long long cap, int own_rank) {
+    if (!d2_reduced_device || cap < 1 || own_rank < 0) return ctx->fail(ME_ERR_ARG, "me_nn_cross_patch: bad argument");
+    Cloud &a = ctx->cloud[ME_SLOT_EST], &b = ctx->cloud[ME_SLOT_GT];
+    const long long c0 = std::min(a.n_unres, cap), c1 = std::min(b.n_unres, cap);
+    if (c0 + c1 == 0) return ME_OK;
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_cross_patch, dim3((unsigned int) ((c0 + c1 + 255) / 256)), dim3(256), 0, ctx->stream, a.nn_unres.as<unsigned int>(), c0,
+                       a.nn_d2.as<double>(), b.nn_unres.as<unsigned int>(), c1, b.nn_d2.as<double>(),
+                       d2_reduced_device + (long long) own_rank * (1 + 2 * cap), cap);
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
 int nn_patch(me_ctx *ctx, int qslot, const double *d2_device, long long count) {
     if (qslot < 0 || qslot > 1 || (count > 0 && !d2_device)) return ctx->fail(ME_ERR_ARG, "me_nn_patch: bad argument");
     Cloud &q = ctx->cloud[qslot];

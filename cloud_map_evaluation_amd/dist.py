@@ -572,15 +572,26 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     #     previous one, one host read instead of two.  A rank with more than `cap` open queries in a direction (far beyond what
     #     the 1 m halo leaves: outliers and non-overlapping regions) makes everybody fall back to a second, exactly sized gather. ---
     cap = _CROSS_CAP
-    mineq = [eng.nn_unresolved(q, with_d2=True) if cnt[i] else None for i, (q, r) in enumerate(dirs)]
-    wdev = next((t.device for t in mineq if t is not None), comm_device)
-    head = torch.zeros((1, 4), dtype=torch.float64, device=comm_device)
-    head[0] = torch.tensor([cnt[0], cnt[1], n_loc[0], n_loc[1]], dtype=torch.float64)
+    # Round 5: the message is written, answered and patched by THREE library calls (me_nn_cross_message / _answer / _patch) where the
+    # engine offers them — the ~60 small tensor operations of the round-4 form (two exports, padding, concatenation, per-direction
+    # slicing, staging copies, two searches and two patches) were most of this phase's 2 ms at 8 ranks.
+    lean = (not single) and hasattr(eng, "nn_cross_message") and cuts is not None and len(cuts) == world + 1
+    mineq = None
+    if lean:
+        msg, _ = eng.nn_cross_message(cap, n_loc[0], n_loc[1])
+        wdev = msg.device
+        msg = _comm(msg, comm_device)
+    else:
+        mineq = [eng.nn_unresolved(q, with_d2=True) if cnt[i] else None for i, (q, r) in enumerate(dirs)]
+        wdev = next((t.device for t in mineq if t is not None), comm_device)
+        head = torch.zeros((1, 4), dtype=torch.float64, device=comm_device)
+        head[0] = torch.tensor([cnt[0], cnt[1], n_loc[0], n_loc[1]], dtype=torch.float64)
     if single:
         table = head.to(torch.int64).cpu()
         allq = None
     else:
-        msg = torch.cat([head] + [_pad_rows(mineq[i][:cap] if mineq[i] is not None else None, cap, 4, comm_device, bound_pad=True) for i in range(2)])
+        if not lean:
+            msg = torch.cat([head] + [_pad_rows(mineq[i][:cap] if mineq[i] is not None else None, cap, 4, comm_device, bound_pad=True) for i in range(2)])
         parts = [torch.empty_like(msg) for _ in range(world)]
         dist.all_gather(parts, msg)
         allq = torch.stack(parts)                                 # (world, 1 + 2 cap, 4)
@@ -590,7 +601,14 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     n_cross = int(table[:, 0].sum() + table[:, 1].sum())
     if not single and n_cross > 0:
         cmax = [int(table[:, 0].max()), int(table[:, 1].max())]
-        if max(cmax) > cap:  # overflow: the exact-size gather of round 2, answered rank by rank
+        if lean and max(cmax) <= cap:
+            mask = (1 if int(table[:, 0].sum()) - cnt[0] > 0 else 0) | (2 if int(table[:, 1].sum()) - cnt[1] > 0 else 0)
+            d2 = _comm(eng.nn_cross_answer(allq, cap, rank, mask, int(slab[0]), cuts, float(slab[3])), comm_device)
+            dist.all_reduce(d2, op=dist.ReduceOp.MIN)
+            eng.nn_cross_patch(d2, cap, rank)
+        elif max(cmax) > cap:  # overflow: the exact-size gather of round 2, answered rank by rank
+            if mineq is None:
+                mineq = [eng.nn_unresolved(q, with_d2=True) if cnt[i] else None for i, (q, r) in enumerate(dirs)]
             msg = torch.cat([_pad_rows(mineq[i], cmax[i], 4, comm_device) for i in range(2)])
             parts = [torch.empty_like(msg) for _ in range(world)]
             dist.all_gather(parts, msg)
@@ -638,10 +656,11 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
                 ans = ans.view(world, cap)
                 ans[rank] = blk[rank, :, 3]
                 d2[:, base:base + cap] = ans
-        dist.all_reduce(d2, op=dist.ReduceOp.MIN)
-        for i, (q, r) in enumerate(dirs):
-            if cnt[i]:
-                eng.nn_patch(q, d2[rank, offs[i]:offs[i] + cnt[i]].contiguous().to(wdev))
+        if not (lean and max(cmax) <= cap):
+            dist.all_reduce(d2, op=dist.ReduceOp.MIN)
+            for i, (q, r) in enumerate(dirs):
+                if cnt[i]:
+                    eng.nn_patch(q, d2[rank, offs[i]:offs[i] + cnt[i]].contiguous().to(wdev))
     tr.mark("cross_rank_nn")
     parts = [eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_) for q, r in dirs]
     tr.mark("nn_sums")

@@ -442,6 +442,36 @@ class Engine:
         self._ck(self._L.me_slab_points(self._ctx, slot, _addr(orig), _addr(owned), n, C.byref(cnt)))
         return orig, owned.astype(bool)
 
+    # ---- the cross-rank 1-NN step on one fixed-capacity message (me_nn_cross_*) ----
+    def nn_cross_message(self, cap: int, n_loc_est: int, n_loc_gt: int):
+        """-> (message (1 + 2 cap, 4) cuda tensor, [open queries map -> gt, gt -> map])."""
+        import torch
+
+        msg = torch.empty((1 + 2 * cap, 4), dtype=torch.float64, device=torch.device("cuda", self.device))
+        counts = np.zeros(2, np.int64)
+        self._ck(self._L.me_nn_cross_message(self._ctx, msg.data_ptr(), int(cap), int(n_loc_est), int(n_loc_gt), _addr(counts)))
+        return msg, [int(counts[0]), int(counts[1])]
+
+    def nn_cross_answer(self, gathered, cap: int, own_rank: int, dir_mask: int, axis: int, cuts, halo: float):
+        """gathered (world, 1 + 2 cap, 4) cuda tensor -> d2 (world, 1 + 2 cap): the block the ranks min-reduce."""
+        import torch
+
+        g = gathered.to(torch.device("cuda", self.device), torch.float64).contiguous()
+        world = int(g.shape[0])
+        d2 = torch.zeros((world, 1 + 2 * cap), dtype=torch.float64, device=g.device)
+        c = np.ascontiguousarray(cuts, dtype=np.float64)
+        torch.cuda.current_stream(g.device).synchronize()
+        self._ck(self._L.me_nn_cross_answer(self._ctx, g.data_ptr(), world, int(cap), int(own_rank), int(dir_mask), int(axis), _addr(c), float(halo),
+                                            d2.data_ptr()))
+        return d2
+
+    def nn_cross_patch(self, d2_reduced, cap: int, own_rank: int):
+        import torch
+
+        d = d2_reduced.to(torch.device("cuda", self.device), torch.float64).contiguous()
+        torch.cuda.current_stream(d.device).synchronize()
+        self._ck(self._L.me_nn_cross_patch(self._ctx, d.data_ptr(), int(cap), int(own_rank)))
+
     def nn_patch(self, query_slot: int, d2):
         import torch
 

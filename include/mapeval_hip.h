@@ -133,6 +133,24 @@ int me_nn_points_bounded(me_ctx *ctx, int ref_slot, const double *xyz_device, in
  * (the computeChamferDistance / getDiffRegResult searches have no distance limit, map_eval.cpp:1398-1431, :1100-1110). */
 int me_nn_points_covered(me_ctx *ctx, int ref_slot, const double *xyz_device, int64_t m, double *d2_inout_device, int axis,
                          const double *covered_device);
+/* The cross-rank step above as three calls on ONE fixed-capacity message per rank (round 5) — what the ranks all-gather and min-reduce:
+ *   row 0                          [open queries map -> gt, open queries gt -> map, n_local_est, n_local_gt]
+ *   rows 1 .. capacity             the open queries of the last me_nn1(ME_SLOT_EST, ME_SLOT_GT): x, y, z, bound (best squared distance so far)
+ *   rows 1 + capacity .. 2 capacity  the same for me_nn1(ME_SLOT_GT, ME_SLOT_EST); unused rows carry the bound -1
+ * me_nn_cross_message  writes this rank's message (1 + 2 capacity rows x 4 doubles, device memory); counts[2] = its open queries per
+ *                      direction (more than `capacity`: the message carries the first `capacity`, the caller falls back to exactly
+ *                      sized messages through me_nn_unresolved / me_nn_points_covered / me_nn_patch).
+ * me_nn_cross_answer   the all-gathered messages of all ranks (world x (1 + 2 capacity) x 4) -> d2_device (world x (1 + 2 capacity)):
+ *                      every slot of another rank = min(its bound, the nearest squared distance among the points held here, looking only
+ *                      OUTSIDE the band [cuts[k] - halo, cuts[k + 1] + halo) of `axis` its owner k has searched completely — as
+ *                      me_nn_points_covered); own slots and padding keep their bound.  dir_mask: bit 0 / 1 = answer the map -> gt /
+ *                      gt -> map block (a direction nobody else has open queries in is copied through).  cuts: host, world + 1 values.
+ * me_nn_cross_patch    after the all-reduce MIN of d2_device over the ranks: this rank's block patches its open queries (me_nn_patch for
+ *                      both directions at once). */
+int me_nn_cross_message(me_ctx *ctx, double *msg_device, int64_t capacity, int64_t n_local_est, int64_t n_local_gt, int64_t counts[2]);
+int me_nn_cross_answer(me_ctx *ctx, const double *gathered_device, int world, int64_t capacity, int own_rank, int dir_mask, int axis,
+                       const double *cuts, double halo, double *d2_device);
+int me_nn_cross_patch(me_ctx *ctx, const double *d2_reduced_device, int64_t capacity, int own_rank);
 /* Overwrites the squared distances of the unresolved queries (same order as me_nn_unresolved returned them) with the
  * globally min-reduced values d2_device[count]. */
 int me_nn_patch(me_ctx *ctx, int query_slot, const double *d2_device, int64_t count);
