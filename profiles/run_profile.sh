@@ -10,6 +10,9 @@ export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --cpu-baseline off --no-h2d"
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --steps 3 --warmup 1 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+# the same with ONE lane (round 5): per-launch averages that are not stretched by the other lane's kernels — what
+# roofline.avg_launch_ms (HIP events, single-lane pass of bench.py) can be recomputed from
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -- $BENCH --steps 3 --warmup 1 --no-overlap --no-roofline > "$OUT/bench_single_lane_under_rocprof.json" 2> "$OUT/stats1.err"
 timeout 900 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- $BENCH --steps 1 --warmup 0 --no-roofline > /dev/null 2> "$OUT/pmc_fetch.err"
 timeout 900 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -- $BENCH --steps 1 --warmup 0 --no-roofline > /dev/null 2> "$OUT/pmc_write.err"
 timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES \
@@ -20,8 +23,9 @@ cd "$ROOT"
 # keep only what the summaries need (raw traces are large)
 find "$OUT" -name "*_kernel_trace.csv" -delete 2>/dev/null
 python profiles/summarize.py "$OUT" "$OUT/summary" "$TAG" | tail -40
+python profiles/summarize.py "$OUT" "$OUT/summary_single_lane" "$TAG" stats1 | tail -12
 # gpurun copies back at most 64 MiB: keep the summaries, drop the raw collections
 mkdir -p "$ROOT/gpurun_out/summary_$TAG"
-cp "$OUT"/summary_* "$OUT/bench_under_rocprof.json" "$ROOT/gpurun_out/summary_$TAG/" 2>/dev/null
+cp "$OUT"/summary_* "$OUT/bench_under_rocprof.json" "$OUT/bench_single_lane_under_rocprof.json" "$ROOT/gpurun_out/summary_$TAG/" 2>/dev/null
 for e in "$OUT"/*.err; do echo "== $e"; grep -v "simple_timer\|Opened result file" "$e" | tail -3 | cut -c1-300; done
 rm -rf "$OUT"

@@ -43,9 +43,9 @@ def kernel_source_sha(root="."):
     return h.hexdigest()[:12]
 
 
-def main(src, out, tag="r02"):
+def main(src, out, tag="r02", stats_dir="stats"):
     rows = defaultdict(lambda: [0, 0.0])
-    for f in glob.glob(f"{src}/stats/*/*_kernel_stats.csv"):
+    for f in glob.glob(f"{src}/{stats_dir}/*/*_kernel_stats.csv"):
         for r in csv.DictReader(open(f)):
             k = short(r["Name"])
             rows[k][0] += int(r["Calls"])
@@ -55,6 +55,9 @@ def main(src, out, tag="r02"):
         fo.write("kernel,calls,total_ms,avg_ms,percent\n")
         for k, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
             fo.write(f"{k},{c},{t/1e6:.3f},{t/1e6/c:.4f},{100*t/tot:.2f}\n")
+    if stats_dir != "stats":  # (a second kernel-trace pass, e.g. the single-lane one: the kernel table only)
+        print(open(out + "_kernel_stats.csv").read()[:1200])
+        return
     traffic = {}
     for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         acc = defaultdict(lambda: [0, 0.0])
@@ -111,4 +114,4 @@ def main(src, out, tag="r02"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "r02")
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "r02", sys.argv[4] if len(sys.argv) > 4 else "stats")

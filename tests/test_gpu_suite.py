@@ -188,3 +188,33 @@ def test_bench_size_step_through_the_one_call_matches_the_python_driver():
         assert a[k] == b[k], k
     for k in ("rmse", "fitness", "sigma", "mean", "number"):
         assert np.array_equal(a["est_gt"][k], b["est_gt"][k]) and np.array_equal(a["gt_est"][k], b["gt_est"][k])
+
+
+def test_an_index_is_complete_on_the_device_when_its_upload_returns():
+    """Round 5 regression (profiles/EXPERIMENTS.md "A cross-stream race"): me_upload_cloud used to return with the cell tables and the
+    octree still in flight on its stream; a second lane (me_twin) that started a kernel on ITS stream right away probed a half-built
+    hash table — silent with a persistent engine (the stale bytes were the previous, identical table), minutes of spinning in a
+    fresh context whose buffers hold recycled bytes.  Fresh engines, fresh host arrays, the hand-over as tight as Python allows:
+    the other lane's results must be the oracle's every time, and no iteration may take seconds."""
+    import time
+
+    import oracle
+    from cloud_map_evaluation_amd import synth
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, gt = synth.multisession_pair(1_500_000, 3, density=2500.0, seed=23)
+    est, gt = est.numpy(), gt.numpy()
+    o = oracle.mme(gt, 0.1, 5, mode=0)
+    for it in range(3):
+        a, b = est.copy(), gt.copy()
+        with Engine(0) as e:
+            lane = e.twin()
+            e.upload(0, a, cell_size=0.1)      # (dirties the allocator's recycled blocks for the next iteration)
+            t0 = time.perf_counter()
+            lane.upload(1, b, cell_size=0.1)   # the index is built on the twin's stream ...
+            m = e.mme(1, 0.1, 5)               # ... and read by a kernel on the primary stream at once
+            idx, d2 = e.nn1(0, 1)
+            dt = time.perf_counter() - t0
+        assert m[3] == o[3] and np.array_equal(m[2], o[2]), it
+        assert dt < 5.0, f"iteration {it} took {dt:.1f} s"
+        del a, b
