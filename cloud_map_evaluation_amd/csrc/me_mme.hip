@@ -104,51 +104,43 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
     // scalar registers for the whole kernel (computed in the kernel they lived in VGPRs and were spilled around the loop).
     // dbg: profiling switches (profiles/README.md) — 1: no candidate streaming at all, 2: pre-test only, nothing accepted.
     static_assert(TILE * 16 >= kGroupRows * 4, "the row masks of the cull alias the tile");
+    (void) fr;
+    (void) cell_h;
     const unsigned int vb = xcd_virtual_block(blockIdx.x, gridDim.x, xcd_chunk);
     const unsigned int loc = vb * blockDim.x + threadIdx.x;
     bool active = i_begin + (long long) loc < i_end;
     const int shift3 = 3 * g.shift;
     const int cell_lim = 1 << (kMortonBits - g.shift);
 
-    double qx = 0, qy = 0, qz = 0;
+    // The query point is NOT kept in registers across the kernel (round 5): a lane needs it when its round starts (origin, FP32
+    // thresholds, the self term) and, a few times in a thousand candidates, for the exact band test — it is loaded there (one coalesced
+    // 32-byte read per lane and round, an L2 hit after the first).  Six registers fewer alive in the candidate loop: round 5's first
+    // leader-origin version kept it and spilled 20 bytes per lane and round — 2.5 GB of scratch traffic per 50 M-query launch
+    // (rocprofv3 FETCH + WRITE 6.3 GB against 3.8 before; profiles/EXPERIMENTS.md).
     unsigned long long mycell = ~0ULL;
     if (active) {
         const long long i = i_begin + (long long) loc;
-        const SPoint q = sp[i];
-        qx = q.x;
-        qy = q.y;
-        qz = q.z;
         mycell = codes[i] >> shift3;
-        if (!slab_owned(slab, qx, qy, qz)) {
-            ent_s[i] = 0.0;
-            valid_s[i] = 0;
-            active = false;
+        if (slab.axis >= 0) {
+            const SPoint q = sp[i];
+            if (!slab_owned(slab, q.x, q.y, q.z)) {
+                ent_s[i] = 0.0;
+                valid_s[i] = 0;
+                active = false;
+            }
         }
     }
     bool done = !active;
 
     __shared__ int2 s_tab[4][kGroupTab + 1];
-#if ME_TUNE_MME_LEADER_ORIGIN
     // One 48-byte record per staged candidate — the FP32 record, (ux, uy), uz — read back with a VECTOR-register address and
     // immediate offsets (round 5): with three arrays indexed by the (scalar) loop counter the compiler rebuilt every LDS address
     // with a v_mov from a scalar register, three vector instructions per accepted candidate that did no arithmetic.
     __shared__ MmeTileRec s_rec[4][TILE];
-#else
-    __shared__ float4 s_tf[4][TILE];     // FP32 records of the staged run (the cull's row masks while the table is built)
-    __shared__ double2 s_txy[4][TILE];   // its fp64 coordinates: (x, y) as one 16-byte record, z apart — two LDS reads per
-    __shared__ double s_tz[4][TILE];     // accepted candidate instead of three (a ds_read_b64 costs a SIMD 8.7 issue cycles)
-#endif
     const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));  // scalar: the wave's LDS bases stay out of VGPRs
     int2 *tab = s_tab[wv];
-#if ME_TUNE_MME_LEADER_ORIGIN
     MmeTileRec *trec = s_rec[wv];
-    float4 *tf = reinterpret_cast<float4 *>(trec);  // (the cull's row masks alias the tile while the table is built)
     const unsigned int trec_lds = (unsigned int) (size_t) trec;  // LDS byte address of the wave's tile (flat -> local: the low 32 bits)
-#else
-    float4 *tf = s_tf[wv];
-    double2 *txy = s_txy[wv];
-    double *tdz = s_tz[wv];
-#endif
     const int lane = threadIdx.x & 63;
 
     unsigned int wave_pairs = 0;  // (scalar: instrumentation only)
@@ -161,13 +153,11 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
 #endif
     while (__ballot(!done)) {
         GroupBox bx;
-        int nk = 0;
+        int nk = 0, leader = 0;
         const int cx = (int) compact21(mycell), cy = (int) compact21(mycell >> 1), cz = (int) compact21(mycell >> 2);
-#if ME_TUNE_MME_LEADER_ORIGIN
-        int leader = 0;
-        const bool in = wave_group_table<1, true>(!done, cx, cy, cz, g, cell_lim, lane, tab, bx, &nk,
-                                                  reinterpret_cast<unsigned int *>(tf), nullptr, nullptr, nullptr, &leader);
-        // Round origin o = the group LEADER'S POINT (round 5), wave-uniform in scalar registers.  Both the FP32 records and the fp64
+        const bool in = wave_group_table<1, true>(!done, cx, cy, cz, g, cell_lim, lane, tab, bx, &nk, reinterpret_cast<unsigned int *>(trec),
+                                                  nullptr, nullptr, nullptr, &leader);
+        // Round origin o = the group LEADER'S POINT, wave-uniform in scalar registers.  Both the FP32 record and the fp64
         // coordinates of a staged candidate are taken relative to it ONCE, by the lane that loads the candidate: u = p - o.  The
         // covariance is translation-invariant, so a lane accumulates sum(u), sum(u u^T) of what it accepts as they come out of the
         // tile — 3 v_add_f64 + 6 v_fma_f64 per accepted candidate instead of 12 fp64 instructions (no per-lane p - q) — and moves
@@ -175,29 +165,36 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
         // stencil, + the offset inside a cell), well inside the 7-cell box the FP32 error bound E was derived for; the cancellation
         // in S2 - S1 S1^T / k costs <= |u|^2 / var ~ 10^2..10^3 of fp64's 10^16: entropies move by ~1e-13.  An exactly degenerate
         // neighbourhood that is axis-aligned (a floor z = const, a line, duplicates of the leader) still sums exact zeros.
+        double qx = 0, qy = 0, qz = 0;
+        if (!done) {
+            unsigned int loc_q = loc;
+            asm volatile("" : "+v"(loc_q));  // (the 64-bit index is rebuilt here, not carried across the rounds)
+            const SPoint q = sp[i_begin + (long long) loc_q];
+            qx = q.x;
+            qy = q.y;
+            qz = q.z;
+        }
         const double ox = uniform_f64(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(qx), leader), __builtin_amdgcn_readlane(__double2loint(qx), leader)));
         const double oy = uniform_f64(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(qy), leader), __builtin_amdgcn_readlane(__double2loint(qy), leader)));
         const double oz = uniform_f64(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(qz), leader), __builtin_amdgcn_readlane(__double2loint(qz), leader)));
-#else
-        const bool in = wave_group_table<1, true>(!done, cx, cy, cz, g, cell_lim, lane, tab, bx, &nk,
-                                                  reinterpret_cast<unsigned int *>(tf));
-        // wave-uniform, and kept in scalar registers (there is no scalar fp64 arithmetic: computed once per round on the
-        // vector unit, then moved over)
-        const double ox = uniform_f64(fr.ox + (double) bx.x0 * cell_h), oy = uniform_f64(fr.oy + (double) bx.y0 * cell_h),
-                     oz = uniform_f64(fr.oz + (double) bx.z0 * cell_h);
-#endif
-        const float ax = (float) (-2.0 * (qx - ox)), ay = (float) (-2.0 * (qy - oy)), az = (float) (-2.0 * (qz - oz));
+        const double rx = qx - ox, ry = qy - oy, rz = qz - oz;  // the lane's own u (the value its staging lane will store for it)
+        const float ax = (float) (-2.0 * rx), ay = (float) (-2.0 * ry), az = (float) (-2.0 * rz);
         const float s = fmaf(az, az, fmaf(ay, ay, ax * ax));
         // (the group predicate rides on the thresholds: lanes outside the group accept nothing)
         const float t_hi = (in && dbg != 2) ? fmaf(-0.25f, s, thr_hi) : -INFINITY;
         const float t_lo = (in && dbg != 2) ? fmaf(-0.25f, s, thr_lo) : -INFINITY;
-        int k = 0;
-        double s1x = 0, s1y = 0, s1z = 0;
-        double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+        // The query itself is one of the candidates (d2 = 0 < r^2: always accepted, the element the reference erases,
+        // map_eval.cpp:1672-1673): the sums START at minus its contribution, so that nothing of q is needed after this point.
+        int k = -1;
+        double s1x = -rx, s1y = -ry, s1z = -rz;
+        double sxx = -(rx * rx), sxy = -(rx * ry), sxz = -(rx * rz), syy = -(ry * ry), syz = -(ry * rz), szz = -(rz * rz);
+        if (!in || dbg == 2) {  // (a lane outside the group accepts nothing, its own point included)
+            k = 0;
+            s1x = s1y = s1z = sxx = sxy = sxz = syy = syz = szz = 0.0;
+        }
 #ifdef ME_MME_STATS
         int st_cand = 0;
 #endif
-#if ME_TUNE_MME_LEADER_ORIGIN
         auto test = [&](const float4 &c, unsigned int ra, int gj) {  // ra: LDS address of the tile record, gj: the candidate's position in `sp`
             const float u = fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
             const bool hi = u < t_hi;
@@ -207,8 +204,13 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 // (both compares land in scalar register pairs: the band test is scalar work, no VALU instruction)
                 if (__builtin_expect(mh != __ballot(acc), 0)) {  // a lane in the band: its exact test decides
                     asm volatile("; band: exact test" ::: "memory");     // (keeps the compiler from evaluating it always)
-                    const SPoint pe = sp[gj];  // (the tile holds u = p - o: the exact test needs p itself; a few candidates in a thousand)
-                    const double ex = pe.x - qx, ey = pe.y - qy, ez = pe.z - qz;
+                    // (the tile holds u = p - o, the registers no q: the exact test takes both points from memory — a few
+                    // candidates in a thousand)
+                    unsigned int loc_b = loc;
+                    asm volatile("" : "+v"(loc_b));
+                    const SPoint qe = sp[i_begin + (long long) loc_b];
+                    const SPoint pe = sp[gj];
+                    const double ex = pe.x - qe.x, ey = pe.y - qe.y, ez = pe.z - qe.z;
                     const double d2 = (ex * ex + ey * ey) + ez * ez;
                     acc = acc || (hi && d2 < r2);                        // strict, nanoflann RadiusResultSet [upstream]
                 }
@@ -228,47 +230,6 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 }
             }
         };
-#else
-        auto test = [&](const float4 &c, int j, int gj) {  // j: slot in the tile, gj: the candidate's position in `sp`
-            const float u = fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
-            const bool hi = u < t_hi;
-            const unsigned long long mh = __ballot(hi);
-            if (mh) {  // some lane may hold this candidate inside its radius
-                bool acc = u < t_lo;
-                // (both compares land in scalar register pairs: the band test is scalar work, no VALU instruction)
-                if (__builtin_expect(mh != __ballot(acc), 0)) {  // a lane in the band: its exact test decides
-                    asm volatile("; band: exact test" ::: "memory");     // (keeps the compiler from evaluating it always)
-#if ME_TUNE_MME_LEADER_ORIGIN
-                    const SPoint pe = sp[gj];  // (the tile holds u = p - o: the exact test needs p itself; a few candidates in a thousand)
-                    const double ex = pe.x - qx, ey = pe.y - qy, ez = pe.z - qz;
-#else
-                    const double2 exy = txy[j];
-                    const double ex = exy.x - qx, ey = exy.y - qy, ez = tdz[j] - qz;
-#endif
-                    const double d2 = (ex * ex + ey * ey) + ez * ez;
-                    acc = acc || (hi && d2 < r2);                        // strict, nanoflann RadiusResultSet [upstream]
-                }
-                if (acc) {
-                    const double2 pxy = txy[j];
-#if ME_TUNE_MME_LEADER_ORIGIN
-                    const double dx = pxy.x, dy = pxy.y, dz = tdz[j];    // u = p - o, staged
-#else
-                    const double dx = pxy.x - qx, dy = pxy.y - qy, dz = tdz[j] - qz;
-#endif
-                    ++k;
-                    s1x += dx;
-                    s1y += dy;
-                    s1z += dz;
-                    sxx = fma(dx, dx, sxx);
-                    sxy = fma(dx, dy, sxy);
-                    sxz = fma(dx, dz, sxz);
-                    syy = fma(dy, dy, syy);
-                    syz = fma(dy, dz, syz);
-                    szz = fma(dz, dz, szz);
-                }
-            }
-        };
-#endif
         if (dbg != 1) wave_for_each_run(tab, nk, lane, [&](int cs, int ce, int) {
             for (int base = cs; base < ce; base += TILE) {
                 const int n = min(TILE, ce - base);
@@ -281,22 +242,15 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                     const float fx = (float) px, fy = (float) py, fz = (float) pz;
                     // |p'|^2 of the ROUNDED coordinates (the error bound is stated for them), rounded once
                     const double w = ((double) fx * (double) fx + (double) fy * (double) fy) + (double) fz * (double) fz;
-#if ME_TUNE_MME_LEADER_ORIGIN
                     trec[lane].f = make_float4(fx, fy, fz, (float) w);
                     trec[lane].xy = make_double2(px, py);
                     trec[lane].z = pz;
-#else
-                    tf[lane] = make_float4(fx, fy, fz, (float) w);
-                    txy[lane] = make_double2(p.x, p.y);
-                    tdz[lane] = p.z;
-#endif
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 int j = 0;
                 // (two records in flight, not four: eight registers fewer is what keeps this kernel at 64 VGPRs without
                 // spilling inside the run loop — the spills of the four-deep version were 3.2x the kernel's useful HBM traffic)
-#if ME_TUNE_MME_LEADER_ORIGIN
                 unsigned int ra = trec_lds;
                 asm volatile("" : "+v"(ra));  // the record address lives in a VECTOR register: reads below use it + an immediate
                 for (; j + 2 <= n; j += 2) {
@@ -312,26 +266,13 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                     ra += (unsigned int) sizeof(MmeTileRec);
                     asm volatile("" : "+v"(ra));
                 }
-#else
-#if ME_MME_DEPTH == 2
-                for (; j + 2 <= n; j += 2) {
-                    const float4 c0 = tf[j], c1 = tf[j + 1];
-                    test(c0, j, base + j);
-                    test(c1, j + 1, base + j + 1);
-                }
-#endif
-                for (; j < n; ++j) {
-                    const float4 c0 = tf[j];
-                    test(c0, j, base + j);
-                }
-#endif
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
             }
         });
 #ifdef ME_MME_STATS
         {
-            int ka = in ? k - 1 : 0;
+            int ka = in ? k : 0;
             for (int o = 32; o > 0; o >>= 1) ka += __shfl_xor(ka, o, 64);
             const int served = __popcll(__ballot(in));
             if (lane == 0) {
@@ -349,27 +290,13 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
         }
 #endif
         if (part_pairs) {  // (wave-uniform branch)
-            int ka = in ? k - 1 : 0;
+            int ka = in ? k : 0;
             for (int o = 32; o > 0; o >>= 1) ka += __shfl_xor(ka, o, 64);
             wave_pairs += (unsigned int) __builtin_amdgcn_readfirstlane(ka);
         }
         if (in) {
             done = true;
-            const int kk = k - 1;  // drop the query itself (map_eval.cpp:1672-1673)
-#if ME_TUNE_MME_LEADER_ORIGIN
-            {   // ... whose u = q - o (the very value its staging lane stored) is in the sums: take it out
-                const double rx = qx - ox, ry = qy - oy, rz = qz - oz;
-                s1x -= rx;
-                s1y -= ry;
-                s1z -= rz;
-                sxx = fma(-rx, rx, sxx);
-                sxy = fma(-rx, ry, sxy);
-                sxz = fma(-rx, rz, sxz);
-                syy = fma(-ry, ry, syy);
-                syz = fma(-ry, rz, syz);
-                szz = fma(-rz, rz, szz);
-            }
-#endif
+            const int kk = k;  // neighbours without the query itself (map_eval.cpp:1672-1673): k started at -1
             if (kk >= min_k) {     // (:1675 k >= 10, :1458 k >= 5)
                 const double inv_k = 1.0 / (double) kk, inv_km1 = 1.0 / (double) (kk - 1);
                 const double cxx = (sxx - s1x * s1x * inv_k) * inv_km1;
