@@ -380,17 +380,50 @@ int MapEval::processDist(double t_loaded) {
         DIST_TRY(me_nn_unresolved(ctx_, dirs[d][0], nullptr, nullptr, 0, &cnt[d]));
     }
     {   // cross-rank step: open queries of both directions in one all-gather, their answers in one MIN-reduce
+        // Round 5: ONE fixed-capacity message per rank, written / answered / patched by three library calls (me_nn_cross_message,
+        // me_nn_cross_answer, me_nn_cross_patch); the open-query counts of all ranks ride on the messages' header rows (no separate
+        // all-reduce), the bands every owner has searched are expanded on the device from the cuts.  A rank with more open queries
+        // than the capacity makes everybody take the exactly sized form below (round 3).
+        constexpr int64_t kCrossCap = 4096;
+        const size_t rows = 1 + 2 * (size_t) kCrossCap;
         std::vector<double> table((size_t) world * 2, 0.0);
-        table[(size_t) rank * 2] = (double) cnt[0];
-        table[(size_t) rank * 2 + 1] = (double) cnt[1];
-        if (allReduceHost(table, false) != 0) return -1;
+        bool lean_done = false;
+        if (world > 1) {
+            medist::DevMem &msg = pool_[0], &all = pool_[1], &ans = pool_[2];  // (the exchange is over: its buffers are free)
+            if (!msg.ensure(rows * 32) || !all.ensure(rows * 32 * (size_t) world) || !ans.ensure(rows * 8 * (size_t) world))
+                return fail("device buffers of the cross-rank step");
+            int64_t c2[2] = {0, 0};
+            DIST_TRY(me_nn_cross_message(ctx_, msg.as<double>(), kCrossCap, 0, 0, c2));
+            COMM_TRY(comm_->all_gather(msg.p, all.p, rows * 32));
+            for (int k = 0; k < world; ++k) {
+                double head[4];
+                if (hipMemcpy(head, all.as<double>() + (size_t) k * rows * 4, sizeof head, hipMemcpyDeviceToHost) != hipSuccess) return fail("hipMemcpy");
+                table[(size_t) k * 2] = head[0];
+                table[(size_t) k * 2 + 1] = head[1];
+            }
+            int64_t cmax_all = 0, others[2] = {0, 0};
+            for (int k = 0; k < world; ++k)
+                for (int d = 0; d < 2; ++d) {
+                    cmax_all = std::max<int64_t>(cmax_all, (int64_t) table[(size_t) k * 2 + d]);
+                    if (k != rank) others[d] += (int64_t) table[(size_t) k * 2 + d];
+                }
+            if (cmax_all <= kCrossCap) {
+                if (cmax_all > 0) {
+                    const int mask = (others[0] > 0 ? 1 : 0) | (others[1] > 0 ? 2 : 0);
+                    DIST_TRY(me_nn_cross_answer(ctx_, all.as<double>(), world, kCrossCap, rank, mask, axis, cuts.data(), halo, ans.as<double>()));
+                    COMM_TRY(comm_->all_reduce_min_f64(ans.as<double>(), rows * (size_t) world));
+                    DIST_TRY(me_nn_cross_patch(ctx_, ans.as<double>(), kCrossCap, rank));
+                }
+                lean_done = true;
+            }
+        }
         int64_t cmax[2] = {0, 0}, total = 0;
         for (int k = 0; k < world; ++k)
             for (int d = 0; d < 2; ++d) {
                 cmax[d] = std::max<int64_t>(cmax[d], (int64_t) table[(size_t) k * 2 + d]);
                 total += (int64_t) table[(size_t) k * 2 + d];
             }
-        if (total > 0 && world > 1) {
+        if (total > 0 && world > 1 && !lean_done) {
             // message of a rank: [X0 (cmax0 x 3) | D0 (cmax0) | X1 (cmax1 x 3) | D1 (cmax1)] doubles
             const size_t msg_len = (size_t) (cmax[0] + cmax[1]) * 4;
             const size_t off_x[2] = {0, (size_t) cmax[0] * 4}, off_d[2] = {(size_t) cmax[0] * 3, (size_t) cmax[0] * 4 + (size_t) cmax[1] * 3};

@@ -345,3 +345,58 @@ def test_nn_points_covered_gives_the_bounded_answer(axis):
     np.testing.assert_array_equal(got, expect)
     np.testing.assert_array_equal(got_none, expect)
     assert (neg == -1.0).all()
+
+
+def test_cross_rank_calls_reproduce_the_whole_cloud_search():
+    """me_nn_cross_message / _answer / _patch (round 5): two contexts in one process play the two ranks of a slab job; the messages are
+    'all-gathered' by stacking them, the answer blocks 'min-reduced' with torch.minimum.  After the patch, every owned query's squared
+    distance must be the WHOLE-cloud oracle's, bit for bit, in both directions — and equal to what the piecewise path
+    (me_nn_unresolved / me_nn_points_covered / me_nn_patch) gives."""
+    import oracle
+    import torch
+
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, gt = _scene(160_000)
+    rng = np.random.default_rng(9)
+    est = np.concatenate([est, est[rng.choice(len(est), 1500, replace=False)] + rng.normal(0, 2.5, (1500, 3))])  # far outliers: open queries
+    axis, halo, cap = 0, 1.0, 4096
+    cut = float(np.median(gt[:, axis]))
+    cuts = [-np.inf, cut, np.inf]
+    want = {0: oracle.nn1(gt, est)[1], 1: oracle.nn1(est, gt)[1]}  # query slot -> exact squared distances over the whole reference
+    engs = [Engine(0), Engine(0)]
+    try:
+        msgs, counts = [], []
+        for r, e in enumerate(engs):
+            e.set_slab(axis, cuts[r], cuts[r + 1], halo)
+            e.upload(0, est, cell_size=0.1)
+            e.upload(1, gt, cell_size=0.1)
+            e.nn1(0, 1, fetch=False)
+            e.nn1(1, 0, fetch=False)
+            c = [e.nn_unresolved_count(0), e.nn_unresolved_count(1)]
+            m, c2 = e.nn_cross_message(cap, e.size(0), e.size(1))
+            assert c2 == c and m.shape == (1 + 2 * cap, 4)
+            head = m[0].cpu().numpy()
+            assert list(head[:2]) == c and (m[1 + c[0]:1 + cap, 3] == -1.0).all() and (m[1 + cap + c[1]:, 3] == -1.0).all()
+            msgs.append(m)
+            counts.append(c)
+        assert sum(c[0] for c in counts) > 100, "the scene was meant to leave open queries"
+        gathered = torch.stack(msgs)                                   # the all-gather
+        blocks = [e.nn_cross_answer(gathered, cap, r, 3, axis, cuts, halo) for r, e in enumerate(engs)]
+        # own slots keep the owner's bound, padding stays -1
+        for r in range(2):
+            assert torch.equal(blocks[r][r, 1:], gathered[r, 1:, 3])
+        reduced = torch.minimum(blocks[0], blocks[1])                  # the all-reduce MIN
+        for r, e in enumerate(engs):
+            e.nn_cross_patch(reduced, cap, r)
+            for q in (0, 1):
+                _, d2 = e.nn_fetch(q)
+                orig, owned = e.slab_points(q)
+                sel = owned.astype(bool)
+                np.testing.assert_array_equal(d2[sel], want[q][orig[sel]])
+        # dir_mask 0: a direction nobody else has open queries in is copied through
+        thru = engs[0].nn_cross_answer(gathered, cap, 0, 0, axis, cuts, halo)
+        assert torch.equal(thru[:, 1:], gathered[:, 1:, 3])
+    finally:
+        for e in engs:
+            e.close()
