@@ -415,43 +415,40 @@ __global__ void k_cell_scatter(const unsigned long long *__restrict__ codes, con
     }
 }
 
-__global__ void k_hash_insert(const unsigned long long *__restrict__ cell_code, long long n_cells,
-                              unsigned long long *__restrict__ hkeys, unsigned int *__restrict__ hvals,
-                              unsigned int mask) {
-    const long long c = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cells) return;
-    const unsigned long long key = cell_code[c];
-    unsigned int s = (unsigned int) hash_u64(key) & mask;
-    for (;;) {
-        const unsigned long long prev = atomicCAS(&hkeys[s], kEmptyKey, key);
-        if (prev == kEmptyKey || prev == key) {
-            hvals[s] = (unsigned int) c;
-            return;
-        }
-        s = (s + 1) & mask;
-    }
-}
-
-__global__ void k_set_u32(unsigned int *p, long long i, unsigned int v) { p[i] = v; }
-
-// highest differing Morton level between neighbours of the sorted code array: hist[k] += 1 when codes[i-1] and
-// codes[i] first differ at level k (bits 3k..3k+2).  #occupied cells at level k = 1 + sum_{j >= k} hist[j].
-__global__ void __launch_bounds__(256) k_level_hist(const unsigned long long *__restrict__ codes, long long n,
-                                                    unsigned long long *__restrict__ hist) {
+// (the level histogram — hist[k] += 1 when codes[i-1] and codes[i] first differ at level k (bits 3k..3k+2); #occupied cells at level k =
+//  1 + sum_{j >= k} hist[j] — comes from the per-block rows of k_level_hist_rows below)
+// ---- cell tables in two passes over the codes (round 5) ----------------------------------------------------------------------------
+// Through round 4 a cell table cost a rank scan of per-point start flags (rocPRIM: codes read, 4 bytes per point written), a scatter
+// that read codes and ranks again, and the hash inserts as a third kernel over the cell codes — after the level histogram had
+// already streamed the same codes once.  But the histogram knows everything the scan computed: a point starts a cell of level L
+// exactly when the highest level at which its code differs from its predecessor's is >= L, so a block's row of the level histogram
+// gives the number of cells of ANY level that start inside the block.  Now:
+//   k_level_hist_rows    per block of kCellChunk sorted points: its row of the level histogram — the one pass that was the histogram's;
+//   k_block_offsets      one block: for a level, the exclusive scan over the blocks' cell counts (and, the first time, the rows added up);
+//   k_cell_fill          the chunks again: start flags ranked in order with ballots (4 wave counts through LDS per 256 points), the
+//                        cell's code, its start and its hash entry written by the lane that found it.
+// Per table 8 bytes per point read instead of 8 read + 4 written (scan) and 12 read (scatter), two launches fewer, the same table entry
+// for entry (cells in sorted order).  Short blocks (2048 points each), no lookback and no persistent grid: a first version with 2048
+// long-running blocks was 0.9 ms per step faster by its own timer and 0.5 ms SLOWER in the two-lane step — it held every wave slot of
+// the chip for its whole duration and the other lane's kernels queued behind it (the round-4 lesson, again).
+constexpr int kCellChunk = 2048;   // sorted points per block
+constexpr int kHistLevels = 24;    // histogram rows hold levels 0 .. 23 (kMortonBits = 21)
+static_assert(kHistLevels > kMortonBits, "a histogram row holds every Morton level");
+__global__ void __launch_bounds__(256)
+k_level_hist_rows(const unsigned long long *__restrict__ codes, long long n, unsigned int *__restrict__ block_hist) {
     __shared__ unsigned int sh[32];
     if (threadIdx.x < 32) sh[threadIdx.x] = 0;
     __syncthreads();
-    // (wave-aggregated: neighbours differ at two or three distinct levels per wavefront, almost all at the lowest ones — one
-    // LDS atomic per distinct level instead of 64 colliding on the same three counters)
-    for (long long i0 = (long long) blockIdx.x * blockDim.x + 1; i0 < n; i0 += (long long) gridDim.x * blockDim.x) {
-        const long long i = i0 + threadIdx.x;
+    const long long i0 = (long long) blockIdx.x * kCellChunk, i1 = i0 + kCellChunk < n ? i0 + kCellChunk : n;
+    for (long long base = i0; base < i1; base += 256) {
+        const long long i = base + threadIdx.x;
         int lv = -1;
-        if (i < n) {
+        if (i < i1 && i > 0) {
             const unsigned long long x = codes[i] ^ codes[i - 1];
             if (x) lv = (63 - __clzll((long long) x)) / 3;
         }
         unsigned long long todo = __ballot(lv >= 0);
-        while (todo) {
+        while (todo) {  // (wave-aggregated: neighbours differ at two or three distinct levels per wavefront)
             const int l0 = __builtin_amdgcn_readlane(lv, __ffsll((long long) todo) - 1);
             const unsigned long long same = __ballot(lv == l0);
             if ((threadIdx.x & 63) == 0) atomicAdd(&sh[l0], (unsigned int) __popcll(same));
@@ -459,31 +456,136 @@ __global__ void __launch_bounds__(256) k_level_hist(const unsigned long long *__
         }
     }
     __syncthreads();
-    if (threadIdx.x < 32 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long) sh[threadIdx.x]);
+    if (threadIdx.x < kHistLevels) block_hist[(long long) blockIdx.x * kHistLevels + threadIdx.x] = sh[threadIdx.x];
+}
+
+// one block of 1024 threads; thread t owns the blocks [t * per, (t + 1) * per).  off[b] = cells of level `level` that start before
+// block b (off[nb] = all of them); with HIST the rows are also added up into hist[0 .. 32)
+template <bool HIST>
+__global__ void __launch_bounds__(1024)
+k_block_offsets(const unsigned int *__restrict__ block_hist, int nb, int per, int level, unsigned int *__restrict__ off,
+                unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int s_tot[1024];
+    __shared__ unsigned long long s_hist[kHistLevels];
+    const int t = threadIdx.x, b0 = t * per, b1 = min(nb, b0 + per);
+    if (HIST && t < kHistLevels) s_hist[t] = 0ULL;
+    unsigned int sum = 0;
+    unsigned int h[kHistLevels];
+    if (HIST) {
+#pragma unroll
+        for (int k = 0; k < kHistLevels; ++k) h[k] = 0u;
+    }
+    for (int b = b0; b < b1; ++b) {
+        const unsigned int *row = block_hist + (long long) b * kHistLevels;
+        if (b == 0) ++sum;  // the first point starts a cell of every level
+        if (HIST) {
+#pragma unroll
+            for (int k = 0; k < kHistLevels; ++k) {
+                const unsigned int r = row[k];
+                h[k] += r;
+                if (k >= level) sum += r;
+            }
+        } else {
+            for (int k = level; k < kHistLevels; ++k) sum += row[k];
+        }
+    }
+    s_tot[t] = sum;
+    __syncthreads();
+    if (HIST) {
+#pragma unroll
+        for (int k = 0; k < kHistLevels; ++k)
+            if (h[k]) atomicAdd(&s_hist[k], (unsigned long long) h[k]);
+    }
+    // inclusive scan of the 1024 thread totals (Hillis-Steele in LDS)
+    unsigned int v = sum;
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned int o = t >= d ? s_tot[t - d] : 0u;
+        __syncthreads();
+        v += o;
+        s_tot[t] = v;
+        __syncthreads();
+    }
+    unsigned int run = v - sum;  // exclusive
+    for (int b = b0; b < b1; ++b) {
+        off[b] = run;
+        const unsigned int *row = block_hist + (long long) b * kHistLevels;
+        if (b == 0) ++run;
+        for (int k = level; k < kHistLevels; ++k) run += row[k];
+    }
+    if (t == 1023) off[nb] = v;
+    if (HIST) {
+        __syncthreads();
+        if (t < 32) hist[t] = t < kHistLevels ? s_hist[t] : 0ULL;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_cell_fill(const unsigned long long *__restrict__ codes, long long n, int shift3, const unsigned int *__restrict__ block_off,
+            long long n_cells, unsigned long long *__restrict__ cell_code, unsigned int *__restrict__ cell_start,
+            unsigned long long *__restrict__ hkeys, unsigned int *__restrict__ hvals, unsigned int hmask) {
+    __shared__ unsigned int s_w[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long i0 = (long long) blockIdx.x * kCellChunk, i1 = i0 + kCellChunk < n ? i0 + kCellChunk : n;
+    unsigned int running = block_off[blockIdx.x];
+    for (long long base = i0; base < i1; base += 256) {
+        const long long i = base + threadIdx.x;
+        bool start = false;
+        unsigned long long c = 0;
+        if (i < i1) {
+            c = codes[i] >> shift3;
+            start = i == 0 || c != (codes[i - 1] >> shift3);
+        }
+        const unsigned long long m = __ballot(start);
+        if (lane == 0) s_w[wv] = (unsigned int) __popcll(m);
+        __syncthreads();
+        unsigned int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned int x = s_w[w];
+            if (w < wv) before += x;
+            total += x;
+        }
+        if (start) {
+            const unsigned int pos = running + before + (unsigned int) __popcll(m & ((1ULL << lane) - 1ULL));
+            cell_code[pos] = c;
+            cell_start[pos] = (unsigned int) i;
+            unsigned int s = (unsigned int) hash_u64(c) & hmask;  // (open addressing, linear probe: first free slot)
+            for (;;) {
+                const unsigned long long prev = atomicCAS(&hkeys[s], kEmptyKey, c);
+                if (prev == kEmptyKey || prev == c) {
+                    hvals[s] = pos;
+                    break;
+                }
+                s = (s + 1) & hmask;
+            }
+        }
+        running += total;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cell_start[n_cells] = (unsigned int) n;
 }
 
 static inline unsigned int grid_for(long long n, int block = 256) { return (unsigned int) ((n + block - 1) / block); }
 
-// occupied cells of Morton level `shift` (unique code >> 3*shift, run starts) + open-addressing hash
-static int build_grid_table(me_ctx *ctx, Cloud &c, int shift, GridTable &t, GridView &g) {
+// occupied cells of Morton level `shift` (unique code >> 3*shift, run starts) + open-addressing hash:
+// a cell table of the sorted points from the blocks' histogram rows (see the kernels above); `offsets_ready`: off already holds this level's scan
+static int build_grid_table_counted(me_ctx *ctx, Cloud &c, int shift, GridTable &t, GridView &g, int nblk, const unsigned int *block_hist,
+                                    unsigned int *block_off, bool offsets_ready) {
     const long long n = c.n;
-    const int shift3 = 3 * shift;
-    DevBuf &pos = ctx->tmp[1];
-    ME_CHECK(ctx, pos.ensure((size_t) n * 4));
-    ME_TRY(cell_start_ranks(ctx, c.codes.as<unsigned long long>(), n, shift3, pos.as<unsigned int>()));
+    if (!offsets_ready)
+        hipLaunchKernelGGL(k_block_offsets<false>, dim3(1), dim3(1024), 0, ctx->stream, block_hist, nblk, (nblk + 1023) / 1024, shift, block_off,
+                           (unsigned long long *) nullptr);
     const long long n_cells = c.level_unique[shift];
     ME_CHECK(ctx, t.cell_code.ensure((size_t) n_cells * 8));
     ME_CHECK(ctx, t.cell_start.ensure((size_t) (n_cells + 1) * 4));
-    hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(),
-                       pos.as<unsigned int>(), n, shift3, t.cell_code.as<unsigned long long>(), t.cell_start.as<unsigned int>());
-    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, ctx->stream, t.cell_start.as<unsigned int>(), n_cells, (unsigned int) n);
     unsigned long long hsize = 64;
     while (hsize < 2ULL * (unsigned long long) n_cells) hsize <<= 1;
     ME_CHECK(ctx, t.hkeys.ensure((size_t) hsize * 8));
     ME_CHECK(ctx, t.hvals.ensure((size_t) hsize * 4));
     ME_CHECK(ctx, hipMemsetAsync(t.hkeys.p, 0xFF, (size_t) hsize * 8, ctx->stream));
-    hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n_cells)), dim3(256), 0, ctx->stream, t.cell_code.as<unsigned long long>(),
-                       n_cells, t.hkeys.as<unsigned long long>(), t.hvals.as<unsigned int>(), (unsigned int) (hsize - 1));
+    hipLaunchKernelGGL(k_cell_fill, dim3((unsigned int) nblk), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(), n, 3 * shift,
+                       block_off, n_cells, t.cell_code.as<unsigned long long>(), t.cell_start.as<unsigned int>(), t.hkeys.as<unsigned long long>(),
+                       t.hvals.as<unsigned int>(), (unsigned int) (hsize - 1));
     t.shift = shift;
     g.cell_code = t.cell_code.as<unsigned long long>();
     g.cell_start = t.cell_start.as<unsigned int>();
@@ -555,7 +657,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
         ME_CHECK(ctx, ctx->red.ensure((size_t) nb * 6 * sizeof(double)));
         Mat4 m{};
         if (T) std::memcpy(m.m, T, sizeof(m.m));
-        hipLaunchKernelGGL(k_ingest, dim3(nb), dim3(256), 0, ctx->stream, src, n, T ? 1 : 0, m, c.xyz.as<double>(),
+        hipLaunchKernelGGL(k_ingest, dim3(nb), dim3(256), 0, ctx->stream, src, n, T ? 1 : 0, m, c.xyz.as_mut<double>(),
                            ctx->red.as<double>());
         bbox_ready = true;
     } else if (ctx->slab.axis < 0) {
@@ -564,7 +666,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
         if (T) {
             Mat4 m;
             std::memcpy(m.m, T, sizeof(m.m));
-            hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), n, m);
+            hipLaunchKernelGGL(k_transform, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as_mut<double>(), n, m);
         }
     } else {
         // slab mode: keep only [reg_lo, reg_hi) along the slab axis of the (transformed) cloud, stable order.  A device
@@ -593,7 +695,7 @@ int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, l
         ME_CHECK(ctx, c.slab_orig.ensure((size_t) std::max<long long>(kept, 1) * 4));
         c.slab_identity = false;
         hipLaunchKernelGGL(k_slab_compact, dim3(grid_for(n)), dim3(256), 0, ctx->stream, in, n, T ? 1 : 0, m,
-                           flags.as<unsigned int>(), pos.as<unsigned int>(), c.xyz.as<double>(), c.slab_orig.as<int>());
+                           flags.as<unsigned int>(), pos.as<unsigned int>(), c.xyz.as_mut<double>(), c.slab_orig.as<int>());
         c.n = kept;
         if (kept == 0) {  // this rank's slab (+halo) holds nothing of this cloud: every pass returns empty partials
             c.uploaded = true;
@@ -664,7 +766,7 @@ int cloud_transform(me_ctx *ctx, int slot, const double *T) {
     Mat4 m;
     std::memcpy(m.m, T, sizeof(m.m));
     ME_CHECK(ctx, c.xyz.make_owned(ctx->stream));  // (a borrowed input buffer is the caller's: transform a private copy)
-    hipLaunchKernelGGL(k_transform, dim3(grid_for(c.n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(), c.n, m);
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(c.n)), dim3(256), 0, ctx->stream, c.xyz.as_mut<double>(), c.n, m);
     ME_TRY(rotate_attributes(ctx, slot, T));  // normals / covariances follow the points (Open3D PointCloud::Transform)
     return cloud_finish(ctx, slot);
 }
@@ -782,11 +884,14 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     // --- occupied cells per Morton level -> pick the 1-NN grid level; build the cell tables ---
     {
         TimerScope ts(ctx, "cells");
-        ME_CHECK(ctx, ctx->red.ensure(64 * 8));
+        // [hist 32 x u64 | block offsets | block histogram rows]: one pass over the sorted codes leaves a histogram row per block; one
+        // block adds the rows up and scans the radius grid's cell counts (its level is known before the histogram is)
+        const int nblk = (int) ((n + kCellChunk - 1) / kCellChunk);
+        ME_CHECK(ctx, ctx->red.ensure(64 * 8 + (size_t) (nblk + 2) * 4 * (1 + kHistLevels)));
         unsigned long long *d_hist = ctx->red.as<unsigned long long>();
-        ME_CHECK(ctx, hipMemsetAsync(d_hist, 0, 32 * 8, ctx->stream));
-        hipLaunchKernelGGL(k_level_hist, dim3((unsigned int) std::min<long long>(1024, (n + 255) / 256)), dim3(256), 0,
-                           ctx->stream, c.codes.as<unsigned long long>(), n, d_hist);
+        unsigned int *d_boff = reinterpret_cast<unsigned int *>(d_hist + 64), *d_bhist = d_boff + (nblk + 2);
+        hipLaunchKernelGGL(k_level_hist_rows, dim3((unsigned int) nblk), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(), n, d_bhist);
+        hipLaunchKernelGGL(k_block_offsets<true>, dim3(1), dim3(1024), 0, ctx->stream, d_bhist, nblk, (nblk + 1023) / 1024, c.shift, d_boff, d_hist);
         unsigned long long h_hist[32];
         {
             MailGuard mg(ctx);
@@ -817,15 +922,15 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
             ts.end();
             return cloud_build_index(ctx, slot, c.cell_size_req);
         }
-        ME_TRY(build_grid_table(ctx, c, c.shift, c.grid_tab, c.grid));
+        ME_TRY(build_grid_table_counted(ctx, c, c.shift, c.grid_tab, c.grid, nblk, d_bhist, d_boff, true));
         c.n_mid = 0;
         if (nn_shift == c.shift) {
             c.nn_grid = c.grid;
         } else {
-            ME_TRY(build_grid_table(ctx, c, nn_shift, c.nn_tab, c.nn_grid));
-            // tables of the levels in between, for the 1-NN cascade (me_nn.hip): each is one scan + one scatter + the hash inserts
+            ME_TRY(build_grid_table_counted(ctx, c, nn_shift, c.nn_tab, c.nn_grid, nblk, d_bhist, d_boff, false));
+            // tables of the levels in between, for the 1-NN cascade (me_nn.hip): each is one scan over the rows + one pass over the codes
             for (int k = nn_shift + 1; k < c.shift && c.n_mid < Cloud::kMaxMid; ++k) {
-                ME_TRY(build_grid_table(ctx, c, k, c.mid_tab[c.n_mid], c.mid_grid[c.n_mid]));
+                ME_TRY(build_grid_table_counted(ctx, c, k, c.mid_tab[c.n_mid], c.mid_grid[c.n_mid], nblk, d_bhist, d_boff, false));
                 ++c.n_mid;
             }
         }
@@ -886,7 +991,7 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     // The index is COMPLETE on the device when this returns ("every call is synchronous on return", mapeval_hip.h).  Through round 4
     // the cell tables and the octree — everything queued after the level histogram's host read — were still in flight here: harmless
     // on one stream, a data race for two lanes (me_twin): the other lane's k_mme3 / k_nn_grid started on ITS stream while this one's
-    // k_hash_insert was still filling the table they probe.  Python's hand-over latency hid it; the C++ lanes of me_run_suite_from
+    // k_cell_fill (then k_hash_insert) was still filling the table they probe.  Python's hand-over latency hid it; the C++ lanes of me_run_suite_from
     // (microseconds) did not: the second evaluation of a process (fresh buffers holding stale bytes instead of the previous,
     // identical table) spun in hash_lookup for minutes at 50 M points (profiles/EXPERIMENTS.md "Round 5").
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));

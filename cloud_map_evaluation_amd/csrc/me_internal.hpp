@@ -66,6 +66,10 @@ struct DevBuf {
     }
     template <class T>
     T *as() const { return reinterpret_cast<T *>(p); }
+    // for kernels that WRITE the buffer: a borrowed buffer (the caller's memory, ME_FLAG_BORROW_DEVICE_INPUT) yields nullptr — a writer
+    // that forgot ensure() / make_owned() faults at once instead of changing the caller's cloud
+    template <class T>
+    T *as_mut() const { return owned ? reinterpret_cast<T *>(p) : nullptr; }
 };
 
 // Sorted point: xyz in fp64 + original index (bit pattern of an int64 in w).
