@@ -424,7 +424,9 @@ __global__ void k_cell_scatter(const unsigned long long *__restrict__ codes, con
 // exactly when the highest level at which its code differs from its predecessor's is >= L, so a block's row of the level histogram
 // gives the number of cells of ANY level that start inside the block.  Now:
 //   k_level_hist_rows    per block of kCellChunk sorted points: its row of the level histogram — the one pass that was the histogram's;
-//   k_block_offsets      one block: for a level, the exclusive scan over the blocks' cell counts (and, the first time, the rows added up);
+//   k_block_counts       one thread per block: its cell count for a level (and, the first time, the rows added up), then a scan
+//                        over the 24 k counts (a first version did both in ONE 1024-thread block: 0.27 ms alone — 2.3 MB through one
+//                        CU, strided — and 2.6 ms when the other lane held the chip: a single block queues behind everything);
 //   k_cell_fill          the chunks again: start flags ranked in order with ballots (4 wave counts through LDS per 256 points), the
 //                        cell's code, its start and its hash entry written by the lane that found it.
 // Per table 8 bytes per point read instead of 8 read + 4 written (scan) and 12 read (scatter), two launches fewer, the same table entry
@@ -456,66 +458,38 @@ k_level_hist_rows(const unsigned long long *__restrict__ codes, long long n, uns
         }
     }
     __syncthreads();
-    if (threadIdx.x < kHistLevels) block_hist[(long long) blockIdx.x * kHistLevels + threadIdx.x] = sh[threadIdx.x];
+    // (level-major: the rows of all blocks for one level lie together — k_block_counts reads them coalesced)
+    if (threadIdx.x < kHistLevels) block_hist[(long long) threadIdx.x * gridDim.x + blockIdx.x] = sh[threadIdx.x];
 }
 
-// one block of 1024 threads; thread t owns the blocks [t * per, (t + 1) * per).  off[b] = cells of level `level` that start before
-// block b (off[nb] = all of them); with HIST the rows are also added up into hist[0 .. 32)
+// cnt[b] = cells of level `level` that start in block b (cnt[nb] = 0: the scan's last entry is the total); with HIST the rows are also
+// added up into hist[0 .. kHistLevels) (zeroed by the caller).  One thread per block of the first pass.
 template <bool HIST>
-__global__ void __launch_bounds__(1024)
-k_block_offsets(const unsigned int *__restrict__ block_hist, int nb, int per, int level, unsigned int *__restrict__ off,
-                unsigned long long *__restrict__ hist) {
-    __shared__ unsigned int s_tot[1024];
-    __shared__ unsigned long long s_hist[kHistLevels];
-    const int t = threadIdx.x, b0 = t * per, b1 = min(nb, b0 + per);
-    if (HIST && t < kHistLevels) s_hist[t] = 0ULL;
-    unsigned int sum = 0;
-    unsigned int h[kHistLevels];
+__global__ void __launch_bounds__(256)
+k_block_counts(const unsigned int *__restrict__ block_hist, int nb, int level, unsigned int *__restrict__ cnt, unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int sh[kHistLevels];
     if (HIST) {
-#pragma unroll
-        for (int k = 0; k < kHistLevels; ++k) h[k] = 0u;
+        if (threadIdx.x < kHistLevels) sh[threadIdx.x] = 0;
+        __syncthreads();
     }
-    for (int b = b0; b < b1; ++b) {
-        const unsigned int *row = block_hist + (long long) b * kHistLevels;
-        if (b == 0) ++sum;  // the first point starts a cell of every level
-        if (HIST) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    unsigned int c = b == 0 ? 1u : 0u;  // the first point starts a cell of every level
 #pragma unroll
-            for (int k = 0; k < kHistLevels; ++k) {
-                const unsigned int r = row[k];
-                h[k] += r;
-                if (k >= level) sum += r;
-            }
-        } else {
-            for (int k = level; k < kHistLevels; ++k) sum += row[k];
+    for (int k = 0; k < kHistLevels; ++k) {
+        if (!HIST && k < level) continue;
+        const unsigned int r = b < nb ? block_hist[(long long) k * nb + b] : 0u;
+        if (k >= level) c += r;
+        if (HIST) {
+            unsigned int w = r;  // (a row entry is <= 2048, a block of 256 of them fits 32 bits with room)
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) w += __shfl_xor(w, d);
+            if ((threadIdx.x & 63) == 0 && w) atomicAdd(&sh[k], w);
         }
     }
-    s_tot[t] = sum;
-    __syncthreads();
-    if (HIST) {
-#pragma unroll
-        for (int k = 0; k < kHistLevels; ++k)
-            if (h[k]) atomicAdd(&s_hist[k], (unsigned long long) h[k]);
-    }
-    // inclusive scan of the 1024 thread totals (Hillis-Steele in LDS)
-    unsigned int v = sum;
-    for (int d = 1; d < 1024; d <<= 1) {
-        const unsigned int o = t >= d ? s_tot[t - d] : 0u;
-        __syncthreads();
-        v += o;
-        s_tot[t] = v;
-        __syncthreads();
-    }
-    unsigned int run = v - sum;  // exclusive
-    for (int b = b0; b < b1; ++b) {
-        off[b] = run;
-        const unsigned int *row = block_hist + (long long) b * kHistLevels;
-        if (b == 0) ++run;
-        for (int k = level; k < kHistLevels; ++k) run += row[k];
-    }
-    if (t == 1023) off[nb] = v;
+    if (b <= nb) cnt[b] = b < nb ? c : 0u;
     if (HIST) {
         __syncthreads();
-        if (t < 32) hist[t] = t < kHistLevels ? s_hist[t] : 0ULL;
+        if (threadIdx.x < kHistLevels && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long) sh[threadIdx.x]);
     }
 }
 
@@ -568,13 +542,17 @@ k_cell_fill(const unsigned long long *__restrict__ codes, long long n, int shift
 static inline unsigned int grid_for(long long n, int block = 256) { return (unsigned int) ((n + block - 1) / block); }
 
 // occupied cells of Morton level `shift` (unique code >> 3*shift, run starts) + open-addressing hash:
-// a cell table of the sorted points from the blocks' histogram rows (see the kernels above); `offsets_ready`: off already holds this level's scan
+// a cell table of the sorted points from the blocks' histogram rows (see the kernels above); `offsets_ready`: block_off already holds this
+// level's scan (block_off is followed by the nblk + 2 counts the scan reads: the layout of cloud_build_index)
 static int build_grid_table_counted(me_ctx *ctx, Cloud &c, int shift, GridTable &t, GridView &g, int nblk, const unsigned int *block_hist,
                                     unsigned int *block_off, bool offsets_ready) {
     const long long n = c.n;
-    if (!offsets_ready)
-        hipLaunchKernelGGL(k_block_offsets<false>, dim3(1), dim3(1024), 0, ctx->stream, block_hist, nblk, (nblk + 1023) / 1024, shift, block_off,
+    if (!offsets_ready) {
+        unsigned int *cnt = block_off + (nblk + 2);
+        hipLaunchKernelGGL(k_block_counts<false>, dim3(grid_for(nblk + 1)), dim3(256), 0, ctx->stream, block_hist, nblk, shift, cnt,
                            (unsigned long long *) nullptr);
+        ME_TRY(exclusive_scan_u32(ctx, cnt, block_off, nblk + 1));
+    }
     const long long n_cells = c.level_unique[shift];
     ME_CHECK(ctx, t.cell_code.ensure((size_t) n_cells * 8));
     ME_CHECK(ctx, t.cell_start.ensure((size_t) (n_cells + 1) * 4));
@@ -884,14 +862,16 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     // --- occupied cells per Morton level -> pick the 1-NN grid level; build the cell tables ---
     {
         TimerScope ts(ctx, "cells");
-        // [hist 32 x u64 | block offsets | block histogram rows]: one pass over the sorted codes leaves a histogram row per block; one
-        // block adds the rows up and scans the radius grid's cell counts (its level is known before the histogram is)
+        // [hist 64 x u64 | block offsets | block counts | block histogram rows]: one pass over the sorted codes leaves a histogram row per
+        // block; the rows are added up and the radius grid's cell counts (its level is known before the histogram is) scanned
         const int nblk = (int) ((n + kCellChunk - 1) / kCellChunk);
-        ME_CHECK(ctx, ctx->red.ensure(64 * 8 + (size_t) (nblk + 2) * 4 * (1 + kHistLevels)));
+        ME_CHECK(ctx, ctx->red.ensure(64 * 8 + (size_t) (nblk + 2) * 4 * (2 + kHistLevels)));
         unsigned long long *d_hist = ctx->red.as<unsigned long long>();
-        unsigned int *d_boff = reinterpret_cast<unsigned int *>(d_hist + 64), *d_bhist = d_boff + (nblk + 2);
+        unsigned int *d_boff = reinterpret_cast<unsigned int *>(d_hist + 64), *d_bcnt = d_boff + (nblk + 2), *d_bhist = d_bcnt + (nblk + 2);
+        ME_CHECK(ctx, hipMemsetAsync(d_hist, 0, 32 * 8, ctx->stream));
         hipLaunchKernelGGL(k_level_hist_rows, dim3((unsigned int) nblk), dim3(256), 0, ctx->stream, c.codes.as<unsigned long long>(), n, d_bhist);
-        hipLaunchKernelGGL(k_block_offsets<true>, dim3(1), dim3(1024), 0, ctx->stream, d_bhist, nblk, (nblk + 1023) / 1024, c.shift, d_boff, d_hist);
+        hipLaunchKernelGGL(k_block_counts<true>, dim3(grid_for(nblk + 1)), dim3(256), 0, ctx->stream, d_bhist, nblk, c.shift, d_bcnt, d_hist);
+        ME_TRY(exclusive_scan_u32(ctx, d_bcnt, d_boff, nblk + 1));
         unsigned long long h_hist[32];
         {
             MailGuard mg(ctx);
