@@ -78,7 +78,7 @@ def test_nn1_large_offsets_far_queries_and_duplicates(eng, campus):
     assert np.all(d2[-2000:] == 0.0)
 
 
-@pytest.mark.parametrize("n_ref", [1, 2, 15, 16, 17, 127, 129, 1025])
+@pytest.mark.parametrize("n_ref", [1, 2, 15, 16, 17, 127, 129, 1025, 2047, 2048, 2049, 4097])  # (2048: the block of the cell-table passes)
 def test_nn1_tiny_and_ragged_reference_sizes(eng, n_ref):
     import oracle
 
