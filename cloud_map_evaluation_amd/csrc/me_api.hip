@@ -182,6 +182,10 @@ me_ctx *me_twin(me_ctx *ctx) {
 void me_destroy(me_ctx *ctx) {
     if (!ctx) return;
     if (ctx->is_twin) return;  // twins belong to their primary context
+    if (ctx->suite_worker && ctx->suite_worker_free) {  // (before the twin goes: the worker drives it)
+        ctx->suite_worker_free(ctx->suite_worker);
+        ctx->suite_worker = nullptr;
+    }
     if (ctx->twin) {
         me_ctx *t = ctx->twin;
         ctx->twin = nullptr;

@@ -225,6 +225,9 @@ struct me_ctx {
         me::Cloud &operator[](int i) const { return *p[i]; }
     } cloud;
     me_ctx *twin = nullptr;  // owned by the primary context
+    // me_run_suite_from's second-lane host thread (me_suite.hip: LaneWorker), created on first use, joined by me_destroy
+    void *suite_worker = nullptr;
+    void (*suite_worker_free)(void *) = nullptr;
     // Small device -> host results (sums, counts, the level histogram) go through a pinned, device-mapped MAILBOX written by a
     // one-wavefront kernel (me::mail_post / me::mail_sync, me_api.hip; round 4).  hipMemcpyAsync to pageable host memory is a blit
     // kernel of ONE 1024-thread workgroup: it needs 16 free wave slots on one CU at once, and while the other lane's k_nn_grid /

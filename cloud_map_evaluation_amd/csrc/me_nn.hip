@@ -1239,6 +1239,7 @@ __global__ void k_cross_collect(const double *__restrict__ gathered, const doubl
     const long long j = t - (long long) k * cap;
     const long long at = (long long) k * (1 + 2 * cap) + 1 + (long long) dir * cap + j;
     d2_out[at] = (k == own_rank) ? gathered[4 * at + 3] : ans[t];
+    if (j == 0 && dir == 0) d2_out[(long long) k * (1 + 2 * cap)] = 0.0;  // the header slot: never read back, but it goes through a min-reduce
 }
 __global__ void k_cross_untouched(const double *__restrict__ gathered, int world, long long cap, int dir, double *__restrict__ d2_out) {
     const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -1246,6 +1247,7 @@ __global__ void k_cross_untouched(const double *__restrict__ gathered, int world
     const int k = (int) (t / cap);
     const long long at = (long long) k * (1 + 2 * cap) + 1 + (long long) dir * cap + (t - (long long) k * cap);
     d2_out[at] = gathered[4 * at + 3];
+    if (t == (long long) k * cap && dir == 0) d2_out[(long long) k * (1 + 2 * cap)] = 0.0;  // (header slot, as k_cross_collect)
 }
 __global__ void k_cross_patch(const unsigned int *__restrict__ list0, long long cnt0, double *__restrict__ d2_0, const unsigned int *__restrict__ list1,
                               long long cnt1, double *__restrict__ d2_1, const double *__restrict__ mine, long long cap) {

@@ -143,7 +143,7 @@ int me_nn_points_covered(me_ctx *ctx, int ref_slot, const double *xyz_device, in
  * me_nn_cross_answer   the all-gathered messages of all ranks (world x (1 + 2 capacity) x 4) -> d2_device (world x (1 + 2 capacity)):
  *                      every slot of another rank = min(its bound, the nearest squared distance among the points held here, looking only
  *                      OUTSIDE the band [cuts[k] - halo, cuts[k + 1] + halo) of `axis` its owner k has searched completely — as
- *                      me_nn_points_covered); own slots and padding keep their bound.  dir_mask: bit 0 / 1 = answer the map -> gt /
+ *                      me_nn_points_covered); own slots and padding keep their bound, every rank's header slot is written as 0.  dir_mask: bit 0 / 1 = answer the map -> gt /
  *                      gt -> map block (a direction nobody else has open queries in is copied through).  cuts: host, world + 1 values.
  * me_nn_cross_patch    after the all-reduce MIN of d2_device over the ranks: this rank's block patches its open queries (me_nn_patch for
  *                      both directions at once). */
@@ -380,7 +380,12 @@ int me_run_suite(me_ctx *ctx, const me_suite_params *p, me_suite_out *out);
  * LOADED, *map_3d_ = map_3d_->Transform(T) (:1206; T row-major 4x4, NULL or the identity = none), both 1-NN directions with the
  * AC / COM / CD statistics (:76), voxel Gaussians, AWD, CDF, SCS (:85).  The caller stays single-threaded (as process() is, :4).
  *   est / gt           double[n][3] — host memory, or device memory with ME_SUITE_DEVICE_INPUT; both NULL = run on the clouds
- *                      already uploaded to the two slots (e.g. after me_voxel_downsample).
+ *                      already uploaded to the two slots (e.g. after me_voxel_downsample).  With resident clouds T is applied to
+ *                      the resident map IN PLACE, as :1206 overwrites map_3d_: a second call with the same T != identity
+ *                      transforms it again (and computes the MME on the already transformed map) — upload afresh, or pass the
+ *                      identity, to evaluate the same pose twice.  An index that is missing or does not fit nn_radius is rebuilt
+ *                      on nn_radius' lattice before the stages (and the second lane) start: the call from resident clouds returns
+ *                      what the call from the raw clouds returns, bit for bit.
  *   ME_SUITE_OVERLAP   two lanes: the calling thread drives `ctx`, an internal thread drives me_twin(ctx) on its own low-priority
  *                      stream — the ground truth is uploaded / indexed and both voxel tables are built UNDER the map's VALU-bound
  *                      MME kernel, and each lane searches one 1-NN direction (schedule: csrc/me_suite.hip).  Same kernels on the

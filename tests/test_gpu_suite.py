@@ -218,3 +218,82 @@ def test_an_index_is_complete_on_the_device_when_its_upload_returns():
         assert m[3] == o[3] and np.array_equal(m[2], o[2]), it
         assert dt < 5.0, f"iteration {it} took {dt:.1f} s"
         del a, b
+
+
+def test_resident_clouds_with_an_unfit_index_are_rebuilt_before_the_lanes_start(pair):
+    """clouds uploaded with cell_size <= 0 ("automatic": extent / 128, far coarser than the radius) and then evaluated
+    with est = gt = NULL.  mme_run rebuilds such an index — re-sorting `sp`, reallocating the cell tables and the octree — and with
+    ME_SUITE_OVERLAP the second lane used to read the same Cloud at that moment (its voxel_build saw index_valid == false and started a
+    second rebuild).  The indexes are now settled on one lane before the second one starts: the overlapped call on resident clouds
+    equals the sequential one and the call from the raw clouds, every time, with and without the ground truth's MME."""
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, gt = pair
+    for gt_mme in (True, False):
+        P = _param()
+        P.evaluate_gt_mme_ = gt_mme
+        with Engine(0) as e:
+            want = e.run_suite_from(est, gt, P, overlap=False)
+            for it in range(3):
+                e.upload(0, est, cell_size=0.0)
+                e.upload(1, gt, cell_size=0.0)
+                got = e.run_suite_from(None, None, P, overlap=True)
+                _same(want, got)
+            e.upload(0, est, cell_size=0.0)
+            e.upload(1, gt, cell_size=0.0)
+            _same(want, e.run_suite_from(None, None, P, overlap=False))
+    # no MME at all: the stages need SOME index only (built by the uploads above; an invalidated one is rebuilt up front as well)
+    P = _param()
+    P.evaluate_mme_ = False
+    with Engine(0) as e:
+        want = e.run_suite_from(est, gt, P, overlap=False)
+        e.upload(0, est, cell_size=0.0)
+        e.upload(1, gt, cell_size=0.0)
+        _same(want, e.run_suite_from(None, None, P, overlap=True))
+
+
+def test_pinned_torch_buffers_with_pin_host_input_on_both_lanes(eng, pair):
+    """buffers that are page-locked ALREADY (torch pinned tensors) with ME_SUITE_PIN_HOST_INPUT | ME_SUITE_OVERLAP —
+    hipHostRegister refuses them ("already pinned: no-op" in the header) on the second lane's own thread, and the refusal used to stay
+    pending there (hipGetLastError is sticky per thread on ROCm 7) until the lane's next ME_CHECK(hipGetLastError()) turned it into
+    ME_ERR_HIP for the whole call."""
+    import torch
+
+    est, gt = pair
+    P = _param()
+    want = eng.run_suite_from(est, gt, P, overlap=True)
+    est_p, gt_p = torch.from_numpy(est).pin_memory(), torch.from_numpy(gt).pin_memory()
+    for overlap in (True, False, True):
+        got = eng.run_suite_from(est_p, gt_p, P, overlap=overlap, pin_host_input=True)
+        _same(want, got)
+    assert torch.equal(est_p, torch.from_numpy(est)) and est_p.is_pinned()  # (still pinned: the call did not unregister what it did not register)
+
+
+def test_the_lane_thread_belongs_to_the_context(pair):
+    """Round 6: the second lane's host thread is created by the first overlapped call of a context, reused by the later ones and joined by
+    me_destroy — many calls on one engine, then engines created and destroyed in a loop (with and without an overlapped call), must
+    neither leak threads nor hang."""
+    import threading
+
+    from cloud_map_evaluation_amd.engine import Engine
+
+    est, gt = pair
+    est, gt = est[:100_000], gt[:100_000]
+    P = _param()
+    with Engine(0) as e:
+        want = e.run_suite_from(est, gt, P, overlap=False)
+        for _ in range(10):
+            _same(want, e.run_suite_from(est, gt, P, overlap=True))
+    n0 = threading.active_count()
+    for i in range(6):
+        with Engine(0) as e:
+            if i % 2 == 0:
+                _same(want, e.run_suite_from(est, gt, P, overlap=True))
+    assert threading.active_count() == n0
+    import os
+
+    native = len(os.listdir("/proc/self/task"))
+    for i in range(6):
+        with Engine(0) as e:
+            _same(want, e.run_suite_from(est, gt, P, overlap=True))
+    assert len(os.listdir("/proc/self/task")) <= native + 1  # (native threads: every context's worker was joined)
