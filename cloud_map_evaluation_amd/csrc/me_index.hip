@@ -833,6 +833,10 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
         }
     }
     const bool depth_cut = pack_bits > 0 && sort_min_level > std::max(0, c.shift - std::max(0, sort_depth));
+#ifdef ME_DBG_INDEX
+    std::fprintf(stderr, "[index slot %d] n=%lld cell_h=%.17g origin=(%.17g %.17g %.17g) bbox_lo=(%.17g %.17g %.17g) shift=%d sort_min_level=%d pack_bits=%d hinted=%d\n", slot, n, cell_h,
+                 c.origin[0], c.origin[1], c.origin[2], c.bbox_lo[0], c.bbox_lo[1], c.bbox_lo[2], c.shift, sort_min_level, pack_bits, (int) pairs_hinted);
+#endif
     if (pack_bits > 0) ME_CHECK(ctx, perm.ensure((size_t) n * 8));  // (the sorted words)
     {
         TimerScope ts(ctx, "morton");

@@ -17,12 +17,23 @@
 
 #include "me_internal.hpp"
 
+#ifndef ME_NN_DBG
+#define ME_NN_DBG 0  // measurement builds of k_nn_grid (profiles/EXPERIMENTS.md "Round 6"): 1 no ranking loop, 2 no staging either, 3 no exact epilogue loads, 4 ranking without note()
+#endif
+
 namespace me {
 
 // v_min_f64 without the NaN canonicalisation the compiler wraps around fmin() (squared distances are never NaN)
 __device__ __forceinline__ double vmin_f64(double a, double b) {
     double r;
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// v_min_f32 without the canonicalisation (ranks are never NaN)
+__device__ __forceinline__ float fminf_raw(float a, float b) {
+    float r;
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 
@@ -158,15 +169,16 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     // is accurate enough in FP32 to ORDER candidates down to ~1e-6 (cell edge 0.1 m) of squared distance: p' and |p'|^2
     // are computed in fp64 ONCE per candidate when its run is staged and stored as one float4, so a candidate costs one
     // 16-byte broadcast LDS read and 3 fp32 FMAs per lane (the fp64 variant of this loop was bound by LDS bandwidth:
-    // 32 bytes per candidate broadcast to 64 lanes).  The loop keeps the two best GROUPS of <= 4 stream-consecutive
+    // 32 bytes per candidate broadcast to 64 lanes).  The loop keeps the two best GROUPS of <= 8 stream-consecutive
     // candidates (rank + position) and the third-best rank.  The epilogue evaluates both groups EXACTLY in fp64
     // ((dx*dx + dy*dy) + dz*dz, the CPU path's value; ties -> smallest original index, as the CPU path) — every
     // candidate outside them ranks at least b3, so the exact minimum over the two groups is the answer whenever
     // b3 - b1 exceeds twice the rank error (rank_tol).  The few lanes where it does not (about 0.05 %: three near-equal
     // neighbours, or duplicates spread over three groups) go to the octree kernel, which is exact.
-    // bias = 0 for the lanes of the current round's group, +inf for the others: a lane ranks candidates in exactly one
-    // round (one origin), never sees a candidate twice, and the loop needs no exec juggling for the predicate.
-    float ax = 0, ay = 0, az = 0, bias = INFINITY;
+    // Only the lanes of the current round's group rank its candidates (in_round: the exec mask of the ranking loop): a lane ranks
+    // candidates in exactly one round (one origin) and never sees a candidate twice.
+    float ax = 0, ay = 0, az = 0;
+    bool in_round = false;  // this lane belongs to the current round's group
     // rank error: the cell box spans <= 7 cells per axis, so |p'| <= 12 h, |a| <= 24 h, every term of r is below ~150 h^2
     // and carries a few 2^-24 relative: E < 1.2e-4 h^2 in the worst case (typically 10x less); the check uses 2E with margin
     const float rank_tol = (float) (1e-3 * cell_h * cell_h);
@@ -179,7 +191,6 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     // costs ~11 issue cycles on gfx950, 4.2 with the mask in an SGPR pair (profiles/r04_issue_rates.txt) — four of them per
     // group of four candidates; b1 needs no select at all (ranks are never NaN: a plain minimum).
     auto note = [&](float m, int j) {
-        m += bias;
         unsigned long long lt1, lt2;
         asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(lt1) : "v"(m), "v"(b1));
         asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(lt2) : "v"(m), "v"(b2));
@@ -193,7 +204,6 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     };
 #else
     auto note = [&](float m, int j) {
-        m += bias;
         const bool lt1 = m < b1, lt2 = m < b2;
         b3 = __builtin_amdgcn_fmed3f(b2, b3, m);
         b2 = __builtin_amdgcn_fmed3f(b1, b2, m);
@@ -218,10 +228,12 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         const float4 c = tile[j];
         return fmaf(c.x, ax, fmaf(c.y, ay, fmaf(c.z, az, c.w)));
     };
+    // (ranks are never NaN: min3 / med3 rather than fminf, which canonicalises its operands first)
+    auto min3 = [](float a, float b, float c) { return __builtin_amdgcn_fmed3f(-INFINITY, a, __builtin_amdgcn_fmed3f(-INFINITY, b, c)); };
     auto stream_run = [&](int cs, int ce) {
         for (int base = cs; base < ce; base += 64) {
             const int n = min(64, ce - base), n4 = (n + 3) & ~3;
-            if (lane < n4) {
+            if (lane < n4 && ME_NN_DBG != 2) {
                 float4 rec = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
                 if (lane < n) {
                     const SPoint p = rsp[base + lane];
@@ -232,10 +244,28 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // (ranks are never NaN: min3 / med3 rather than fminf, which canonicalises its operands first)
-            for (int j = 0; j < n4; j += 4)
-                note(__builtin_amdgcn_fmed3f(-INFINITY, rank(j), __builtin_amdgcn_fmed3f(-INFINITY, rank(j + 1), __builtin_amdgcn_fmed3f(-INFINITY, rank(j + 2), rank(j + 3)))),
-                     base + j);
+            // Groups of EIGHT stream-consecutive candidates per note() (round 6; four through round 5): the three-smallest update
+            // and its position selects cost 11 vector instructions whatever the group holds — 25 per four candidates, 37 per eight —
+            // and the epilogue pays with eight exact fp64 evaluations per kept group instead of four.  A run's last four (n4 % 8)
+            // are noted as a group of their own; the epilogue evaluates eight positions from any group's start (positions past a
+            // group belong to the next cell along the curve: real reference points all the same).
+            // The group predicate is the EXEC mask of the ranking loop (lanes outside the round's group rank nothing), not a +inf
+            // bias added to every group's minimum.
+            if (in_round && ME_NN_DBG != 1 && ME_NN_DBG != 2) {
+                int j = 0;
+#if ME_NN_DBG == 4
+                float acc = 0.0f;
+                for (; j < n4; ++j) acc += rank(j);
+                if (acc == 12345.0f) note(acc, base);
+                j = n4;
+#endif
+                for (; j + 8 <= n4; j += 8) {
+                    const float m0 = min3(rank(j), rank(j + 1), rank(j + 2));
+                    const float m1 = min3(rank(j + 3), rank(j + 4), rank(j + 5));
+                    note(min3(m0, m1, fminf_raw(rank(j + 6), rank(j + 7))), base + j);
+                }
+                if (j < n4) note(min3(rank(j), rank(j + 1), fminf_raw(rank(j + 2), rank(j + 3))), base + j);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
         }
@@ -256,7 +286,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             ay = (float) (-2.0 * (qy - oy));
             az = (float) (-2.0 * (qz - oz));
         }
-        bias = in ? 0.0f : INFINITY;
+        in_round = in;
         wave_for_each_run<true>(tab, nk, lane, [&](int cs, int ce, int) { stream_run(cs, ce); });
         if (in) done = true;
         __builtin_amdgcn_wave_barrier();
@@ -270,9 +300,9 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         double best_x = INFINITY;
         long long best_i = 0x7fffffffffffffffLL;
         auto exact_group = [&](int jg) {
-            if (jg < 0) return;
+            if (jg < 0 || ME_NN_DBG == 3) return;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 8; ++t) {
                 const long long pos = (long long) jg + t;
                 if (pos < nr) {
                     const SPoint p = rsp[pos];
@@ -285,7 +315,12 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
             }
         };
         exact_group(j1);
-        exact_group(j2);
+        // The second group is evaluated only where it can matter (round 6): when b2 - b1 exceeds the rank tolerance every candidate
+        // outside the best group — the second group's included — is strictly farther than the best group's minimum, in exact
+        // arithmetic too.  Eight scattered 32-byte loads per lane less for the large majority of the lanes (the vector memory
+        // pipe's cost of a load follows its active lanes): with groups of eight the epilogue moved 25 GB per 50 M-query launch
+        // through L1 / L2 and ate what the ranking loop had saved.
+        if (!(b2 - b1 > rank_tol)) exact_group(j2);
         const bool ranking_safe = b3 - b1 > rank_tol;
         if (in_grid && j1 >= 0 && ranking_safe) {
             // distance from q to the faces of the 3x3x3 cell block around its cell (>= one cell edge... minus where
@@ -300,6 +335,7 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         d2_out[q_begin + (long long) qoff] = best_x;  // final if resolved, initial bound otherwise
         idx_out[q_begin + (long long) qoff] = (j1 >= 0) ? (int) best_i : -1;
     }
+    if (ME_NN_DBG) unresolved = false;  // (measurement builds: nothing goes to the octree pass)
     if (!FROM_LIST && flag_out) {
         // first pass of the cascade: flag the unresolved queries; the ordered list is built by a stream compaction
         if (q_begin + (long long) qoff < q_end) flag_out[qoff] = unresolved ? 1 : 0;

@@ -221,8 +221,10 @@ def test_an_index_is_complete_on_the_device_when_its_upload_returns():
 
 
 def test_resident_clouds_with_an_unfit_index_are_rebuilt_before_the_lanes_start(pair):
-    """clouds uploaded with cell_size <= 0 ("automatic": extent / 128, far coarser than the radius) and then evaluated
-    with est = gt = NULL.  mme_run rebuilds such an index — re-sorting `sp`, reallocating the cell tables and the octree — and with
+    """clouds uploaded with a cell size that does not fit the radius (0.5 m here; the "automatic" extent / 128 of
+    cell_size <= 0 is another such value for all but the smallest scenes — for THIS pair's ground truth it happens to be 0.108 m, which
+    fits r = 0.1 and is therefore kept: another lattice, other wavefronts, entropies equal to ~1e-11 instead of bit for bit) and then
+    evaluated with est = gt = NULL.  mme_run rebuilds such an index — re-sorting `sp`, reallocating the cell tables and the octree — and with
     ME_SUITE_OVERLAP the second lane used to read the same Cloud at that moment (its voxel_build saw index_valid == false and started a
     second rebuild).  The indexes are now settled on one lane before the second one starts: the overlapped call on resident clouds
     equals the sequential one and the call from the raw clouds, every time, with and without the ground truth's MME."""
@@ -235,20 +237,28 @@ def test_resident_clouds_with_an_unfit_index_are_rebuilt_before_the_lanes_start(
         with Engine(0) as e:
             want = e.run_suite_from(est, gt, P, overlap=False)
             for it in range(3):
-                e.upload(0, est, cell_size=0.0)
-                e.upload(1, gt, cell_size=0.0)
+                e.upload(0, est, cell_size=0.5)
+                e.upload(1, gt, cell_size=0.5)
                 got = e.run_suite_from(None, None, P, overlap=True)
                 _same(want, got)
+            e.upload(0, est, cell_size=0.5)
+            e.upload(1, gt, cell_size=0.5)
+            _same(want, e.run_suite_from(None, None, P, overlap=False))
+            # "automatic" cells: rebuilt where they do not fit, kept where they do — every count equal, sums to rounding
             e.upload(0, est, cell_size=0.0)
             e.upload(1, gt, cell_size=0.0)
-            _same(want, e.run_suite_from(None, None, P, overlap=False))
+            auto = e.run_suite_from(None, None, P, overlap=True)
+            assert (auto.mme_est_valid, auto.mme_gt_valid, auto.n_w_voxels) == (want.mme_est_valid, want.mme_gt_valid, want.n_w_voxels)
+            assert list(auto.est_gt.number) == list(want.est_gt.number) and list(auto.gt_est.number) == list(want.gt_est.number)
+            np.testing.assert_allclose([auto.mme_est, auto.mme_gt, auto.full_chamfer, auto.awd, auto.scs],
+                                       [want.mme_est, want.mme_gt, want.full_chamfer, want.awd, want.scs], rtol=1e-11)
     # no MME at all: the stages need SOME index only (built by the uploads above; an invalidated one is rebuilt up front as well)
     P = _param()
     P.evaluate_mme_ = False
     with Engine(0) as e:
         want = e.run_suite_from(est, gt, P, overlap=False)
-        e.upload(0, est, cell_size=0.0)
-        e.upload(1, gt, cell_size=0.0)
+        e.upload(0, est, cell_size=0.5)
+        e.upload(1, gt, cell_size=0.5)
         _same(want, e.run_suite_from(None, None, P, overlap=True))
 
 
