@@ -359,6 +359,9 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
 #ifndef ME_TUNE_NN_FAR_LEAF
 #define ME_TUNE_NN_FAR_LEAF 1024  // points a node may hold for k_nn_far to scan it whole instead of descending further
 #endif
+#ifndef ME_TUNE_SUITE_NN_FIRST
+#define ME_TUNE_SUITE_NN_FIRST 1  // me_run_suite_from, second lane: the reverse 1-NN search before the voxel tables (0: round 5's order)
+#endif
 inline unsigned int xcd_chunk_setting() { return (unsigned int) ME_TUNE_XCD_CHUNK; }
 
 // ---- me_api.hip: copies between caller (host) memory and the device ----

@@ -29,6 +29,9 @@
 #ifndef ME_MME_DEPTH
 #define ME_MME_DEPTH 2
 #endif
+#ifndef ME_MME_DBG
+#define ME_MME_DBG 0  // measurement builds of k_mme3 (profiles/EXPERIMENTS.md): 1 no candidate streaming, 2 pre-test only (nothing accepted), 3 staging only (no test loop)
+#endif
 
 namespace me {
 
@@ -102,7 +105,7 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
     // roofline.valu divides by the fp64 vector peak
     // cell_h = edge of a radius-grid cell; thr_lo / thr_hi = r^2 -+ E in FP32 (E = 2^-12 cell_h^2): kernel arguments, i.e.
     // scalar registers for the whole kernel (computed in the kernel they lived in VGPRs and were spilled around the loop).
-    // dbg: profiling switches (profiles/README.md) — 1: no candidate streaming at all, 2: pre-test only, nothing accepted.
+    // dbg: profiling switches (profiles/README.md) — 1: no candidate streaming at all, 2: pre-test only, nothing accepted, 3: staging only.
     static_assert(TILE * 16 >= kGroupRows * 4, "the row masks of the cull alias the tile");
     (void) fr;
     (void) cell_h;
@@ -248,7 +251,7 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                int j = 0;
+                int j = (dbg == 3) ? n : 0;
                 // (two records in flight, not four: eight registers fewer is what keeps this kernel at 64 VGPRs without
                 // spilling inside the run loop — the spills of the four-deep version were 3.2x the kernel's useful HBM traffic)
                 unsigned int ra = trec_lds;
@@ -521,7 +524,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
 #ifdef ME_AB
 #include "me_mme_dispatch_ab.inc"
 #else
-        ME_LAUNCH_MME3(32, 8, 0);
+        ME_LAUNCH_MME3(32, 8, ME_MME_DBG);
 #endif
 #undef ME_LAUNCH_MME3
         ts.end();

@@ -230,45 +230,57 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     };
     // (ranks are never NaN: min3 / med3 rather than fminf, which canonicalises its operands first)
     auto min3 = [](float a, float b, float c) { return __builtin_amdgcn_fmed3f(-INFINITY, a, __builtin_amdgcn_fmed3f(-INFINITY, b, c)); };
-    auto stream_run = [&](int cs, int ce) {
-        for (int base = cs; base < ce; base += 64) {
-            const int n = min(64, ce - base), n4 = (n + 3) & ~3;
-            if (lane < n4 && ME_NN_DBG != 2) {
-                float4 rec = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
-                if (lane < n) {
-                    const SPoint p = rsp[base + lane];
-                    const double px = p.x - ox, py = p.y - oy, pz = p.z - oz;
-                    rec = make_float4((float) px, (float) py, (float) pz, (float) fma(pz, pz, fma(py, py, px * px)));
-                }
-                tile[lane] = rec;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // Groups of EIGHT stream-consecutive candidates per note() (round 6; four through round 5): the three-smallest update
-            // and its position selects cost 11 vector instructions whatever the group holds — 25 per four candidates, 37 per eight —
-            // and the epilogue pays with eight exact fp64 evaluations per kept group instead of four.  A run's last four (n4 % 8)
-            // are noted as a group of their own; the epilogue evaluates eight positions from any group's start (positions past a
-            // group belong to the next cell along the curve: real reference points all the same).
-            // The group predicate is the EXEC mask of the ranking loop (lanes outside the round's group rank nothing), not a +inf
-            // bias added to every group's minimum.
-            if (in_round && ME_NN_DBG != 1 && ME_NN_DBG != 2) {
-                int j = 0;
-#if ME_NN_DBG == 4
-                float acc = 0.0f;
-                for (; j < n4; ++j) acc += rank(j);
-                if (acc == 12345.0f) note(acc, base);
-                j = n4;
-#endif
-                for (; j + 8 <= n4; j += 8) {
-                    const float m0 = min3(rank(j), rank(j + 1), rank(j + 2));
-                    const float m1 = min3(rank(j + 3), rank(j + 4), rank(j + 5));
-                    note(min3(m0, m1, fminf_raw(rank(j + 6), rank(j + 7))), base + j);
-                }
-                if (j < n4) note(min3(rank(j), rank(j + 1), fminf_raw(rank(j + 2), rank(j + 3))), base + j);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
+    // One staged chunk (<= 64 points of one run, or of several runs that are contiguous in the sorted array): the lane's point of the
+    // chunk arrives in (px64, py64, pz64) — loaded ONE CHUNK AHEAD (round 6, below) — is shifted to the round's origin, written to
+    // the tile as an FP32 record and ranked by every lane of the group.
+    double px64 = 0, py64 = 0, pz64 = 0;
+    auto load_chunk = [&](int base, int n) {
+        if (lane < n && ME_NN_DBG != 2) {
+            const SPoint p = rsp[(ME_NN_DBG == 5) ? ((base + lane) & 4095) : (base + lane)];  // (5: staging from a cache-resident stretch)
+            px64 = p.x;
+            py64 = p.y;
+            pz64 = p.z;
         }
+    };
+    auto stage_chunk = [&](int n) {
+        const int n4 = (n + 3) & ~3;
+        if (lane < n4 && ME_NN_DBG != 2) {
+            float4 rec = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
+            if (lane < n) {
+                const double px = px64 - ox, py = py64 - oy, pz = pz64 - oz;
+                rec = make_float4((float) px, (float) py, (float) pz, (float) fma(pz, pz, fma(py, py, px * px)));
+            }
+            tile[lane] = rec;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto rank_chunk = [&](int base, int n) {
+        const int n4 = (n + 3) & ~3;
+        // Groups of EIGHT stream-consecutive candidates per note() (round 6; four through round 5): the three-smallest update
+        // and its position selects cost 11 vector instructions whatever the group holds — 25 per four candidates, 37 per eight —
+        // and the epilogue pays with eight exact fp64 evaluations per kept group instead of four.  A run's last four (n4 % 8)
+        // are noted as a group of their own; the epilogue evaluates eight positions from any group's start (positions past a
+        // group belong to the next cell along the curve: real reference points all the same).
+        // The group predicate is the EXEC mask of the ranking loop (lanes outside the round's group rank nothing), not a +inf
+        // bias added to every group's minimum.
+        if (in_round && ME_NN_DBG != 1 && ME_NN_DBG != 2) {
+            int j = 0;
+#if ME_NN_DBG == 4
+            float acc = 0.0f;
+            for (; j < n4; ++j) acc += rank(j);
+            if (acc == 12345.0f) note(acc, base);
+            j = n4;
+#endif
+            for (; j + 8 <= n4; j += 8) {
+                const float m0 = min3(rank(j), rank(j + 1), rank(j + 2));
+                const float m1 = min3(rank(j + 3), rank(j + 4), rank(j + 5));
+                note(min3(m0, m1, fminf_raw(rank(j + 6), rank(j + 7))), base + j);
+            }
+            if (j < n4) note(min3(rank(j), rank(j + 1), fminf_raw(rank(j + 2), rank(j + 3))), base + j);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the tile is overwritten by the next chunk
     };
     // (the candidate set of a round is a superset of the lane's own 3x3x3 block; extra candidates only help)
     int2 *tab = s_tab[threadIdx.x >> 6];
@@ -282,12 +294,63 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
         oy = uniform_f64(fr.oy + (double) bx.y0 * cell_h);
         oz = uniform_f64(fr.oz + (double) bx.z0 * cell_h);
         if (in) {
-            ax = (float) (-2.0 * (qx - ox));
-            ay = (float) (-2.0 * (qy - oy));
-            az = (float) (-2.0 * (qz - oz));
+            // (the query point is NOT carried through the ranking loop — six vector registers the prefetched chunk point needs: it is
+            // loaded again where it is used, here and in the epilogue; an L2 hit)
+            unsigned int qo = qoff;
+            asm volatile("" : "+v"(qo));
+            const SPoint q = qsp[q_begin + (long long) qo];
+            ax = (float) (-2.0 * (q.x - ox));
+            ay = (float) (-2.0 * (q.y - oy));
+            az = (float) (-2.0 * (q.z - oz));
         }
         in_round = in;
-        wave_for_each_run<true>(tab, nk, lane, [&](int cs, int ce, int) { stream_run(cs, ce); });
+        // The chunks of the round, from an explicit iterator over the run table (wave-uniform state: scalar registers) with the NEXT
+        // chunk's load in flight while the current one is ranked (round 6): with the load issued after the previous chunk's ranking
+        // the wave sat out an L2 / HBM round trip ~20 times per round — 1.4 of 12.2 ms per step (ME_NN_DBG=5: the same kernel staging
+        // from a cache-resident stretch).  Runs that are contiguous in the sorted array (the curve visits cell x + 1 right after cell
+        // x) are streamed as one, as wave_for_each_run<MERGE> did.
+        int it_blk = -64, it_pos = 0, it_end = 0;
+        unsigned long long it_m = 0;
+        auto next_chunk = [&](int &cbase, int &cn) -> bool {
+            if (it_pos >= it_end) {
+                while (!it_m) {
+                    it_blk += 64;
+                    if (it_blk >= nk) return false;
+                    const int t = it_blk + lane;
+                    const int cnt = (t < nk) ? tab[t].y : 0;
+                    it_m = __ballot(cnt > 0);
+                }
+                const int sidx = __ffsll((long long) it_m) - 1;
+                it_m &= it_m - 1;
+                const int2 run = tab[it_blk + sidx];
+                it_pos = __builtin_amdgcn_readfirstlane(run.x);
+                it_end = it_pos + __builtin_amdgcn_readfirstlane(run.y);
+                while (it_m) {  // contiguous successors inside this block of the table
+                    const int s2 = __ffsll((long long) it_m) - 1;
+                    const int2 nx = tab[it_blk + s2];
+                    if (__builtin_amdgcn_readfirstlane(nx.x) != it_end) break;
+                    it_end += __builtin_amdgcn_readfirstlane(nx.y);
+                    it_m &= it_m - 1;
+                }
+            }
+            cbase = it_pos;
+            cn = min(64, it_end - it_pos);
+            it_pos += cn;
+            return true;
+        };
+        int cb = 0, cn = 0;
+        bool have = next_chunk(cb, cn);
+        if (have) load_chunk(cb, cn);
+        while (have) {
+            stage_chunk(cn);
+            int nb2 = 0, nn2 = 0;
+            const bool nhave = next_chunk(nb2, nn2);
+            if (nhave) load_chunk(nb2, nn2);  // lands under the ranking below
+            rank_chunk(cb, cn);
+            have = nhave;
+            cb = nb2;
+            cn = nn2;
+        }
         if (in) done = true;
         __builtin_amdgcn_wave_barrier();
     }
@@ -295,6 +358,14 @@ k_nn_grid(const SPoint *__restrict__ qsp, long long q_begin, long long q_end, co
     bool unresolved = false;
     if (active) {
         unresolved = true;
+        {
+            unsigned int qo = qoff;
+            asm volatile("" : "+v"(qo));
+            const SPoint q = qsp[q_begin + (long long) qo];
+            qx = q.x;
+            qy = q.y;
+            qz = q.z;
+        }
         // exact distances of the two best groups (positions past a group's run belong to cells outside the candidate set:
         // real reference points all the same, so a closer one among them is a better answer, not an error)
         double best_x = INFINITY;

@@ -106,11 +106,24 @@ struct SuiteLane {
             ME_TRY(me::cloud_upload(t, ME_SLOT_GT, gt, gt_on_device, n_gt, nullptr, p->nn_radius));
         }
         set(&SuiteLane::gt_ready);
+#if ME_TUNE_SUITE_NN_FIRST
+        // Round 6: the reverse search FIRST, the voxel tables last.  The search is VALU-bound like the main lane's MME of the ground
+        // truth beside it — together they keep the vector unit busy —, and the two voxel tables (HBM-bound, 2.7 ms alone) then run
+        // under the main lane's own search.  In the other order the low-priority voxel passes starved under the MME (19 ms for 2.7 ms
+        // of work), the reverse search started when the main lane's had finished, and for ~3 ms in between only HBM-bound kernels and
+        // the octree tails were running (profiles/r05_timeline_two_lane.txt).
+        if (!wait(&SuiteLane::est_final)) return ME_OK;
+        ME_TRY(me::nn_search(t, ME_SLOT_GT, ME_SLOT_EST));
+        ME_TRY(me::nn_partial(t, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &back));
+        ME_TRY(me::voxel_build(t, ME_SLOT_GT, p->vmd_voxel_size, false));
+        if (!est_voxel_on_main) ME_TRY(me::voxel_build(t, ME_SLOT_EST, p->vmd_voxel_size, false));  // (never both lanes: same buffers)
+#else
         ME_TRY(me::voxel_build(t, ME_SLOT_GT, p->vmd_voxel_size, false));
         if (!wait(&SuiteLane::est_final)) return ME_OK;
         if (!est_voxel_on_main) ME_TRY(me::voxel_build(t, ME_SLOT_EST, p->vmd_voxel_size, false));  // (never both lanes: same buffers)
         ME_TRY(me::nn_search(t, ME_SLOT_GT, ME_SLOT_EST));
         ME_TRY(me::nn_partial(t, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &back));
+#endif
         return ME_OK;
     }
     // waits until run() has returned; false: the lane failed
