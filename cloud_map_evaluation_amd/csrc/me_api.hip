@@ -563,6 +563,7 @@ int me_timers_reset(me_ctx *ctx) {
     ctx->timers.clear();
     ctx->nn_fallback = ctx->nn_queries = 0;
     ctx->mme_pairs = 0;
+    ctx->mme_refined = 0;
     if (ctx->nn1_dbg_buf.p) (void) hipMemsetAsync(ctx->nn1_dbg_buf.p, 0, 128, ctx->stream);
     return ME_OK;
 }
@@ -580,6 +581,11 @@ int me_timer_get(me_ctx *ctx, const char *name, double *total_ms, int64_t *launc
     if (std::strcmp(name, "mme_pairs") == 0) {  // accepted (query, neighbour) pairs of the MME launches since the last reset
         if (total_ms) *total_ms = 0.0;
         if (launches) *launches = ctx->mme_pairs;
+        return ME_OK;
+    }
+    if (std::strcmp(name, "mme_refined") == 0) {  // queries recomputed by k_mme_refine (thin neighbourhoods) since the last reset; counted always
+        if (total_ms) *total_ms = 0.0;
+        if (launches) *launches = ctx->mme_refined;
         return ME_OK;
     }
     if (std::strncmp(name, "nn1_", 4) == 0 && std::strlen(name) > 4) {

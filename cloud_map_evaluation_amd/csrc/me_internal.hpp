@@ -264,6 +264,8 @@ struct me_ctx {
     long long nn_fallback = 0, nn_queries = 0;  // counted only while timers are on
     long long mme_pairs = 0;                     // accepted (query, neighbour) pairs of the MME launches since the last reset (timers on)
     me::DevBuf mme_pairs_buf;
+    me::DevBuf mme_refine;                       // k_mme3 -> k_mme_refine: [0] count, [1 ..] sorted offsets of the thin neighbourhoods
+    long long mme_refined = 0;                   // queries recomputed by k_mme_refine since the last reset (me_timer_get "mme_refined")
     me::DevBuf nn_far;                           // queries whose octree walk k_nn1 handed over to k_nn_far
     me::DevBuf nn_flags, nn_list_a, nn_list_b;   // 1-NN cascade: unresolved flags of the fine-grid pass, their ordered list, ping-pong
     me::DevBuf mme_keep_e, mme_keep_v;           // me_run_suite_from: the map's per-point MME result across its transform (mme_carry_*)
@@ -358,6 +360,9 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
 #endif
 #ifndef ME_TUNE_NN_FAR_LEAF
 #define ME_TUNE_NN_FAR_LEAF 1024  // points a node may hold for k_nn_far to scan it whole instead of descending further
+#endif
+#ifndef ME_TUNE_MME_REFINE_COND
+#define ME_TUNE_MME_REFINE_COND 1.8e-6  // k_mme3 flags a neighbourhood whose smallest covariance eigenvalue is below ~this x cell_h^2 for k_mme_refine (0: never)
 #endif
 #ifndef ME_TUNE_SUITE_NN_FIRST
 #define ME_TUNE_SUITE_NN_FIRST 1  // me_run_suite_from, second lane: the reverse 1-NN search before the voxel tables (0: round 5's order)

@@ -100,7 +100,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
 k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, long long i_end,
        GridView g, FrameView fr, SlabView slab, double r2, int min_k, double *__restrict__ ent_s,
        unsigned char *__restrict__ valid_s, double *__restrict__ part_sum, long long *__restrict__ part_cnt,
-       unsigned int xcd_chunk, int dbg, double cell_h, float thr_lo, float thr_hi, unsigned long long *__restrict__ part_pairs) {
+       unsigned int xcd_chunk, int dbg, double cell_h, float thr_lo, float thr_hi, unsigned long long *__restrict__ part_pairs,
+       unsigned int *__restrict__ refine_list, unsigned int *__restrict__ refine_count, double cond) {
+    // refine_list / refine_count / cond (round 6): lanes whose covariance is so thin that the rounding of the leader-origin sums shows
+    // (det < (tr / 2)^2 * cond, i.e. smallest eigenvalue below ~cond = 1.8e-6 h^2: a sheet thinner than ~0.2 mm at h = 0.1 m) are
+    // appended to refine_list; k_mme_refine recomputes them with a two-pass covariance about the query itself (mme_run).
     // part_pairs (instrumentation, NULL in product runs): per block, the accepted (query, neighbour) pairs — what bench.py's
     // roofline.valu divides by the fp64 vector peak
     // cell_h = edge of a radius-grid cell; thr_lo / thr_hi = r^2 -+ E in FP32 (E = 2^-12 cell_h^2): kernel arguments, i.e.
@@ -149,6 +153,7 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
     unsigned int wave_pairs = 0;  // (scalar: instrumentation only)
     double det_keep = 0.0;  // determinant of the neighbourhood covariance (valid when have_det)
     bool have_det = false;  // the query has at least min_k neighbours
+    bool thin = false;      // ... and its covariance is thin enough for k_mme_refine
     // A lane accumulates in exactly ONE round (the one whose group it belongs to), so the moments live inside the round:
     // nothing of them is alive while the next round's table is built.
 #ifdef ME_MME_STATS
@@ -311,9 +316,20 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
                 // Eigen 3x3 determinant (cofactor expansion along row 0)
                 det_keep = cxx * (cyy * czz - cyz * cyz) - cxy * (cxy * czz - cyz * cxz) + cxz * (cxy * cyz - cyy * cxz);
                 have_det = true;
+                const double tr = (cxx + cyy) + czz;
+                thin = det_keep < 0.25 * tr * tr * cond;  // lambda_3 >= det / (lambda_1 lambda_2) >= 4 det / tr^2
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (refine_list) {  // wave-aggregated append (any order: every listed query is recomputed on its own)
+        const unsigned long long tm = __ballot(thin);
+        if (tm) {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(refine_count, (unsigned int) __popcll(tm));
+            base = (unsigned int) readlane_i((int) base, 0);
+            if (thin) refine_list[base + (unsigned int) __popcll(tm & ((1ULL << lane) - 1ULL))] = loc;
+        }
     }
     // (the logarithm stays outside the round loop: inside, the compiler hoists its polynomial constants into VGPRs that
     // live across the candidate loop and spills them)
@@ -346,6 +362,181 @@ k_mme3(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ cod
         if (lane == 0) smp[wv] = wave_pairs;
         __syncthreads();
         if (threadIdx.x == 0) part_pairs[blockIdx.x] = (unsigned long long) smp[0] + smp[1] + smp[2] + smp[3];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// k_mme_refine (round 6) — the thin neighbourhoods again, two-pass and about the query itself.
+// k_mme3 sums u and u u^T about the round LEADER's point (|u| up to ~4 cells): the rounding it accumulates, ~eps |u|^2 per entry,
+// divided by the smallest eigenvalue of the covariance, is what its entropy is off by — 6e-11 for a surface with 1 mm of relief,
+// 9e-7 at 10 um, 6e-5 at 1 um (tests/test_gpu_degenerate.py, tilted sheets against the reference's own loops).  The lanes k_mme3
+// flags (smallest eigenvalue below ~1.8e-6 h^2) are recomputed here the way the reference does it (map_eval.cpp:1684-1689) — mean
+// first, then the centred products — but with every offset taken from the QUERY (d = p - q, exact for neighbours), so that no sum
+// ever holds a term larger than r^2.  What is left is the conditioning of the 3x3 cofactor determinant itself (eps (r^2/4)^3 / det),
+// which the reference's own arithmetic has too.  Eight lanes per query: lane c probes cells c, c + 8, c + 16, c + 24 of the 3x3x3
+// block, the runs are scanned 32 points per trip (four independent loads per lane), the partial sums meet in three DPP stages.
+// The accepted set is the exact test's (d2 < r2, strict), the element the reference erases (the query itself, d2 = 0) is taken out
+// algebraically: it contributes 0 to sum(d) and (0 - m)(0 - m)^T to the centred products.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kRefineBlock = 256;  // 32 queries per block
+__global__ void __launch_bounds__(kRefineBlock)
+k_mme_refine(const SPoint *__restrict__ sp, const unsigned long long *__restrict__ codes, long long i_begin, GridView g, double r2,
+             int min_k, const unsigned int *__restrict__ list, unsigned int n_list, double *__restrict__ ent_s,
+             unsigned char *__restrict__ valid_s) {
+    __shared__ int2 s_runs[kRefineBlock / 8][28];  // (28: the rows start in different banks)
+    const int sub = threadIdx.x & 7, oct = threadIdx.x >> 3;
+    const unsigned int t = blockIdx.x * (kRefineBlock / 8) + oct;
+    const bool alive = t < n_list;
+    const long long i = i_begin + (long long) (alive ? list[t] : 0u);
+    const SPoint q = sp[alive ? i : i_begin];
+    const unsigned long long cell = codes[alive ? i : i_begin] >> (3 * g.shift);
+    const int cx = (int) compact21(cell), cy = (int) compact21(cell >> 1), cz = (int) compact21(cell >> 2);
+    const int cell_lim = 1 << (kMortonBits - g.shift);
+    {   // the 27 runs of the block, four probes per lane in flight
+        unsigned long long key[4], got[4];
+        unsigned int slot[4];
+        bool want[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = sub + 8 * u;
+            const int ix = cx + (c % 3) - 1, iy = cy + ((c / 3) % 3) - 1, iz = cz + (c / 9) - 1;
+            want[u] = alive && c < 27 && ix >= 0 && iy >= 0 && iz >= 0 && ix < cell_lim && iy < cell_lim && iz < cell_lim;
+            key[u] = spread21((unsigned long long) ix) | (spread21((unsigned long long) iy) << 1) | (spread21((unsigned long long) iz) << 2);
+            slot[u] = (unsigned int) hash_u64(key[u]) & g.hmask;
+            got[u] = kEmptyKey;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (want[u]) got[u] = g.hkeys[slot[u]];
+        unsigned int ci[4], c0[4], c1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            while (want[u] && got[u] != key[u] && got[u] != kEmptyKey) {  // (collisions: linear probing, rare)
+                slot[u] = (slot[u] + 1) & g.hmask;
+                got[u] = g.hkeys[slot[u]];
+            }
+            want[u] = want[u] && got[u] == key[u];
+            ci[u] = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (want[u]) ci[u] = g.hvals[slot[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c0[u] = c1[u] = 0;
+            if (want[u]) {
+                c0[u] = g.cell_start[ci[u]];
+                c1[u] = g.cell_start[ci[u] + 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (sub + 8 * u < 27) s_runs[oct][sub + 8 * u] = make_int2((int) c0[u], (int) (c1[u] - c0[u]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (an octet lies inside one wavefront)
+    // f(d, inside) for every point of the block, d = p - q
+    auto scan = [&](auto &&f) {
+        for (int c = 0; c < 27; ++c) {
+            const int2 run = s_runs[oct][c];
+            for (int j0 = 0; j0 < run.y; j0 += 32) {
+                SPoint p[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) p[u] = sp[run.x + min(j0 + sub + 8 * u, run.y - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double dx = p[u].x - q.x, dy = p[u].y - q.y, dz = p[u].z - q.z;
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;  // the exact test's expression
+                    if (j0 + sub + 8 * u < run.y && d2 < r2) f(dx, dy, dz);  // strict, nanoflann RadiusResultSet [upstream]
+                }
+            }
+        }
+    };
+    auto oct_sum = [](double v) {
+        v += octet_partner_d<0>(v);
+        v += octet_partner_d<1>(v);
+        v += octet_partner_d<2>(v);
+        return v;
+    };
+    // pass 1: how many, and where their mean lies
+    int cnt = 0;
+    double s1x = 0, s1y = 0, s1z = 0;
+    scan([&](double dx, double dy, double dz) {
+        ++cnt;
+        s1x += dx;
+        s1y += dy;
+        s1z += dz;
+    });
+    cnt += octet_partner_i<0>(cnt);
+    cnt += octet_partner_i<1>(cnt);
+    cnt += octet_partner_i<2>(cnt);
+    s1x = oct_sum(s1x);
+    s1y = oct_sum(s1y);
+    s1z = oct_sum(s1z);
+    const int kk = cnt - 1;  // without the query itself (map_eval.cpp:1672-1673)
+    double H = 0.0;
+    bool ok = false;
+    if (kk >= min_k) {  // (octet-uniform)
+        const double mx = s1x / (double) kk, my = s1y / (double) kk, mz = s1z / (double) kk;  // rowwise().mean() (:1684), relative to q
+        // pass 2: the centred products (:1685-1688)
+        double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+        scan([&](double dx, double dy, double dz) {
+            const double ex = dx - mx, ey = dy - my, ez = dz - mz;
+            sxx = fma(ex, ex, sxx);
+            sxy = fma(ex, ey, sxy);
+            sxz = fma(ex, ez, sxz);
+            syy = fma(ey, ey, syy);
+            syz = fma(ey, ez, syz);
+            szz = fma(ez, ez, szz);
+        });
+        sxx = oct_sum(sxx);
+        sxy = oct_sum(sxy);
+        sxz = oct_sum(sxz);
+        syy = oct_sum(syy);
+        syz = oct_sum(syz);
+        szz = oct_sum(szz);
+        // the erased element: d = 0
+        sxx -= mx * mx;
+        sxy -= mx * my;
+        sxz -= mx * mz;
+        syy -= my * my;
+        syz -= my * mz;
+        szz -= mz * mz;
+        const double inv = 1.0 / (double) (kk - 1);
+        const double cxx = sxx * inv, cxy = sxy * inv, cxz = sxz * inv, cyy = syy * inv, cyz = syz * inv, czz = szz * inv;
+        const double det = cxx * (cyy * czz - cyz * cyz) - cxy * (cxy * czz - cyz * cxz) + cxz * (cxy * cyz - cyy * cxz);
+        const double h = 0.5 * log(2.0 * M_PI * M_E * det);  // ComputeEntropy (:1656)
+        if (!isnan(h) && !isinf(h)) {                         // (:1692)
+            H = h;
+            ok = true;
+        }
+    }
+    if (alive && sub == 0) {
+        ent_s[i] = H;
+        valid_s[i] = ok ? 1 : 0;
+    }
+}
+
+// the block partials of k_mme3 again, from the per-point arrays (after k_mme_refine has rewritten some of them): block b sums the 256
+// sorted points from i_begin + 256 b on — any fixed order is a deterministic sum
+__global__ void __launch_bounds__(256)
+k_mme_resum(const double *__restrict__ ent_s, const unsigned char *__restrict__ valid_s, long long i_begin, long long i_end,
+            double *__restrict__ part_sum, long long *__restrict__ part_cnt) {
+    const long long i = i_begin + (long long) blockIdx.x * 256 + threadIdx.x;
+    double H = 0.0;
+    long long ok = 0;
+    if (i < i_end) {
+        H = ent_s[i];
+        ok = valid_s[i] ? 1 : 0;
+    }
+    __shared__ double smd[4];
+    __shared__ long long smi[4];
+    const double bs = block_sum_256(H, smd);
+    const long long bc = block_sum_256_ll(ok, smi);
+    if (threadIdx.x == 0) {
+        part_sum[blockIdx.x] = bs;
+        part_cnt[blockIdx.x] = bc;
     }
 }
 
@@ -516,11 +707,17 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
             d_pairs = ctx->mme_pairs_buf.as<unsigned long long>() + 2;
         }
 #endif
+        // thin neighbourhoods (k_mme_refine): [0] the list's length, [1 ..] the sorted offsets of the flagged queries
+        ME_CHECK(ctx, ctx->mme_refine.ensure((size_t) (e - b + 1) * 4 + 64));
+        unsigned int *d_refine = ctx->mme_refine.as<unsigned int>();
+        ME_CHECK(ctx, hipMemsetAsync(d_refine, 0, 4, ctx->stream));
+        const double cond = ME_TUNE_MME_REFINE_COND * c.cell_h * c.cell_h;
         TimerScope ts(ctx, "mme");
 #define ME_LAUNCH_MME3(T, W, DBG)                                                                                             \
     hipLaunchKernelGGL((k_mme3<T, W>), dim3(nb), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),                                \
                        c.codes.as<unsigned long long>(), b, e, c.grid, fr, c.slab, r2, min_k, ent_s.as<double>(),             \
-                       val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), DBG, c.cell_h, thr_lo, thr_hi, d_pairs)
+                       val_s.as<unsigned char>(), ps, pc, xcd_chunk_setting(), DBG, c.cell_h, thr_lo, thr_hi, d_pairs, d_refine + 1,      \
+                       d_refine, cond)
 #ifdef ME_AB
 #include "me_mme_dispatch_ab.inc"
 #else
@@ -548,14 +745,38 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
     hipLaunchKernelGGL(k_mme_final, dim3(1), dim3(256), 0, ctx->stream, ps2, pc2, (long long) kStage, (long long) kStage, outs, outc);
     double hs = 0;
     long long hc = 0;
-    if (entropies || valid) ME_TRY(mme_unpermute_to_host(ctx, c, b, e, entropies, valid));
-    {   // the two sums through the mailbox (not hipMemcpyAsync: me_ctx::mail_h), posted after everything above that can fail —
-        // their destinations are locals of this frame (MailGuard)
+    unsigned int n_thin = 0;
+    {   // the two sums (and how many neighbourhoods were flagged as thin) through the mailbox (not hipMemcpyAsync: me_ctx::mail_h),
+        // posted after everything above that can fail — their destinations are locals of this frame (MailGuard)
+        MailGuard mg(ctx);
+        ME_TRY(mail_post(ctx, &hs, outs, 8));
+        ME_TRY(mail_post(ctx, &hc, outc, 8));
+        ME_TRY(mail_post(ctx, &n_thin, ctx->mme_refine.as<unsigned int>(), 4));
+        ME_TRY(mg.sync());
+    }
+    if (n_thin > 0) {
+        // (rare: surfaces with less than ~0.2 mm of relief inside the radius — synthetic planes, CAD samples)  The flagged queries
+        // are recomputed two-pass about themselves, then the block partials are formed again from the per-point arrays.
+        ME_TRACE_POINT(ctx, "mme_run: refining thin neighbourhoods");
+        {
+            TimerScope ts(ctx, "mme_refine");
+            hipLaunchKernelGGL(k_mme_refine, dim3((n_thin + kRefineBlock / 8 - 1) / (kRefineBlock / 8)), dim3(kRefineBlock), 0, ctx->stream,
+                               c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), b, c.grid, r2, min_k,
+                               (const unsigned int *) (ctx->mme_refine.as<unsigned int>() + 1), n_thin, ent_s.as<double>(), val_s.as<unsigned char>());
+        }
+        const unsigned int nb2 = (unsigned int) ((e - b + 255) / 256);  // (<= nb: the partial arrays are large enough)
+        hipLaunchKernelGGL(k_mme_resum, dim3(nb2), dim3(256), 0, ctx->stream, (const double *) ent_s.as<double>(),
+                           (const unsigned char *) val_s.as<unsigned char>(), b, e, ps, pc);
+        const long long chunk2 = ((long long) nb2 + kStage - 1) / kStage;
+        hipLaunchKernelGGL(k_mme_final, dim3(kStage), dim3(256), 0, ctx->stream, ps, pc, (long long) nb2, chunk2, ps2, pc2);
+        hipLaunchKernelGGL(k_mme_final, dim3(1), dim3(256), 0, ctx->stream, ps2, pc2, (long long) kStage, (long long) kStage, outs, outc);
         MailGuard mg(ctx);
         ME_TRY(mail_post(ctx, &hs, outs, 8));
         ME_TRY(mail_post(ctx, &hc, outc, 8));
         ME_TRY(mg.sync());
+        ctx->mme_refined += (long long) n_thin;
     }
+    if (entropies || valid) ME_TRY(mme_unpermute_to_host(ctx, c, b, e, entropies, valid));
     ME_TRACE_POINT(ctx, "mme_run: synced");
     ME_CHECK(ctx, hipGetLastError());
 #ifdef ME_MME_STATS
