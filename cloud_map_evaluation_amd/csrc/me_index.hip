@@ -213,21 +213,43 @@ __global__ void k_morton(const double *__restrict__ xyz, long long n, double ox,
 
 // sorted points, and their Morton codes (the cell keys of every level; recomputed here rather than carried through the sort)
 // (packed != nullptr: the sorted (key, index) words of the keys-only sort, the index in the low bits under idx_mask)
-__global__ void k_gather(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, const unsigned long long *__restrict__ packed,
-                         unsigned long long idx_mask, long long n, double ox, double oy, double oz, double fine_h,
-                         SPoint *__restrict__ sp, unsigned long long *__restrict__ codes) {
-    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned int s = packed ? (unsigned int) (packed[i] & idx_mask) : perm[i];
-    SPoint p;
-    p.x = xyz[3 * (long long) s];
-    p.y = xyz[3 * (long long) s + 1];
-    p.z = xyz[3 * (long long) s + 2];
-    p.idx = (long long) s;
-    sp[i] = p;
-    unsigned int cx, cy, cz;
-    fine_cell(xyz, (long long) s, ox, oy, oz, fine_h, cx, cy, cz);
-    codes[i] = spread21((unsigned long long) cx) | (spread21((unsigned long long) cy) << 1) | (spread21((unsigned long long) cz) << 2);
+constexpr int kGatherPer = 4;  // sorted points per thread (round 6): the four index loads, then the twelve coordinate loads of a thread are in flight together
+__global__ void __launch_bounds__(256)
+k_gather(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, const unsigned long long *__restrict__ packed,
+         unsigned long long idx_mask, long long n, double ox, double oy, double oz, double fine_h,
+         SPoint *__restrict__ sp, unsigned long long *__restrict__ codes) {
+    // (a block covers 256 x kGatherPer consecutive sorted points, a thread the points base + k * 256 + threadIdx.x: every store is coalesced)
+    const long long base = (long long) blockIdx.x * (256 * kGatherPer) + threadIdx.x;
+    unsigned int s[kGatherPer];
+#pragma unroll
+    for (int k = 0; k < kGatherPer; ++k) {
+        const long long i = base + 256 * k;
+        s[k] = i < n ? (packed ? (unsigned int) (packed[i] & idx_mask) : perm[i]) : 0u;
+    }
+    double x[kGatherPer], y[kGatherPer], z[kGatherPer];
+#pragma unroll
+    for (int k = 0; k < kGatherPer; ++k) {
+        x[k] = xyz[3 * (long long) s[k]];
+        y[k] = xyz[3 * (long long) s[k] + 1];
+        z[k] = xyz[3 * (long long) s[k] + 2];
+    }
+    const double lim = 2097151.0;
+#pragma unroll
+    for (int k = 0; k < kGatherPer; ++k) {
+        const long long i = base + 256 * k;
+        if (i >= n) continue;
+        SPoint p;
+        p.x = x[k];
+        p.y = y[k];
+        p.z = z[k];
+        p.idx = (long long) s[k];
+        sp[i] = p;
+        // (fine_cell's arithmetic on the values already in registers: division, not reciprocal multiply)
+        const unsigned int cx = (unsigned int) fmin(fmax(fine_coord(x[k], ox, fine_h), 0.0), lim);
+        const unsigned int cy = (unsigned int) fmin(fmax(fine_coord(y[k], oy, fine_h), 0.0), lim);
+        const unsigned int cz = (unsigned int) fmin(fmax(fine_coord(z[k], oz, fine_h), 0.0), lim);
+        codes[i] = spread21((unsigned long long) cx) | (spread21((unsigned long long) cy) << 1) | (spread21((unsigned long long) cz) << 2);
+    }
 }
 
 // octree level 0: one node per occupied 1-NN-grid cell (a contiguous run of sorted points).  Eight lanes per cell (round 4): they
@@ -442,13 +464,17 @@ k_level_hist_rows(const unsigned long long *__restrict__ codes, long long n, uns
     if (threadIdx.x < 32) sh[threadIdx.x] = 0;
     __syncthreads();
     const long long i0 = (long long) blockIdx.x * kCellChunk, i1 = i0 + kCellChunk < n ? i0 + kCellChunk : n;
-    for (long long base = i0; base < i1; base += 256) {
-        const long long i = base + threadIdx.x;
-        int lv = -1;
-        if (i < i1 && i > 0) {
-            const unsigned long long x = codes[i] ^ codes[i - 1];
-            if (x) lv = (63 - __clzll((long long) x)) / 3;
-        }
+    // (round 6: the chunk's eight rows of 256 codes are loaded before the first is looked at — eight loads in flight per lane instead of
+    // eight dependent load -> ballot rounds)
+    unsigned long long x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long i = i0 + 256 * k + threadIdx.x;
+        x[k] = (i < i1 && i > 0) ? (codes[i] ^ codes[i - 1]) : 0ULL;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int lv = x[k] ? (63 - __clzll((long long) x[k])) / 3 : -1;
         unsigned long long todo = __ballot(lv >= 0);
         while (todo) {  // (wave-aggregated: neighbours differ at two or three distinct levels per wavefront)
             const int l0 = __builtin_amdgcn_readlane(lv, __ffsll((long long) todo) - 1);
@@ -493,48 +519,58 @@ k_block_counts(const unsigned int *__restrict__ block_hist, int nb, int level, u
     }
 }
 
+// (round 6) A wavefront owns 512 CONSECUTIVE points of the block's chunk, eight per lane, and loads all of them (and their predecessors)
+// before it looks at any: the first version walked the chunk 256 points at a time with two block barriers per step — eight dependent
+// load -> ballot -> LDS -> barrier rounds per block, 0.50 ms per 50 M points for 0.4 GB read.  One barrier per block now.
 __global__ void __launch_bounds__(256)
 k_cell_fill(const unsigned long long *__restrict__ codes, long long n, int shift3, const unsigned int *__restrict__ block_off,
             long long n_cells, unsigned long long *__restrict__ cell_code, unsigned int *__restrict__ cell_start,
             unsigned long long *__restrict__ hkeys, unsigned int *__restrict__ hvals, unsigned int hmask) {
+    static_assert(kCellChunk == 2048, "four wavefronts x eight rows of 64 points");
     __shared__ unsigned int s_w[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long i0 = (long long) blockIdx.x * kCellChunk, i1 = i0 + kCellChunk < n ? i0 + kCellChunk : n;
-    unsigned int running = block_off[blockIdx.x];
-    for (long long base = i0; base < i1; base += 256) {
-        const long long i = base + threadIdx.x;
-        bool start = false;
-        unsigned long long c = 0;
-        if (i < i1) {
-            c = codes[i] >> shift3;
-            start = i == 0 || c != (codes[i - 1] >> shift3);
-        }
-        const unsigned long long m = __ballot(start);
-        if (lane == 0) s_w[wv] = (unsigned int) __popcll(m);
-        __syncthreads();
-        unsigned int before = 0, total = 0;
+    const long long w0 = i0 + (long long) wv * 512;
+    unsigned long long c[8], cp[8];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const unsigned int x = s_w[w];
-            if (w < wv) before += x;
-            total += x;
-        }
-        if (start) {
-            const unsigned int pos = running + before + (unsigned int) __popcll(m & ((1ULL << lane) - 1ULL));
-            cell_code[pos] = c;
-            cell_start[pos] = (unsigned int) i;
-            unsigned int s = (unsigned int) hash_u64(c) & hmask;  // (open addressing, linear probe: first free slot)
+    for (int k = 0; k < 8; ++k) {
+        const long long i = w0 + 64 * k + lane;
+        c[k] = i < i1 ? codes[i] : 0ULL;
+        cp[k] = (i < i1 && i > 0) ? codes[i - 1] : 0ULL;
+    }
+    unsigned long long m[8];
+    unsigned int wave_total = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long i = w0 + 64 * k + lane;
+        c[k] >>= shift3;
+        const bool start = i < i1 && (i == 0 || c[k] != (cp[k] >> shift3));
+        m[k] = __ballot(start);
+        wave_total += (unsigned int) __popcll(m[k]);
+    }
+    if (lane == 0) s_w[wv] = wave_total;
+    __syncthreads();
+    unsigned int pos0 = block_off[blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wv) pos0 += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if ((m[k] >> lane) & 1ULL) {
+            const unsigned int pos = pos0 + (unsigned int) __popcll(m[k] & ((1ULL << lane) - 1ULL));
+            cell_code[pos] = c[k];
+            cell_start[pos] = (unsigned int) (w0 + 64 * k + lane);
+            unsigned int sl = (unsigned int) hash_u64(c[k]) & hmask;  // (open addressing, linear probe: first free slot)
             for (;;) {
-                const unsigned long long prev = atomicCAS(&hkeys[s], kEmptyKey, c);
-                if (prev == kEmptyKey || prev == c) {
-                    hvals[s] = pos;
+                const unsigned long long prev = atomicCAS(&hkeys[sl], kEmptyKey, c[k]);
+                if (prev == kEmptyKey || prev == c[k]) {
+                    hvals[sl] = pos;
                     break;
                 }
-                s = (s + 1) & hmask;
+                sl = (sl + 1) & hmask;
             }
         }
-        running += total;
-        __syncthreads();
+        pos0 += (unsigned int) __popcll(m[k]);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) cell_start[n_cells] = (unsigned int) n;
 }
@@ -857,7 +893,7 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
                                   iota.as<unsigned int>(), perm.as<unsigned int>(), n, 3 * sort_min_level, 63));
     {
         TimerScope ts(ctx, "gather");
-        hipLaunchKernelGGL(k_gather, dim3(grid_for(n)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
+        hipLaunchKernelGGL(k_gather, dim3(grid_for(n, 256 * kGatherPer)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
                            pack_bits > 0 ? (const unsigned int *) nullptr : perm.as<unsigned int>(),
                            pack_bits > 0 ? perm.as<unsigned long long>() : (const unsigned long long *) nullptr,
                            pack_bits > 0 ? ((1ULL << pack_bits) - 1ULL) : 0ULL, n, c.origin[0], c.origin[1], c.origin[2], c.fine_h,

@@ -919,10 +919,8 @@ k_nn_partial(const double *__restrict__ d2s, long long q_begin, long long q_end,
     for (int k = 0; k < kStatD; ++k) sd[k] = 0;
 #pragma unroll
     for (int k = 0; k < kStatI; ++k) si[k] = 0;
-    for (long long i = q_begin + (long long) blockIdx.x * blockDim.x + threadIdx.x; i < q_end;
-         i += (long long) gridDim.x * blockDim.x) {
-        const double d2 = d2s[i];
-        if (d2 < 0.0) continue;     // slab mode: halo point, not a query of this rank
+    auto take = [&](double d2) {
+        if (d2 < 0.0) return;       // slab mode: halo point, not a query of this rank
         const double d = sqrt(d2);  // (map_pt - gt_pt).norm(), map_eval.cpp:1095
         sd[10] += d;                // computeChamferDistance, ungated (map_eval.cpp:1416)
         if (gate_pass(sp, d2)) {
@@ -935,7 +933,19 @@ k_nn_partial(const double *__restrict__ d2s, long long q_begin, long long q_end,
                     si[1 + k] += 1;
                 }
         }
+    };
+    // (round 6: four loads in flight per thread — a thread walks ~190 strided elements of a 50 M-point pass, one dependent L2 / HBM
+    // round trip each before; the elements are taken in the same order, so every sum is bit for bit what it was)
+    const long long S = (long long) gridDim.x * blockDim.x;
+    long long i = q_begin + (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * S < q_end; i += 4 * S) {
+        const double a0 = d2s[i], a1 = d2s[i + S], a2 = d2s[i + 2 * S], a3 = d2s[i + 3 * S];
+        take(a0);
+        take(a1);
+        take(a2);
+        take(a3);
     }
+    for (; i < q_end; i += S) take(d2s[i]);
     __shared__ double smd[4];
     __shared__ long long smi[4];
 #pragma unroll
@@ -958,9 +968,7 @@ __global__ void __launch_bounds__(256)
 k_nn_sigma(const double *__restrict__ d2s, long long q_begin, long long q_end, StatParams sp, Mean5 mean,
            double *__restrict__ pd) {
     double s[5] = {0, 0, 0, 0, 0};
-    for (long long i = q_begin + (long long) blockIdx.x * blockDim.x + threadIdx.x; i < q_end;
-         i += (long long) gridDim.x * blockDim.x) {
-        const double d2 = d2s[i];
+    auto take = [&](double d2) {
         if (d2 >= 0.0 && gate_pass(sp, d2)) {
             const double d = sqrt(d2);
 #pragma unroll
@@ -969,7 +977,17 @@ k_nn_sigma(const double *__restrict__ d2s, long long q_begin, long long q_end, S
                 s[k] += e * e;
             }
         }
+    };
+    const long long S = (long long) gridDim.x * blockDim.x;  // (four loads in flight, same order of summation: see k_nn_partial)
+    long long i = q_begin + (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * S < q_end; i += 4 * S) {
+        const double a0 = d2s[i], a1 = d2s[i + S], a2 = d2s[i + 2 * S], a3 = d2s[i + 3 * S];
+        take(a0);
+        take(a1);
+        take(a2);
+        take(a3);
     }
+    for (; i < q_end; i += S) take(d2s[i]);
     __shared__ double smd[4];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -1413,7 +1431,7 @@ int nn_cross_answer(me_ctx *ctx, const double *gathered_device, int world, long 
                            qs.as<SPoint>(), bd.as<double>(), cv.as<double>());
         if (r.n > 0) {
             ME_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));
-            TimerScope ts(ctx, "nn1");
+            TimerScope ts(ctx, "nn1_cross");  // (the other ranks' open queries: k_nn1 + k_nn_far)
             unsigned long long *dbgp = ctx->timers_on ? ctx->nn1_dbg() : nullptr;
             const dim3 g1((unsigned int) std::min<long long>((m + 7) / 8, 256 * 4 * kNn1Waves));
             if (dbgp)

@@ -91,6 +91,26 @@ __device__ __forceinline__ double seg_sum_to_head(double v, int seg, int lane) {
     }
     return v;
 }
+// Sum over the WHOLE wave delivered to lane 0, on the vector unit (round 6): four DPP row shifts leave each row's sum in its first
+// lane, three readlanes add the rows.  The segmented sums above cost three ds_bpermute per value and stage — 108 LDS-pipe operations
+// per wavefront in k_vox_pass2, which made the voxel passes LDS-bound (0.5 ms per pass and 50 M points where the 1.6 GB they read
+// take 0.33) — and a 3 m voxel holds thousands of consecutive sorted points: nearly every wavefront is ONE run.
+__device__ __forceinline__ double wave_sum_to_lane0(double v) {
+#define ME_ROW_SHL_ADD(N)                                                                                                    \
+    {                                                                                                                        \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + (N), 0xF, 0xF, true);                       \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + (N), 0xF, 0xF, true);                       \
+        v += __hiloint2double(hi, lo);                                                                                       \
+    }
+    ME_ROW_SHL_ADD(1)
+    ME_ROW_SHL_ADD(2)
+    ME_ROW_SHL_ADD(4)
+    ME_ROW_SHL_ADD(8)
+#undef ME_ROW_SHL_ADD
+    auto row = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
+    return ((row(0) + row(16)) + (row(32) + row(48)));  // (wave-uniform; lane 0 uses it)
+}
+
 __device__ __forceinline__ int seg_sum_to_head_i(int v, int seg, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -120,8 +140,19 @@ k_vox_pass1(const SPoint *__restrict__ sp, long long n, double vs, SlabView slab
     const int lane = threadIdx.x & 63;
     double x, y, z;
     const RunLane r = wave_runs(sp, i, n, vs, slab, err, lane, x, y, z);
-    const int cnt = seg_sum_to_head_i(r.valid ? 1 : 0, r.seg, lane);
-    const double sx = seg_sum_to_head(x, r.seg, lane), sy = seg_sum_to_head(y, r.seg, lane), sz = seg_sum_to_head(z, r.seg, lane);
+    int cnt;
+    double sx, sy, sz;
+    if (__ballot(r.head) == 1ULL) {  // (wave-uniform) the wavefront is one run: plain sums on the vector unit (invalid lanes hold zeros)
+        cnt = __popcll(__ballot(r.valid));
+        sx = wave_sum_to_lane0(x);
+        sy = wave_sum_to_lane0(y);
+        sz = wave_sum_to_lane0(z);
+    } else {
+        cnt = seg_sum_to_head_i(r.valid ? 1 : 0, r.seg, lane);
+        sx = seg_sum_to_head(x, r.seg, lane);
+        sy = seg_sum_to_head(y, r.seg, lane);
+        sz = seg_sum_to_head(z, r.seg, lane);
+    }
     if (r.head) {
         const long long rid = (long long) wave_off[i >> 6] + r.run_local;
         rec_key[rid] = r.key;
@@ -179,9 +210,22 @@ k_vox_pass2(const SPoint *__restrict__ sp, long long n, double vs, SlabView slab
         dy = y - vmu[3 * v + 1];
         dz = z - vmu[3 * v + 2];
     }
-    const double cxx = seg_sum_to_head(dx * dx, r.seg, lane), cxy = seg_sum_to_head(dx * dy, r.seg, lane);
-    const double cxz = seg_sum_to_head(dx * dz, r.seg, lane), cyy = seg_sum_to_head(dy * dy, r.seg, lane);
-    const double cyz = seg_sum_to_head(dy * dz, r.seg, lane), czz = seg_sum_to_head(dz * dz, r.seg, lane);
+    double cxx, cxy, cxz, cyy, cyz, czz;
+    if (__ballot(r.head) == 1ULL) {  // (wave-uniform) one run: see k_vox_pass1
+        cxx = wave_sum_to_lane0(dx * dx);
+        cxy = wave_sum_to_lane0(dx * dy);
+        cxz = wave_sum_to_lane0(dx * dz);
+        cyy = wave_sum_to_lane0(dy * dy);
+        cyz = wave_sum_to_lane0(dy * dz);
+        czz = wave_sum_to_lane0(dz * dz);
+    } else {
+        cxx = seg_sum_to_head(dx * dx, r.seg, lane);
+        cxy = seg_sum_to_head(dx * dy, r.seg, lane);
+        cxz = seg_sum_to_head(dx * dz, r.seg, lane);
+        cyy = seg_sum_to_head(dy * dy, r.seg, lane);
+        cyz = seg_sum_to_head(dy * dz, r.seg, lane);
+        czz = seg_sum_to_head(dz * dz, r.seg, lane);
+    }
     if (r.head) {
         double *o = rec_m2 + 6 * rid;
         o[0] = cxx;

@@ -111,26 +111,41 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
             best, best_t = 1e9, None
             for rep in range(3):
                 eng.timers_enable(rep == 2)
+                tw = eng.twin() if OVERLAP else None
+                if tw is not None:
+                    tw.timers_enable(rep == 2)
                 if rep == 2:
                     eng.timers_reset()
+                    if tw is not None:
+                        tw.timers_reset()
                 if fd is not None:
                     fd.n_gather = 0
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 if world == 1:
-                    medist.suite_step(eng, None, dev, est, gt, P, True, overlap=OVERLAP)
+                    res = medist.suite_step(eng, None, dev, est, gt, P, True, overlap=OVERLAP)
                 else:
-                    medist.suite_step_dist(eng, fd, dev, pieces[rank][0], pieces[rank][1], P, rank, world, True, halo=halo, overlap=OVERLAP)
+                    res = medist.suite_step_dist(eng, fd, dev, pieces[rank][0], pieces[rank][1], P, rank, world, True, halo=halo, overlap=OVERLAP)
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
-            best_t = {k: round(eng.timer(k)[0], 2) for k in ("mme", "nn_grid", "nn_grid2", "nn1", "nn_far", "sort", "morton", "gather", "cells", "voxel",
-                                                            "slab_filter", "halo_pack", "nn_stats") if eng.timer(k)[1]}
-            eng.timers_enable(False)
+            names = ("mme", "nn_grid", "nn_grid2", "nn1", "nn_far", "nn1_cross", "sort", "morton", "gather", "cells", "voxel", "slab_filter", "halo_pack", "nn_stats")
+            best_t = {}
+            for e2 in ([eng] + ([eng.twin()] if OVERLAP else [])):  # (both lanes: each context keeps its own timers)
+                for k in names:
+                    ms, cnt = e2.timer(k)
+                    if cnt:
+                        best_t[k] = round(best_t.get(k, 0.0) + ms, 2)
+                e2.timers_enable(False)
+            best_t["open_queries"] = int(res.get("n_cross_rank_queries", 0)) if isinstance(res, dict) else 0
+            for k in ("nn1_opened", "nn1_scans", "nn1_max_opened", "nn1_far", "nn1_far_opened", "nn1_far_points", "nn1_far_max"):  # (main lane's walks)
+                best_t[k] = int(eng.timer(k)[1])
             medist.dist_slab_cuts = _orig_cuts
             per_rank.append(best * 1e3)
             detail.append(best_t)
         worst = max(range(world), key=lambda r: per_rank[r])
-        out[world] = {"max_ms": per_rank[worst], "mean_ms": sum(per_rank) / world, "slowest_rank_kernel_ms": detail[worst]}
+        out[world] = {"max_ms": per_rank[worst], "mean_ms": sum(per_rank) / world, "slowest_rank_kernel_ms": detail[worst],
+                      "per_rank_ms": [round(x, 2) for x in per_rank],
+                      "per_rank_kernel_ms": detail}
         print(world, out[world], flush=True)
         if world > 1:
             del packs
