@@ -199,6 +199,7 @@ void me_destroy(me_ctx *ctx) {
         (void) hipEventDestroy(p.b);
     }
     for (auto e : ctx->event_pool) (void) hipEventDestroy(e);
+    if (ctx->suite_event) (void) hipEventDestroy(static_cast<hipEvent_t>(ctx->suite_event));
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     if (ctx->mail_h) (void) hipHostFree(ctx->mail_h);
     delete ctx;

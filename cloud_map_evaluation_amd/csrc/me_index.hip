@@ -349,10 +349,12 @@ __global__ void k_oct_up(ONode *__restrict__ child, long long n_child, const uns
 // them all, level after level — what took a scan, k_cell_scatter and k_oct_up launch PER LEVEL (about ten levels of a few thousand
 // nodes down to one: ~40 launch-sized kernels per cloud, nothing else).  Same node records as k_oct_up writes.
 constexpr int kOctTopMax = 16384;
-__global__ void __launch_bounds__(1024)
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 k_oct_top(ONode *__restrict__ nodes, unsigned int *__restrict__ pbeg, OctView v, int l0, const unsigned long long *__restrict__ codes0,
           unsigned long long *__restrict__ ca, unsigned long long *__restrict__ cb, unsigned int *__restrict__ begin) {
-    __shared__ unsigned int s_cnt[16];
+    constexpr int NW = BLOCK / 64;
+    __shared__ unsigned int s_cnt[NW];
     const int t = threadIdx.x;
     const unsigned long long *cur = codes0;
     for (int l = l0; l + 1 < v.n_levels; ++l) {
@@ -361,10 +363,10 @@ k_oct_top(ONode *__restrict__ nodes, unsigned int *__restrict__ pbeg, OctView v,
         ONode *child = nodes + v.off[l], *parent = nodes + v.off[l + 1];
         const unsigned int *cpb = pbeg + v.off[l];
         unsigned int *ppb = pbeg + v.off[l + 1];
-        // parents start where the 3-bit-shorter prefix changes: rank the flags in order (ballot inside a wave, 16 wave totals
-        // through LDS), 1024 children per sweep, coalesced
+        // parents start where the 3-bit-shorter prefix changes: rank the flags in order (ballot inside a wave, the wave totals
+        // through LDS), BLOCK children per sweep, coalesced
         unsigned int running = 0;
-        for (long long base = 0; base < nc; base += 1024) {
+        for (long long base = 0; base < nc; base += BLOCK) {
             const long long i = base + t;
             const bool flag = i < nc && (i == 0 || (cur[i] >> 3) != (cur[i - 1] >> 3));
             const unsigned long long m = __ballot(flag);
@@ -372,7 +374,7 @@ k_oct_top(ONode *__restrict__ nodes, unsigned int *__restrict__ pbeg, OctView v,
             if (lane == 0) s_cnt[wv] = (unsigned int) __popcll(m);
             __syncthreads();
             unsigned int before = 0, total = 0;
-            for (int w = 0; w < 16; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 const unsigned int c = s_cnt[w];
                 if (w < wv) before += c;
                 total += c;
@@ -388,7 +390,7 @@ k_oct_top(ONode *__restrict__ nodes, unsigned int *__restrict__ pbeg, OctView v,
         __threadfence_block();
         __syncthreads();
         // parent records (k_oct_up)
-        for (long long p = t; p <= np; p += 1024) {
+        for (long long p = t; p <= np; p += BLOCK) {
             ONode nd;
             if (p == np) {
                 for (int d = 0; d < 3; ++d) nd.lo[d] = nd.hi[d] = 0.0f;
@@ -891,6 +893,7 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     else
         ME_TRY(sort_pairs_u64_u32(ctx, codes_in.as<unsigned long long>(), c.codes.as<unsigned long long>(),
                                   iota.as<unsigned int>(), perm.as<unsigned int>(), n, 3 * sort_min_level, 63));
+    if (ctx->sort_hook) ctx->sort_hook(ctx->sort_hook_arg, ctx->stream);  // (me_run_suite_from: see SuiteLane::sort_queued)
     {
         TimerScope ts(ctx, "gather");
         hipLaunchKernelGGL(k_gather, dim3(grid_for(n, 256 * kGatherPer)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
@@ -990,8 +993,14 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
                     // (`cur` may live in ca / cb: the kernel's first output buffer must be the other one)
                     unsigned long long *first = (cur == ca.as<unsigned long long>()) ? cb.as<unsigned long long>() : ca.as<unsigned long long>();
                     unsigned long long *second = (first == ca.as<unsigned long long>()) ? cb.as<unsigned long long>() : ca.as<unsigned long long>();
-                    hipLaunchKernelGGL(k_oct_top, dim3(1), dim3(1024), 0, ctx->stream, nodes, pbeg, v, l, cur, first, second,
-                                       begin.as<unsigned int>());
+                    // (a twin lane runs beside the main lane's full-chip kernels: a 1024-thread block needs 16 free wave slots on ONE CU
+                    // at the same moment and waited 10 ms for them under k_mme3 — profiles/r06_timeline.txt; four waves find room)
+                    if (ctx->is_twin)
+                        hipLaunchKernelGGL((k_oct_top<256>), dim3(1), dim3(256), 0, ctx->stream, nodes, pbeg, v, l, cur, first, second,
+                                           begin.as<unsigned int>());
+                    else
+                        hipLaunchKernelGGL((k_oct_top<1024>), dim3(1), dim3(1024), 0, ctx->stream, nodes, pbeg, v, l, cur, first, second,
+                                           begin.as<unsigned int>());
                     break;
                 }
                 ME_CHECK(ctx, pos.ensure((size_t) nc * 4));

@@ -225,7 +225,12 @@ struct me_ctx {
         me::Cloud &operator[](int i) const { return *p[i]; }
     } cloud;
     me_ctx *twin = nullptr;  // owned by the primary context
+    // called by cloud_build_index right after its radix sort has been QUEUED on the context's stream (me_run_suite_from's second lane
+    // uses it to let the main lane order its MME behind the sort: me_suite.hip)
+    void (*sort_hook)(void *arg, hipStream_t stream) = nullptr;
+    void *sort_hook_arg = nullptr;
     // me_run_suite_from's second-lane host thread (me_suite.hip: LaneWorker), created on first use, joined by me_destroy
+    void *suite_event = nullptr;  // hipEvent_t of me_run_suite_from's "sort queued" hand-over, created on first use
     void *suite_worker = nullptr;
     void (*suite_worker_free)(void *) = nullptr;
     // Small device -> host results (sums, counts, the level histogram) go through a pinned, device-mapped MAILBOX written by a
@@ -363,6 +368,9 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
 #endif
 #ifndef ME_TUNE_MME_REFINE_COND
 #define ME_TUNE_MME_REFINE_COND 1.8e-6  // k_mme3 flags a neighbourhood whose smallest covariance eigenvalue is below ~this x cell_h^2 for k_mme_refine (0: never)
+#endif
+#ifndef ME_TUNE_SUITE_SORT_FIRST
+#define ME_TUNE_SUITE_SORT_FIRST 1  // me_run_suite_from: the map's MME is ordered behind the ground truth's radix sort (rocPRIM's onesweep crawls under a full chip)
 #endif
 #ifndef ME_TUNE_SUITE_NN_FIRST
 #define ME_TUNE_SUITE_NN_FIRST 1  // me_run_suite_from, second lane: the reverse 1-NN search before the voxel tables (0: round 5's order)

@@ -49,6 +49,7 @@ struct SuiteLane {
     long long n_gt = 0;
     bool gt_on_device = false, upload_gt = false, wait_for_link = false, pin_gt = false;
     bool est_voxel_on_main = false;  // host input: the main lane builds the map's voxel table while the ground truth is in flight
+    std::atomic<int> est_voxel_taken{0};  // device input: the lane that sets it builds the map's voxel table
     bool gt_pinned = false;  // this call page-locked the ground truth's buffer (released by the caller of run())
     std::mutex m;
     std::condition_variable cv;
@@ -60,6 +61,20 @@ struct SuiteLane {
     bool finished = false;       // lane -> main: run() has returned (the lane touches nothing of this object afterwards)
     bool started = false;        // the worker has been handed this lane
     me_nn_partial back{};        // ground truth -> map partial sums
+    // Round 6: rocPRIM's onesweep radix pass uses decoupled lookback, and under a chip filled by the main lane's k_mme3 ONE pass of the
+    // ground truth's sort took 12.8 ms instead of 0.3 (every other kernel of its index build ran at its normal speed beside the MME:
+    // profiles/r06_timeline.txt) — the ground truth was indexed at 21.4 ms, the main lane waited 1 ms for it, and this lane's search
+    // could not start before.  The lane records an event when its sort has been queued; the main lane makes its stream wait for that
+    // event before the map's MME: ~0.3 ms later for the MME, ~12 ms earlier for everything on this lane.
+    hipEvent_t sort_event = nullptr;
+    bool sort_queued = false;    // lane -> main: sort_event has been recorded (or there is no sort to wait for)
+    static void sort_hook(void *self, hipStream_t stream) {
+        SuiteLane *l = static_cast<SuiteLane *>(self);
+        if (l->sort_event && !l->sort_queued) {
+            (void) hipEventRecord(l->sort_event, stream);
+            l->set(&SuiteLane::sort_queued);
+        }
+    }
 
     void set(bool SuiteLane::*flag) {
         {
@@ -87,6 +102,7 @@ struct SuiteLane {
         {   // gt_ready: a failed lane must not leave the main lane waiting; finished: last touch of this object
             std::lock_guard<std::mutex> g(m);
             gt_ready = true;
+            sort_queued = true;
             finished = true;
         }
         cv.notify_all();
@@ -103,8 +119,13 @@ struct SuiteLane {
                 (void) hipGetLastError();
             }
             if (wait_for_link && !wait(&SuiteLane::est_on_device)) return ME_OK;
-            ME_TRY(me::cloud_upload(t, ME_SLOT_GT, gt, gt_on_device, n_gt, nullptr, p->nn_radius));
+            t->sort_hook = sort_event ? &SuiteLane::sort_hook : nullptr;
+            t->sort_hook_arg = this;
+            const int urc = me::cloud_upload(t, ME_SLOT_GT, gt, gt_on_device, n_gt, nullptr, p->nn_radius);
+            t->sort_hook = nullptr;
+            if (urc != ME_OK) return urc;
         }
+        set(&SuiteLane::sort_queued);  // (nothing to wait for any more, whatever happened above)
         set(&SuiteLane::gt_ready);
 #if ME_TUNE_SUITE_NN_FIRST
         // Round 6: the reverse search FIRST, the voxel tables last.  The search is VALU-bound like the main lane's MME of the ground
@@ -116,7 +137,9 @@ struct SuiteLane {
         ME_TRY(me::nn_search(t, ME_SLOT_GT, ME_SLOT_EST));
         ME_TRY(me::nn_partial(t, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &back));
         ME_TRY(me::voxel_build(t, ME_SLOT_GT, p->vmd_voxel_size, false));
-        if (!est_voxel_on_main) ME_TRY(me::voxel_build(t, ME_SLOT_EST, p->vmd_voxel_size, false));  // (never both lanes: same buffers)
+        // the map's voxel table: whichever lane gets to it first (never both: same buffers) — the main lane claims it when its own
+        // search is over and this lane is still busy with the ground truth's table
+        if (!est_voxel_on_main && !est_voxel_taken.exchange(1)) ME_TRY(me::voxel_build(t, ME_SLOT_EST, p->vmd_voxel_size, false));
 #else
         ME_TRY(me::voxel_build(t, ME_SLOT_GT, p->vmd_voxel_size, false));
         if (!wait(&SuiteLane::est_final)) return ME_OK;
@@ -329,6 +352,12 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
         lane.wait_for_link = upload && !on_device;
         lane.pin_gt = pin;
         lane.est_voxel_on_main = upload && !on_device;
+#if ME_TUNE_SUITE_SORT_FIRST
+        if (upload && on_device && p->evaluate_mme) {
+            if (!ctx->suite_event) ME_CHECK(ctx, hipEventCreateWithFlags(reinterpret_cast<hipEvent_t *>(&ctx->suite_event), hipEventDisableTiming));
+            lane.sort_event = static_cast<hipEvent_t>(ctx->suite_event);
+        }
+#endif
         worker->post(&lane);
     }
     bool est_pinned = false, gt_pinned_here = false;
@@ -353,6 +382,12 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
             double s = 0;
             long long nv = 0;
             t0 = Clock::now();
+            if (overlap && lane.sort_event) {
+                // (device-resident input only: the ground truth's sort is queued within a millisecond of the call's start — with host
+                // input it follows a 20 ms copy, and the map's MME is what hides that copy)
+                if (!lane.wait(&SuiteLane::sort_queued)) return lane.rc.load() != ME_OK ? lane.rc.load() : ME_ERR_STATE;
+                ME_CHECK(ctx, hipStreamWaitEvent(ctx->stream, lane.sort_event, 0));
+            }
             ME_TRY(me::mme_run(ctx, ME_SLOT_EST, p->nn_radius, 10, nullptr, nullptr, &s, &nv));  // k >= 10 (:1675)
             out->stage_ms[4] = ms_since(t0);
             out->mme_est = nv > 0 ? s / (double) nv : 0.0;
@@ -394,6 +429,14 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
         ME_TRY(me::nn_partial(ctx, ME_SLOT_EST, p->icp_max_distance, p->gate_mode, p->trunc, &pe));
         out->stage_ms[1] = ms_since(t0);
         t0 = Clock::now();
+#if ME_TUNE_SUITE_NN_FIRST
+        if (overlap && !lane.est_voxel_on_main && !lane.est_voxel_taken.exchange(1)) {
+            // (the second lane is still searching or on the ground truth's voxel table: the map's is built here instead of waiting)
+            ME_TRY(me::voxel_build(ctx, ME_SLOT_EST, p->vmd_voxel_size, false));
+            out->stage_ms[6] += ms_since(t0);
+            t0 = Clock::now();
+        }
+#endif
         if (overlap) {
             if (!lane.join()) return lane.rc.load();  // the second lane has searched the other direction meanwhile (and built both voxel tables)
             pg = lane.back;
