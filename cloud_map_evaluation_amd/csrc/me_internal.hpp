@@ -372,6 +372,9 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
 #ifndef ME_TUNE_SUITE_SORT_FIRST
 #define ME_TUNE_SUITE_SORT_FIRST 1  // me_run_suite_from: the map's MME is ordered behind the ground truth's radix sort (rocPRIM's onesweep crawls under a full chip)
 #endif
+#ifndef ME_TUNE_VOX_MERGE_SORT
+#define ME_TUNE_VOX_MERGE_SORT 1  // voxel run records sorted by rocPRIM's merge sort (plain kernels) instead of its onesweep radix sort
+#endif
 #ifndef ME_TUNE_SUITE_NN_FIRST
 #define ME_TUNE_SUITE_NN_FIRST 1  // me_run_suite_from, second lane: the reverse 1-NN search before the voxel tables (0: round 5's order)
 #endif
@@ -404,7 +407,10 @@ struct MailGuard {
 // ---- me_prims.hip (rocPRIM-backed primitives) ----
 int sort_pairs_u64_u32(me_ctx *ctx, const unsigned long long *k_in, unsigned long long *k_out,
                        const unsigned int *v_in, unsigned int *v_out, long long n, int begin_bit, int end_bit);
+int sort_pairs_merge_u64_u32(me_ctx *ctx, const unsigned long long *k_in, unsigned long long *k_out, const unsigned int *v_in,
+                             unsigned int *v_out, long long n);
 int exclusive_scan_u32(me_ctx *ctx, const unsigned int *in, unsigned int *out, long long n);
+int exclusive_scan_u32_plain(me_ctx *ctx, const unsigned int *in, unsigned int *out, long long n);  // no decoupled lookback (in != out)
 int cell_start_ranks(me_ctx *ctx, const unsigned long long *codes, long long n, int shift3, unsigned int *out);
 int sort_keys_f64(me_ctx *ctx, const double *in, double *out, long long n);
 int sort_keys_u64(me_ctx *ctx, const unsigned long long *in, unsigned long long *out, long long n, int begin_bit, int end_bit);

@@ -749,7 +749,7 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
         TimerScope ts(ctx, "voxel");
         hipLaunchKernelGGL(k_vox_count_runs, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sp, n, voxel_size, c.slab, wave_runs, d_err);
     }
-    ME_TRY(exclusive_scan_u32(ctx, wave_runs, wave_off, nw));
+    ME_TRY(exclusive_scan_u32_plain(ctx, wave_runs, wave_off, nw));  // (plain kernels: this build runs beside the other lane's full-chip kernels)
     unsigned int last_off = 0, last_runs = 0;
     ME_TRACE_POINT(ctx, "voxel_build: count_runs + scan queued");
     int h_err = 0;
@@ -781,9 +781,13 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
                            iota, rec_n, rec_sum, d_err);
     }
     // radix sort is stable: the sorted order is preserved inside every voxel (fixed summation order)
+#if ME_TUNE_VOX_MERGE_SORT
+    ME_TRY(sort_pairs_merge_u64_u32(ctx, rec_key, skey, iota, perm_r, R));  // (stable, like the radix sort: same order, plain kernels)
+#else
     ME_TRY(sort_pairs_u64_u32(ctx, rec_key, skey, iota, perm_r, R, 0, 63));
+#endif
     hipLaunchKernelGGL(k_head_flags, dim3(grid_for(R)), dim3(256), 0, ctx->stream, skey, R, flags);
-    ME_TRY(exclusive_scan_u32(ctx, flags, pos, R));
+    ME_TRY(exclusive_scan_u32_plain(ctx, flags, pos, R));
     unsigned int last_pos = 0, last_flag = 0;
     unsigned long long last_key = 0;
     {
