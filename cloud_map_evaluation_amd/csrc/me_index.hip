@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "me_internal.hpp"
+#include "me_vox_rows.hpp"
 
 namespace me {
 
@@ -214,28 +215,37 @@ __global__ void k_morton(const double *__restrict__ xyz, long long n, double ox,
 // sorted points, and their Morton codes (the cell keys of every level; recomputed here rather than carried through the sort)
 // (packed != nullptr: the sorted (key, index) words of the keys-only sort, the index in the low bits under idx_mask)
 constexpr int kGatherPer = 4;  // sorted points per thread (round 6): the four index loads, then the twelve coordinate loads of a thread are in flight together
-__global__ void __launch_bounds__(256)
+constexpr int kGatherPerVox = 2;  // ... two when the gather also emits the voxel run records: with four it needs 88 vector registers, and a block
+// that needs more registers than a retiring k_mme3 block frees (64 per lane) waits for two of them to retire on the same SIMDs — the
+// ground truth's gather took 14 ms beside the map's MME (profiles/EXPERIMENTS.md "Round 6")
+// VOX (round 6): the gather also emits the run records of the one-pass voxel build (me_vox_rows.hpp) for the voxel size the context
+// carries as a hint (me_run_suite_from): it has the sorted points in registers and waits on random reads, the records' arithmetic
+// costs it little — and the voxel build that follows has no pass over the cloud left.
+template <bool VOX, int PER>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_gather(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, const unsigned long long *__restrict__ packed,
          unsigned long long idx_mask, long long n, double ox, double oy, double oz, double fine_h,
-         SPoint *__restrict__ sp, unsigned long long *__restrict__ codes) {
-    // (a block covers 256 x kGatherPer consecutive sorted points, a thread the points base + k * 256 + threadIdx.x: every store is coalesced)
-    const long long base = (long long) blockIdx.x * (256 * kGatherPer) + threadIdx.x;
-    unsigned int s[kGatherPer];
+         SPoint *__restrict__ sp, unsigned long long *__restrict__ codes, VoxPack vp, SlabView slab,
+         unsigned long long *__restrict__ rec_key, int *__restrict__ rec_n, double *__restrict__ rec_s, unsigned int *__restrict__ rec_cnt,
+         unsigned int n_rows, unsigned int rec_cap) {
+    // (a block covers 256 x PER consecutive sorted points, a thread the points base + k * 256 + threadIdx.x: every store is coalesced)
+    const long long base = (long long) blockIdx.x * (256 * PER) + threadIdx.x;
+    unsigned int s[PER];
 #pragma unroll
-    for (int k = 0; k < kGatherPer; ++k) {
+    for (int k = 0; k < PER; ++k) {
         const long long i = base + 256 * k;
         s[k] = i < n ? (packed ? (unsigned int) (packed[i] & idx_mask) : perm[i]) : 0u;
     }
-    double x[kGatherPer], y[kGatherPer], z[kGatherPer];
+    double x[PER], y[PER], z[PER];
 #pragma unroll
-    for (int k = 0; k < kGatherPer; ++k) {
+    for (int k = 0; k < PER; ++k) {
         x[k] = xyz[3 * (long long) s[k]];
         y[k] = xyz[3 * (long long) s[k] + 1];
         z[k] = xyz[3 * (long long) s[k] + 2];
     }
     const double lim = 2097151.0;
 #pragma unroll
-    for (int k = 0; k < kGatherPer; ++k) {
+    for (int k = 0; k < PER; ++k) {
         const long long i = base + 256 * k;
         if (i >= n) continue;
         SPoint p;
@@ -249,6 +259,14 @@ k_gather(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, 
         const unsigned int cy = (unsigned int) fmin(fmax(fine_coord(y[k], oy, fine_h), 0.0), lim);
         const unsigned int cz = (unsigned int) fmin(fmax(fine_coord(z[k], oz, fine_h), 0.0), lim);
         codes[i] = spread21((unsigned long long) cx) | (spread21((unsigned long long) cy) << 1) | (spread21((unsigned long long) cz) << 2);
+    }
+    if (VOX) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {  // (every lane of the row takes part: shuffles and ballots inside)
+            const long long i = base + 256 * k;
+            vox_emit_row(i < n, i, x[k], y[k], z[k], vp, slab, threadIdx.x & 63, rec_key, rec_n, rec_s, rec_cnt + 1, n_rows, rec_cap,
+                         reinterpret_cast<int *>(rec_cnt));
+        }
     }
 }
 
@@ -894,13 +912,37 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
         ME_TRY(sort_pairs_u64_u32(ctx, codes_in.as<unsigned long long>(), c.codes.as<unsigned long long>(),
                                   iota.as<unsigned int>(), perm.as<unsigned int>(), n, 3 * sort_min_level, 63));
     if (ctx->sort_hook) ctx->sort_hook(ctx->sort_hook_arg, ctx->stream);  // (me_run_suite_from: see SuiteLane::sort_queued)
+    // voxel run records on the side, when the context carries a voxel size for them (me_run_suite_from) and their sort key fits
+    VoxPack vp{};
+    c.vox_rec_valid = false;
+    const bool fuse_vox = ME_TUNE_VOX_ONEPASS && ctx->vox_hint > 0 && vox_make_pack(c, ctx->vox_hint, n, vp);
+    const long long rec_cap = vox_record_capacity(n);
+    if (fuse_vox) {
+        ME_CHECK(ctx, c.vox_rec_key.ensure((size_t) rec_cap * 8));
+        ME_CHECK(ctx, c.vox_rec_n.ensure((size_t) rec_cap * 4));
+        ME_CHECK(ctx, c.vox_rec_s.ensure((size_t) rec_cap * 8 * kVoxRec));
+        ME_CHECK(ctx, c.vox_rec_cnt.ensure(64));
+        ME_CHECK(ctx, hipMemsetAsync(c.vox_rec_key.p, 0xFF, (size_t) rec_cap * 8, ctx->stream));  // kVoxEmptySlot
+        ME_CHECK(ctx, hipMemsetAsync(c.vox_rec_cnt.p, 0, 8, ctx->stream));
+    }
     {
         TimerScope ts(ctx, "gather");
-        hipLaunchKernelGGL(k_gather, dim3(grid_for(n, 256 * kGatherPer)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),
-                           pack_bits > 0 ? (const unsigned int *) nullptr : perm.as<unsigned int>(),
-                           pack_bits > 0 ? perm.as<unsigned long long>() : (const unsigned long long *) nullptr,
-                           pack_bits > 0 ? ((1ULL << pack_bits) - 1ULL) : 0ULL, n, c.origin[0], c.origin[1], c.origin[2], c.fine_h,
-                           c.sp.as<SPoint>(), c.codes.as<unsigned long long>());
+#define ME_LAUNCH_GATHER(VOX_, PER_)                                                                                                     \
+    hipLaunchKernelGGL((k_gather<VOX_, PER_>), dim3(grid_for(n, 256 * PER_)), dim3(256), 0, ctx->stream, c.xyz.as<double>(),            \
+                       pack_bits > 0 ? (const unsigned int *) nullptr : perm.as<unsigned int>(),                                       \
+                       pack_bits > 0 ? perm.as<unsigned long long>() : (const unsigned long long *) nullptr,                           \
+                       pack_bits > 0 ? ((1ULL << pack_bits) - 1ULL) : 0ULL, n, c.origin[0], c.origin[1], c.origin[2], c.fine_h,        \
+                       c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), vp, c.slab, c.vox_rec_key.as<unsigned long long>(),        \
+                       c.vox_rec_n.as<int>(), c.vox_rec_s.as<double>(), c.vox_rec_cnt.as<unsigned int>(), (unsigned int) ((n + 63) / 64), \
+                       (unsigned int) rec_cap)
+        if (fuse_vox) ME_LAUNCH_GATHER(true, kGatherPerVox);
+        else ME_LAUNCH_GATHER(false, kGatherPer);
+#undef ME_LAUNCH_GATHER
+    }
+    if (fuse_vox) {
+        c.vox_rec_valid = true;
+        c.vox_rec_cap = rec_cap;
+        c.vox_rec_pack = vp;
     }
     // --- occupied cells per Morton level -> pick the 1-NN grid level; build the cell tables ---
     {

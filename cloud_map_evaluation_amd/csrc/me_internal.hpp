@@ -137,7 +137,22 @@ struct FrameView {
     double fine_h;      // edge of the finest (21-bit) cell
 };
 
+// sort key layout of the one-pass voxel build's run records (me_vox_rows.hpp)
+struct VoxPack {
+    double vs;
+    int min_x, min_y, min_z;   // smallest voxel index of the cloud's bounding box per axis
+    int bits_y, bits_z;        // bits of the y / z index ranges (x takes what is left)
+    int pos_bits;              // bits below the compact voxel key: row (i >> 6) and the run inside the row (6 bits)
+    unsigned long long sentinel;  // compact key of the halo points (slab mode): above every real one
+};
+
 struct Cloud {
+    // run records of the one-pass voxel build, emitted by the index build's gather when the context carries a voxel-size hint
+    // (me_run_suite_from): slot keys | populations | sums, the counter block [range error, appended records]
+    DevBuf vox_rec_key, vox_rec_n, vox_rec_s, vox_rec_cnt;
+    bool vox_rec_valid = false;
+    long long vox_rec_cap = 0;
+    VoxPack vox_rec_pack{};
     bool sort_pairs_hint = false;  // the keys-only sort had to cut the sort depth and the cloud was dense: use the pair sort (me_index.hip)
     long long hint_n = 0;          // ... for a cloud of this shape only (same count, lattice depth and cell edge)
     int hint_shift = 0;
@@ -257,6 +272,7 @@ struct me_ctx {
     bool borrow_device_input = false;   // me_create flag ME_FLAG_BORROW_DEVICE_INPUT
     bool morton_order = false;          // me_create flag ME_FLAG_MORTON_ORDER: points sorted along the Z curve instead of the Hilbert curve
     me::SlabView slab{-1, 0, 0, 0, 0};  // applied to the next uploads
+    double vox_hint = 0;                // > 0: index builds also emit the voxel run records for this voxel size (me_run_suite_from)
     // instrumentation
     bool timers_on = false;
     std::map<std::string, me::TimerRec> timers;
@@ -374,6 +390,9 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
 #endif
 #ifndef ME_TUNE_VOX_MERGE_SORT
 #define ME_TUNE_VOX_MERGE_SORT 1  // voxel run records sorted by rocPRIM's merge sort (plain kernels) instead of its onesweep radix sort
+#endif
+#ifndef ME_TUNE_VOX_ONEPASS
+#define ME_TUNE_VOX_ONEPASS 1     // voxel tables from ONE pass over the sorted cloud (records about the voxel centres; 0: the three-pass build)
 #endif
 #ifndef ME_TUNE_SUITE_NN_FIRST
 #define ME_TUNE_SUITE_NN_FIRST 1  // me_run_suite_from, second lane: the reverse 1-NN search before the voxel tables (0: round 5's order)

@@ -324,6 +324,19 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
     std::memset(out, 0, sizeof(*out));
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     const auto t_all = Clock::now();
+    // the index builds of this call also emit the voxel run records for vmd_voxel_size (me_index.hip: k_gather<VOX>), on both lanes
+    struct VoxHint {
+        me_ctx *a, *b = nullptr;
+        VoxHint(me_ctx *c, double v) : a(c) { a->vox_hint = v; }
+        void also(me_ctx *t, double v) {
+            b = t;
+            if (b) b->vox_hint = v;
+        }
+        ~VoxHint() {
+            a->vox_hint = 0;
+            if (b) b->vox_hint = 0;
+        }
+    } vox_hint(ctx, upload ? p->vmd_voxel_size : 0.0);
 
     if (!upload) {
         // Resident clouds: with two lanes both start at once on the SAME two Cloud objects, and a stage that finds a
@@ -342,6 +355,7 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
     if (overlap) {
         lane.t = me_twin(ctx);
         if (!lane.t) return ME_ERR_HIP;  // (me_twin has set the message)
+        vox_hint.also(lane.t, upload ? p->vmd_voxel_size : 0.0);
         worker = lane_worker(ctx);
         if (!worker) return ME_ERR_HIP;
         lane.p = p;

@@ -13,20 +13,9 @@
 #include <cmath>
 
 #include "me_internal.hpp"
+#include "me_vox_rows.hpp"
 
 namespace me {
-
-constexpr int kKeyBias = 1 << 20;
-
-__device__ __host__ __forceinline__ unsigned long long pack_key(int kx, int ky, int kz) {
-    return ((unsigned long long) (unsigned int) (kx + kKeyBias) << 42) |
-           ((unsigned long long) (unsigned int) (ky + kKeyBias) << 21) | (unsigned long long) (unsigned int) (kz + kKeyBias);
-}
-__device__ __host__ __forceinline__ void unpack_key(unsigned long long k, int &kx, int &ky, int &kz) {
-    kx = (int) ((k >> 42) & 0x1fffff) - kKeyBias;
-    ky = (int) ((k >> 21) & 0x1fffff) - kKeyBias;
-    kz = (int) (k & 0x1fffff) - kKeyBias;
-}
 
 constexpr unsigned long long kVoxSentinel = 0x7fffffffffffffffULL;  // sorts after every real key
 
@@ -79,46 +68,6 @@ __device__ __forceinline__ RunLane wave_runs(const SPoint *__restrict__ sp, long
     r.run_local = __popcll(hm & ((2ULL << lane) - 1ULL)) - 1;
     r.seg = r.valid ? r.run_local : 64 + lane;
     return r;
-}
-
-// sum over the lanes of the same (contiguous) segment, delivered to the segment's first lane
-__device__ __forceinline__ double seg_sum_to_head(double v, int seg, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double ov = __shfl_down(v, o, 64);
-        const int os = __shfl_down(seg, o, 64);
-        if (lane + o < 64 && os == seg) v += ov;
-    }
-    return v;
-}
-// Sum over the WHOLE wave delivered to lane 0, on the vector unit (round 6): four DPP row shifts leave each row's sum in its first
-// lane, three readlanes add the rows.  The segmented sums above cost three ds_bpermute per value and stage — 108 LDS-pipe operations
-// per wavefront in k_vox_pass2, which made the voxel passes LDS-bound (0.5 ms per pass and 50 M points where the 1.6 GB they read
-// take 0.33) — and a 3 m voxel holds thousands of consecutive sorted points: nearly every wavefront is ONE run.
-__device__ __forceinline__ double wave_sum_to_lane0(double v) {
-#define ME_ROW_SHL_ADD(N)                                                                                                    \
-    {                                                                                                                        \
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + (N), 0xF, 0xF, true);                       \
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + (N), 0xF, 0xF, true);                       \
-        v += __hiloint2double(hi, lo);                                                                                       \
-    }
-    ME_ROW_SHL_ADD(1)
-    ME_ROW_SHL_ADD(2)
-    ME_ROW_SHL_ADD(4)
-    ME_ROW_SHL_ADD(8)
-#undef ME_ROW_SHL_ADD
-    auto row = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
-    return ((row(0) + row(16)) + (row(32) + row(48)));  // (wave-uniform; lane 0 uses it)
-}
-
-__device__ __forceinline__ int seg_sum_to_head_i(int v, int seg, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int ov = __shfl_down(v, o, 64);
-        const int os = __shfl_down(seg, o, 64);
-        if (lane + o < 64 && os == seg) v += ov;
-    }
-    return v;
 }
 
 __global__ void __launch_bounds__(256)
@@ -306,6 +255,117 @@ k_vox_final(const unsigned int *__restrict__ perm_r, const unsigned int *__restr
         for (int k = 0; k < 9; ++k) vsig[9 * v + k] = S[k];
         vent[v] = ent;
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// ONE pass over the sorted cloud (round 6).  The three-pass build above reads `sp` three times (run counts, per-run sums, per-run
+// centred products about the voxel's mean — which only exists after the second pass).  A voxel's CENTRE is known from its key alone:
+// every run emits (n, sum d, sum d d^T) with d = p - centre (|d| <= half a voxel diagonal), the records are sorted, one wavefront
+// per voxel adds them up and forms   mu = centre + S1 / n,   M2 = S2 - S1 S1^T / n.   The cancellation costs |mu - centre|^2 against
+// the matrix's own scale — a few eps; the tests' tolerance is 1e-9 of that scale.  No counting pass either: every row of 64 sorted
+// points owns TWO record slots (its first two runs: a row that crosses a voxel face has two, hardly any has more), further runs are
+// appended behind the rows' slots with one atomic per such row (a first version appended every record: 780 k atomics on one
+// counter, 8 ms per 50 M points; one slot per row and an atomic for every second run: 60 k atomics, still 0.5 ms).  The used slots
+// are compacted (flags + a plain scan), the survivors sorted by key; the order inside a voxel is the sorted cloud's (the merge sort
+// is stable and the slots are laid out in row order, the appended ones — runs 3.. of their rows — behind: a fixed order too, because
+// a record's KEY carries its row and run number below the voxel's bits).
+// Same rows, same runs as the three-pass build: keys and populations identical, means and covariances equal to rounding.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_vox_records(const SPoint *__restrict__ sp, long long n, VoxPack vp, SlabView slab, unsigned long long *__restrict__ rec_key,
+              int *__restrict__ rec_n, double *__restrict__ rec_s, unsigned int *__restrict__ rec_count, unsigned int n_rows,
+              unsigned int cap, int *__restrict__ err) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    double x = 0, y = 0, z = 0;
+    if (valid) {
+        const SPoint p = sp[i];
+        x = p.x;
+        y = p.y;
+        z = p.z;
+    }
+    vox_emit_row(valid, i, x, y, z, vp, slab, threadIdx.x & 63, rec_key, rec_n, rec_s, rec_count, n_rows, cap, err);
+}
+
+__global__ void k_used_flags(const unsigned long long *__restrict__ keys, long long n, unsigned int *__restrict__ flags) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = keys[i] != kVoxEmptySlot ? 1u : 0u;
+}
+// the used slots, in slot order: (key, slot index) pairs for the sort
+__global__ void k_compact_used(const unsigned long long *__restrict__ keys, const unsigned int *__restrict__ flags,
+                               const unsigned int *__restrict__ pos, long long n, unsigned long long *__restrict__ ckey,
+                               unsigned int *__restrict__ cidx) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flags[i]) {
+        ckey[pos[i]] = keys[i];
+        cidx[pos[i]] = (unsigned int) i;
+    }
+}
+
+__global__ void k_head_flags_shifted(const unsigned long long *__restrict__ keys, long long n, int shift, unsigned int *__restrict__ flags) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) ? 1u : 0u;
+}
+
+// one wavefront per voxel: the records of the voxel in sorted order (= the sorted cloud's order) -> n, mu, M2, and the reference's
+// finalisation (as k_vox_final)
+__global__ void __launch_bounds__(256)
+k_vox_reduce(const unsigned long long *__restrict__ skey, const unsigned int *__restrict__ perm_r, const unsigned int *__restrict__ seg_start,
+             long long n_vox, VoxPack vp, const int *__restrict__ rec_n, const double *__restrict__ rec_s, int raw,
+             unsigned long long *__restrict__ vkey, int *__restrict__ vn, double *__restrict__ vmu, double *__restrict__ vsig,
+             double *__restrict__ vent) {
+    const int lane = threadIdx.x & 63;
+    const long long v = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_vox) return;
+    const long long b = seg_start[v], e = seg_start[v + 1];
+    long long cnt = 0;
+    double a[kVoxRec];
+#pragma unroll
+    for (int k = 0; k < kVoxRec; ++k) a[k] = 0.0;
+    for (long long j = b + lane; j < e; j += 64) {
+        const long long r = perm_r[j];
+        cnt += rec_n[r];
+#pragma unroll
+        for (int k = 0; k < kVoxRec; ++k) a[k] += rec_s[kVoxRec * r + k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+#pragma unroll
+    for (int k = 0; k < kVoxRec; ++k) a[k] = wave_allsum(a[k]);
+    if (lane != 0) return;
+    const unsigned long long ck = skey[b] >> vp.pos_bits;
+    const int ix = (int) (ck >> (vp.bits_y + vp.bits_z)) + vp.min_x;
+    const int iy = (int) ((ck >> vp.bits_z) & ((1ULL << vp.bits_y) - 1ULL)) + vp.min_y;
+    const int iz = (int) (ck & ((1ULL << vp.bits_z) - 1ULL)) + vp.min_z;
+    vkey[v] = pack_key(ix, iy, iz);
+    vn[v] = (int) cnt;
+    const double nn = (double) cnt;
+    const double mx = a[0] / nn, my = a[1] / nn, mz = a[2] / nn;  // mean offset from the voxel's centre
+    vmu[3 * v] = ((double) ix + 0.5) * vp.vs + mx;
+    vmu[3 * v + 1] = ((double) iy + 0.5) * vp.vs + my;
+    vmu[3 * v + 2] = ((double) iz + 0.5) * vp.vs + mz;
+    // M2 = sum (p - mu)(p - mu)^T = S2 - S1 S1^T / n (Welford's S, voxel_calculator.cpp:41)
+    const double cxx = a[3] - a[0] * mx, cxy = a[4] - a[0] * my, cxz = a[5] - a[0] * mz;
+    const double cyy = a[6] - a[1] * my, cyz = a[7] - a[1] * mz, czz = a[8] - a[2] * mz;
+    double S[9] = {cxx, cxy, cxz, cxy, cyy, cyz, cxz, cyz, czz};
+    double ent = 0.0;
+    if (cnt > 10 && !raw) {  // (:47); raw = keep M2 undivided (multi-GPU partials)
+        const double nm1 = (double) (cnt - 1);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S[k] = S[k] / nm1;  // first division (:48)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S[k] = S[k] / nm1;  // second division, computeVoxelEntropy (:102)
+        const double det = det3_rowmajor(S);
+        if (det > 0) {
+            const double PI = 3.141592653589793238463;
+            ent = 0.5 * log(pow(2 * PI * exp(1.0), 3.0) * det);  // (:109)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) vsig[9 * v + k] = S[k];
+    vent[v] = ent;
 }
 
 // ---- join est x gt on the packed key (both ascending) ----
@@ -716,6 +776,133 @@ int scs_table(me_ctx *ctx, const int32_t *keys, const double *w, long long n, in
     return ME_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// host side of the one-pass build
+static int voxel_build_onepass(me_ctx *ctx, Cloud &c, double voxel_size, bool raw, const VoxPack &vp, int *d_err) {
+    const long long n = c.n;
+    const SPoint *sp = c.sp.as<SPoint>();
+    unsigned int *d_cnt = reinterpret_cast<unsigned int *>(d_err) + 1;
+    const long long nw = (n + 63) / 64;  // rows of 64 sorted points: two record slots each, further runs behind them
+    DevBuf &kbuf = ctx->tmp[1], &sbuf = ctx->tmp[2], &ibuf = ctx->tmp[3], &mbuf = ctx->tmp[4];  // (tmp[5]: sort / scan scratch)
+    long long cap = vox_record_capacity(n), S = 0;
+    // the records the index build's gather left on the cloud (same rows, same arithmetic: me_vox_rows.hpp), when they are for this
+    // voxel size and all fitted; otherwise the pass below
+    bool fused = c.vox_rec_valid && c.vox_rec_pack.vs == voxel_size && c.vox_rec_cap == cap;
+    const unsigned long long *slot_key_src = nullptr;
+    const int *rec_n_src = nullptr;
+    const double *rec_s_src = nullptr;
+    if (fused) {
+        unsigned int h2[2] = {0, 0};
+        {
+            MailGuard mg(ctx);
+            ME_TRY(mail_post(ctx, h2, c.vox_rec_cnt.p, 8));
+            ME_TRY(mg.sync());
+        }
+        if (h2[0]) return ctx->fail(ME_ERR_ARG, "voxel index out of range (|floor(p/voxel_size)| must be < 2^20)");
+        S = 2 * nw + (long long) h2[1];
+        if (S > cap) fused = false;  // (more appended runs than there was room for: the pass below, with room)
+    }
+    if (fused) {
+        slot_key_src = c.vox_rec_key.as<unsigned long long>();
+        rec_n_src = c.vox_rec_n.as<int>();
+        rec_s_src = c.vox_rec_s.as<double>();
+        ME_CHECK(ctx, kbuf.ensure((size_t) cap * 24));
+        ME_CHECK(ctx, ibuf.ensure((size_t) cap * 12));
+        ME_CHECK(ctx, mbuf.ensure((size_t) cap * 8 + 64));
+    }
+    for (int attempt = 0; attempt < 2 && !fused; ++attempt) {
+        ME_CHECK(ctx, kbuf.ensure((size_t) cap * 24));      // slot keys | compacted keys | sorted keys
+        ME_CHECK(ctx, sbuf.ensure((size_t) cap * 8 * kVoxRec));
+        ME_CHECK(ctx, ibuf.ensure((size_t) cap * 12));      // rec_n | compacted slot indices | sorted slot indices
+        ME_CHECK(ctx, mbuf.ensure((size_t) cap * 8 + 64));  // flags | positions
+        unsigned long long *slot_key_w = kbuf.as<unsigned long long>();
+        int *rec_n_w = ibuf.as<int>();
+        ME_CHECK(ctx, hipMemsetAsync(slot_key_w, 0xFF, (size_t) cap * 8, ctx->stream));  // kVoxEmptySlot
+        ME_CHECK(ctx, hipMemsetAsync(d_err, 0, 8, ctx->stream));
+        {
+            TimerScope ts(ctx, "voxel");
+            hipLaunchKernelGGL(k_vox_records, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sp, n, vp, c.slab, slot_key_w, rec_n_w, sbuf.as<double>(),
+                               d_cnt, (unsigned int) nw, (unsigned int) cap, d_err);
+        }
+        unsigned int h_cnt = 0;
+        int h_err = 0;
+        {
+            MailGuard mg(ctx);
+            ME_TRY(mail_post(ctx, &h_cnt, d_cnt, 4));
+            ME_TRY(mail_post(ctx, &h_err, d_err, 4));
+            ME_TRY(mg.sync());
+        }
+        if (h_err) return ctx->fail(ME_ERR_ARG, "voxel index out of range (|floor(p/voxel_size)| must be < 2^20)");
+        S = 2 * nw + (long long) h_cnt;  // slots in use (with holes: the unused second slots of the rows)
+        if (S <= cap) {
+            slot_key_src = kbuf.as<unsigned long long>();
+            rec_n_src = ibuf.as<int>();
+            rec_s_src = sbuf.as<double>();
+            break;
+        }
+        if (attempt == 1) return ctx->fail(ME_ERR_STATE, "voxel pass: record count changed between two passes");
+        cap = S;  // (rows with three and more runs all over: scattered outliers, a voxel smaller than a row's extent) once more
+    }
+    unsigned long long *ckey = kbuf.as<unsigned long long>() + cap, *skey = ckey + cap;
+    const unsigned long long *slot_key = slot_key_src;
+    const int *rec_n = rec_n_src;
+    unsigned int *cidx = ibuf.as<unsigned int>() + cap, *perm_r = cidx + cap;
+    unsigned int *flags = mbuf.as<unsigned int>(), *pos = flags + cap;
+    // the used slots, compacted in slot order
+    hipLaunchKernelGGL(k_used_flags, dim3(grid_for(S)), dim3(256), 0, ctx->stream, slot_key, S, flags);
+    ME_TRY(exclusive_scan_u32_plain(ctx, flags, pos, S));
+    unsigned int last_pos = 0, last_flag = 0;
+    {
+        MailGuard mg(ctx);
+        ME_TRY(mail_post(ctx, &last_pos, pos + (S - 1), 4));
+        ME_TRY(mail_post(ctx, &last_flag, flags + (S - 1), 4));
+        ME_TRY(mg.sync());
+    }
+    const long long R = (long long) last_pos + last_flag;  // run records
+    hipLaunchKernelGGL(k_compact_used, dim3(grid_for(S)), dim3(256), 0, ctx->stream, slot_key, (const unsigned int *) flags,
+                       (const unsigned int *) pos, S, ckey, cidx);
+    ME_TRY(sort_pairs_merge_u64_u32(ctx, ckey, skey, cidx, perm_r, R));
+    hipLaunchKernelGGL(k_head_flags_shifted, dim3(grid_for(R)), dim3(256), 0, ctx->stream, (const unsigned long long *) skey, R, vp.pos_bits, flags);
+    ME_TRY(exclusive_scan_u32_plain(ctx, flags, pos, R));
+    unsigned long long last_key = 0;
+    {
+        MailGuard mg(ctx);
+        ME_TRY(mail_post(ctx, &last_pos, pos + (R - 1), 4));
+        ME_TRY(mail_post(ctx, &last_flag, flags + (R - 1), 4));
+        ME_TRY(mail_post(ctx, &last_key, skey + (R - 1), 8));
+        ME_TRY(mg.sync());
+    }
+    long long V = (long long) last_pos + last_flag;
+    const bool has_sentinel = c.slab.axis >= 0 && (last_key >> vp.pos_bits) == vp.sentinel;
+    if (has_sentinel) V -= 1;  // the halo points' segment (the last one) is dropped
+    ME_CHECK(ctx, c.vox_tmp.ensure((size_t) (V + 2) * 4));
+    unsigned int *seg_start = c.vox_tmp.as<unsigned int>();
+    ME_CHECK(ctx, c.vox_key.ensure((size_t) (V + 1) * 8));
+    ME_CHECK(ctx, c.vox_n.ensure((size_t) std::max<long long>(V, 1) * 4));
+    ME_CHECK(ctx, c.vox_mu.ensure((size_t) std::max<long long>(V, 1) * 24));
+    ME_CHECK(ctx, c.vox_sigma.ensure((size_t) std::max<long long>(V, 1) * 72));
+    ME_CHECK(ctx, c.vox_entropy.ensure((size_t) std::max<long long>(V, 1) * 8));
+    // (k_seg_scatter also writes the heads' keys: into ckey, dead since the sort)
+    hipLaunchKernelGGL(k_seg_scatter, dim3(grid_for(R)), dim3(256), 0, ctx->stream, (const unsigned long long *) skey, (const unsigned int *) flags,
+                       (const unsigned int *) pos, R, ckey, seg_start);
+    if (!has_sentinel) hipLaunchKernelGGL(k_set_u32v, dim3(1), dim3(1), 0, ctx->stream, seg_start, V, (unsigned int) R);
+    if (V > 0) {
+        TimerScope ts(ctx, "voxel");
+        hipLaunchKernelGGL(k_vox_reduce, dim3((unsigned int) ((V + 3) / 4)), dim3(256), 0, ctx->stream, (const unsigned long long *) skey,
+                           (const unsigned int *) perm_r, (const unsigned int *) seg_start, V, vp, rec_n, rec_s_src,
+                           raw ? 1 : 0, c.vox_key.as<unsigned long long>(), c.vox_n.as<int>(), c.vox_mu.as<double>(), c.vox_sigma.as<double>(),
+                           c.vox_entropy.as<double>());
+    }
+    ME_CHECK(ctx, hipGetLastError());
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    c.n_vox = V;
+    c.vox_size = voxel_size;
+    c.vox_raw = raw;
+    c.vox_valid = true;
+    return ME_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
     if (slot < 0 || slot > 1) return ctx->fail(ME_ERR_ARG, "bad slot");
@@ -740,7 +927,13 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
     const SPoint *sp = c.sp.as<SPoint>();
     ME_CHECK(ctx, ctx->red.ensure(64));
     int *d_err = ctx->red.as<int>();
-    ME_CHECK(ctx, hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    ME_CHECK(ctx, hipMemsetAsync(d_err, 0, 8, ctx->stream));  // [0] index-range error flag, [1] record counter of the one-pass build
+#if ME_TUNE_VOX_ONEPASS
+    {
+        VoxPack vp;
+        if (vox_make_pack(c, voxel_size, n, vp)) return voxel_build_onepass(ctx, c, voxel_size, raw, vp, d_err);
+    }
+#endif
     // --- runs per wavefront -> record offsets ---
     DevBuf &wbuf = ctx->tmp[0];
     ME_CHECK(ctx, wbuf.ensure((size_t) nw * 8));
