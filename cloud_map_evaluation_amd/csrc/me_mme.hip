@@ -2,25 +2,26 @@
 // (ComputeMeanMapEntropyUsingNormalTBB map_eval.cpp:1608-1737; the OpenMP and serial variants :1538-1606,
 //  :1438-1535 compute the same thing with k >= 10 / k >= 5).
 //
-// Mapping.  Points are Morton-sorted on a grid whose cell edge is (a hair above) the search radius, so the
-// neighbours of every point of a cell lie in the 3x3x3 block around it, and each cell is one contiguous run of
-// the sorted array.  A wavefront owns 64 consecutive sorted points.  Per round (usually one or two per wave) it
-//   * groups the lanes whose cell is within Chebyshev distance 2 of the leader's (normally the whole wave) and resolves the
-//     group's cell box grown by one with one hash probe per (lane, slot) into a wave-private LDS run table
-//     (wave_group_table),
-//   * streams every non-empty run ONCE with WAVE-UNIFORM addresses (one fetch feeds all 64 lanes; the compiler turns
-//     it into scalar loads, the candidate sits in SGPRs), every group lane testing it against its own query in fp64.
-// rocprofv3 SQ counters put this kernel at ~80 % of the fp64 VALU issue rate: it is bound by the candidate tests, not by
-// memory.  It is tuned to 64 VGPRs (8 waves per SIMD: the scalar fetches are L2 round trips that only other waves can
-// hide); the run table lives in LDS and the 64-bit point index is rebuilt where needed for that reason, and the four
-// registers the allocator still spills are touched in the prologue / epilogue only.  A per-lane walk (fewer candidates
-// per lane) was measured slower (vector-L1 tag-lookup bound), half-radius cells with a 5x5x5 stencil likewise (same
-// union, 6x the probes), sub-wave groups as well (profiles/README.md).
-// The reference materialises index/distance vectors per query and gathers a 3xk matrix; here nothing is
-// materialised: k, sum(p-q) and sum((p-q)(p-q)^T) are accumulated in registers about the QUERY as origin
-// (|p-q| < r, so the one-pass covariance is as well conditioned as the reference's two-pass one).
-// The query itself (d2 == 0, the element the reference erases at :1672-1673) contributes zero to both sums, so
-// dropping it is `k - 1`.
+// Mapping.  Points are sorted along the Hilbert curve on a grid whose cell edge is (a hair above) the search radius, so the
+// neighbours of every point of a cell lie in the 3x3x3 block around it, and each cell is one contiguous run of the sorted array.
+// A wavefront owns 64 consecutive sorted points.  Per round (1.2 per wave on the bench's map, 1.07 on its ground truth) it
+//   * groups the lanes whose cell is within Chebyshev distance 2 of a leader's (the best of five candidates along the pending
+//     stretch; normally the whole wave) and resolves the group's cell box grown by one with one hash probe per (lane, slot) into a
+//     wave-private LDS run table, runs adjacent to no lane of the group culled (wave_group_table<1, true>),
+//   * stages every run ONCE through a wave-private LDS tile — one coalesced vector load per 32 points, the staging lane storing an
+//     FP32 record (p', |p'|^2) and u = p - o in fp64, o = the leader's point — and reads it back with broadcast ds_reads, every
+//     group lane testing the candidate against its own query: an FP32 pre-test with an exact fp64 band (k_mme3 below), then
+//     k, sum(u), sum(u u^T) accumulated straight from the tile (the covariance is translation-invariant; the sums start at minus
+//     the lane's own contribution: the element the reference erases at :1672-1673).
+// The kernel is bound by vector instruction issue (96 % busy: profiles/r04_mme3_c4_sq_per_wave.json): 57 VGPRs, eight waves per
+// SIMD, no scratch; per step on the 50 M + 50 M pair (ME_MME_DBG builds, round 6) table + prologue + epilogue 3.3 ms, staging 4.7
+// (hidden by the other waves in the full kernel: prefetching the next chunk made it slower), the pre-test 6.7, the accumulation —
+// nine fp64 instructions for every candidate SOME lane accepts, at 12 - 17 % lane efficiency — 8.4.  What was measured and dropped
+// (a per-lane walk, half-radius cells, sub-wave groups, scalar-cache delivery, readlane broadcasts, per-lane compaction, streaming
+// waves, the f32 / int8 matrix pipes, per-octet candidate streams): profiles/EXPERIMENTS.md.
+// The reference materialises index / distance vectors per query and gathers a 3 x k matrix; here nothing is materialised.
+// Neighbourhoods so thin that the rounding of the leader-origin sums would show (smallest covariance eigenvalue below ~1.8e-6
+// cell^2) are recomputed two-pass about the query itself by k_mme_refine.
 #include <cmath>
 #include <cstdlib>
 

@@ -11,12 +11,16 @@
 //   main lane (ctx, highest stream priority)            second lane (twin, lowest priority)
 //   ---------------------------------------            ----------------------------------------------------------------
 //   upload + index the map                              [host input: wait until the map has crossed the link]
-//   MME of the map            (VALU-bound)              upload + index the ground truth     (HBM-bound, under the MME)
-//   [T: transform + re-index the map, :1206]            voxel Gaussians of the ground truth
-//   [host input: voxel Gaussians of the map]
-//   wait: ground truth indexed                          wait: map final
-//   MME of the ground truth                             voxel Gaussians of the map
-//   1-NN map -> ground truth + partial sums             1-NN ground truth -> map + partial sums
+//   (the gathers also emit the voxel run records        upload + index the ground truth  (its radix sort BEFORE the map's MME
+//    for vmd_voxel_size: me_vox_rows.hpp)                starts: onesweep crawls beside a full chip; the rest under that MME)
+//   wait: ground truth's sort queued (event)
+//   MME of the map            (VALU-bound)              wait: map final
+//   [T: transform + re-index the map, :1206]            1-NN ground truth -> map + partial sums
+//   [host input: voxel Gaussians of the map]            voxel Gaussians of the ground truth (sort + reduce of its records)
+//   wait: ground truth indexed                          voxel Gaussians of the map, unless the main lane got there first
+//   MME of the ground truth
+//   1-NN map -> ground truth + partial sums
+//   voxel Gaussians of the map, unless the second lane got there first
 //   join; sigma passes; AWD / CDF / SCS
 #include <atomic>
 #include <chrono>
