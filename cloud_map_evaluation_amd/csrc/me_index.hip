@@ -264,7 +264,7 @@ k_gather(const double *__restrict__ xyz, const unsigned int *__restrict__ perm, 
 #pragma unroll
         for (int k = 0; k < PER; ++k) {  // (every lane of the row takes part: shuffles and ballots inside)
             const long long i = base + 256 * k;
-            vox_emit_row(i < n, i, x[k], y[k], z[k], vp, slab, threadIdx.x & 63, rec_key, rec_n, rec_s, rec_cnt + 1, n_rows, rec_cap,
+            vox_emit_row(i < n, i, x[k], y[k], z[k], vp, slab, threadIdx.x & 63, rec_key, rec_n, rec_s, rec_cnt + 2, n_rows, rec_cap,
                          reinterpret_cast<int *>(rec_cnt));
         }
     }
@@ -921,9 +921,9 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
         ME_CHECK(ctx, c.vox_rec_key.ensure((size_t) rec_cap * 8));
         ME_CHECK(ctx, c.vox_rec_n.ensure((size_t) rec_cap * 4));
         ME_CHECK(ctx, c.vox_rec_s.ensure((size_t) rec_cap * 8 * kVoxRec));
-        ME_CHECK(ctx, c.vox_rec_cnt.ensure(64));
+        ME_CHECK(ctx, c.vox_rec_cnt.ensure(kVoxCounterBytes));
         ME_CHECK(ctx, hipMemsetAsync(c.vox_rec_key.p, 0xFF, (size_t) rec_cap * 8, ctx->stream));  // kVoxEmptySlot
-        ME_CHECK(ctx, hipMemsetAsync(c.vox_rec_cnt.p, 0, 8, ctx->stream));
+        ME_CHECK(ctx, hipMemsetAsync(c.vox_rec_cnt.p, 0, kVoxCounterBytes, ctx->stream));
     }
     {
         TimerScope ts(ctx, "gather");
@@ -934,7 +934,7 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
                        pack_bits > 0 ? ((1ULL << pack_bits) - 1ULL) : 0ULL, n, c.origin[0], c.origin[1], c.origin[2], c.fine_h,        \
                        c.sp.as<SPoint>(), c.codes.as<unsigned long long>(), vp, c.slab, c.vox_rec_key.as<unsigned long long>(),        \
                        c.vox_rec_n.as<int>(), c.vox_rec_s.as<double>(), c.vox_rec_cnt.as<unsigned int>(), (unsigned int) ((n + 63) / 64), \
-                       (unsigned int) rec_cap)
+                       (unsigned int) vox_region_size(n))
         if (fuse_vox) ME_LAUNCH_GATHER(true, kGatherPerVox);
         else ME_LAUNCH_GATHER(false, kGatherPer);
 #undef ME_LAUNCH_GATHER

@@ -64,6 +64,7 @@ __device__ __forceinline__ int seg_sum_to_head_i(int v, int seg, int lane) {
 
 
 constexpr unsigned long long kVoxEmptySlot = ~0ULL;
+constexpr unsigned int kVoxRegions = 4096;  // overflow regions (a power of two)
 
 __device__ __forceinline__ unsigned long long vox_compact_key(double x, double y, double z, const VoxPack &vp, const SlabView &slab,
                                                              int *__restrict__ err, double &cx, double &cy, double &cz) {
@@ -89,7 +90,7 @@ constexpr int kVoxRec = 9;  // doubles per record: sum d (3), sum d d^T (xx, xy,
 __device__ __forceinline__ void vox_emit_row(bool valid, long long i, double x, double y, double z, const VoxPack &vp, const SlabView &slab,
                                              int lane, unsigned long long *__restrict__ rec_key, int *__restrict__ rec_n,
                                              double *__restrict__ rec_s, unsigned int *__restrict__ rec_count, unsigned int n_rows,
-                                             unsigned int cap, int *__restrict__ err) {
+                                             unsigned int region_size, int *__restrict__ err) {
     double cx, cy, cz;
     const unsigned long long key = valid ? vox_compact_key(x, y, z, vp, slab, err, cx, cy, cz) : ~0ULL;
     const unsigned long long prev = __shfl_up(key, 1, 64);
@@ -110,16 +111,22 @@ __device__ __forceinline__ void vox_emit_row(bool valid, long long i, double x, 
 #pragma unroll
         for (int k = 0; k < kVoxRec; ++k) v[k] = seg_sum_to_head(v[k], seg, lane);
     }
+    // record slots: two per row; the further runs of a row go to one of kVoxRegions regions behind the rows' slots (the region of
+    // row r is r mod kVoxRegions: neighbouring rows — which cross the same voxel faces — spread over the regions), reserved with
+    // one atomic per such row on the REGION's counter: on one counter for the whole cloud, 10^5 - 10^6 atomics went through one L2
+    // channel (0.5 - 8 ms).  A region that overflows is counted, not stored: the host sees it and takes the three-pass build.
     unsigned int base = 0;
     const int extra = __popcll(hm) - 2;  // runs beyond the row's two slots
+    const unsigned int region = (unsigned int) (i >> 6) & (kVoxRegions - 1);
     if (extra > 0) {
-        if (lane == 0) base = atomicAdd(rec_count, (unsigned int) extra);
+        if (lane == 0) base = atomicAdd(rec_count + region, (unsigned int) extra);
         base = (unsigned int) __builtin_amdgcn_readfirstlane((int) base);
     }
     if (head) {
+        const bool fits = run_local < 2 || base + (unsigned int) (run_local - 2) < region_size;
         const unsigned int r = run_local < 2 ? 2u * (unsigned int) (i >> 6) + (unsigned int) run_local
-                                             : 2u * n_rows + base + (unsigned int) (run_local - 2);
-        if (r < cap) {  // (past the capacity: counted, not stored — the host runs the pass again with room for all)
+                                             : 2u * n_rows + region * region_size + base + (unsigned int) (run_local - 2);
+        if (fits) {
             rec_key[r] = (key << vp.pos_bits) | ((unsigned long long) (i >> 6) << 6) | (unsigned long long) run_local;
             rec_n[r] = cnt;
 #pragma unroll
@@ -157,7 +164,11 @@ inline bool vox_make_pack(const Cloud &c, double vs, long long n, VoxPack &vp) {
     vp.sentinel = 1ULL << (bx + by + bz);  // one above every real compact key
     return bx + by + bz + 1 + vp.pos_bits <= 63;  // (bit 63 stays clear: kVoxEmptySlot is no record's key)
 }
-// record slots of a cloud of n points: two per row of 64, room for the further runs behind them
-inline long long vox_record_capacity(long long n) { return 2 * ((n + 63) / 64) + n / 256 + 4096; }
+// record slots of a cloud of n points: two per row of 64, then kVoxRegions regions for the further runs — together as many again
+// (a row crosses a voxel face, or holds an outlier of another voxel, more often than one would think: 10 - 70 % of the rows
+// of the bench's clouds have three or more runs)
+inline long long vox_region_size(long long n) { return (2 * ((n + 63) / 64) + kVoxRegions - 1) / kVoxRegions + 16; }
+inline long long vox_record_capacity(long long n) { return 2 * ((n + 63) / 64) + (long long) kVoxRegions * vox_region_size(n); }
+constexpr size_t kVoxCounterBytes = (size_t) (2 + kVoxRegions) * 4;  // [range error, max region fill (k_vox_region_max)] + the regions' counters
 
 }  // namespace me

@@ -275,7 +275,7 @@ k_vox_final(const unsigned int *__restrict__ perm_r, const unsigned int *__restr
 __global__ void __launch_bounds__(256)
 k_vox_records(const SPoint *__restrict__ sp, long long n, VoxPack vp, SlabView slab, unsigned long long *__restrict__ rec_key,
               int *__restrict__ rec_n, double *__restrict__ rec_s, unsigned int *__restrict__ rec_count, unsigned int n_rows,
-              unsigned int cap, int *__restrict__ err) {
+              unsigned int region_size, int *__restrict__ err) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     double x = 0, y = 0, z = 0;
@@ -285,7 +285,19 @@ k_vox_records(const SPoint *__restrict__ sp, long long n, VoxPack vp, SlabView s
         y = p.y;
         z = p.z;
     }
-    vox_emit_row(valid, i, x, y, z, vp, slab, threadIdx.x & 63, rec_key, rec_n, rec_s, rec_count, n_rows, cap, err);
+    vox_emit_row(valid, i, x, y, z, vp, slab, threadIdx.x & 63, rec_key, rec_n, rec_s, rec_count, n_rows, region_size, err);
+}
+
+// the fullest overflow region -> cnt[1] (the host compares it with the region size)
+__global__ void __launch_bounds__(256) k_vox_region_max(unsigned int *__restrict__ cnt) {
+    unsigned int m = 0;
+    for (unsigned int i = threadIdx.x; i < kVoxRegions; i += 256) m = max(m, cnt[2 + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int) __shfl_xor((int) m, o, 64));
+    __shared__ unsigned int sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[1] = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
 }
 
 __global__ void k_used_flags(const unsigned long long *__restrict__ keys, long long n, unsigned int *__restrict__ flags) {
@@ -782,67 +794,49 @@ int scs_table(me_ctx *ctx, const int32_t *keys, const double *w, long long n, in
 static int voxel_build_onepass(me_ctx *ctx, Cloud &c, double voxel_size, bool raw, const VoxPack &vp, int *d_err) {
     const long long n = c.n;
     const SPoint *sp = c.sp.as<SPoint>();
-    unsigned int *d_cnt = reinterpret_cast<unsigned int *>(d_err) + 1;
+    (void) d_err;
     const long long nw = (n + 63) / 64;  // rows of 64 sorted points: two record slots each, further runs behind them
     DevBuf &kbuf = ctx->tmp[1], &sbuf = ctx->tmp[2], &ibuf = ctx->tmp[3], &mbuf = ctx->tmp[4];  // (tmp[5]: sort / scan scratch)
-    long long cap = vox_record_capacity(n), S = 0;
+    const long long cap = vox_record_capacity(n), rsize = vox_region_size(n);
+    const long long S = cap;  // every slot is looked at: the rows' two each, then the regions (with holes: compacted below)
     // the records the index build's gather left on the cloud (same rows, same arithmetic: me_vox_rows.hpp), when they are for this
-    // voxel size and all fitted; otherwise the pass below
-    bool fused = c.vox_rec_valid && c.vox_rec_pack.vs == voxel_size && c.vox_rec_cap == cap;
+    // voxel size; otherwise the pass below.  A region that overflowed: the three-pass build.
+    const bool fused = c.vox_rec_valid && c.vox_rec_pack.vs == voxel_size && c.vox_rec_cap == cap;
     const unsigned long long *slot_key_src = nullptr;
     const int *rec_n_src = nullptr;
     const double *rec_s_src = nullptr;
+    unsigned int *cnt = nullptr;
     if (fused) {
-        unsigned int h2[2] = {0, 0};
-        {
-            MailGuard mg(ctx);
-            ME_TRY(mail_post(ctx, h2, c.vox_rec_cnt.p, 8));
-            ME_TRY(mg.sync());
-        }
-        if (h2[0]) return ctx->fail(ME_ERR_ARG, "voxel index out of range (|floor(p/voxel_size)| must be < 2^20)");
-        S = 2 * nw + (long long) h2[1];
-        if (S > cap) fused = false;  // (more appended runs than there was room for: the pass below, with room)
-    }
-    if (fused) {
+        cnt = c.vox_rec_cnt.as<unsigned int>();
         slot_key_src = c.vox_rec_key.as<unsigned long long>();
         rec_n_src = c.vox_rec_n.as<int>();
         rec_s_src = c.vox_rec_s.as<double>();
-        ME_CHECK(ctx, kbuf.ensure((size_t) cap * 24));
-        ME_CHECK(ctx, ibuf.ensure((size_t) cap * 12));
-        ME_CHECK(ctx, mbuf.ensure((size_t) cap * 8 + 64));
-    }
-    for (int attempt = 0; attempt < 2 && !fused; ++attempt) {
+    } else {
         ME_CHECK(ctx, kbuf.ensure((size_t) cap * 24));      // slot keys | compacted keys | sorted keys
         ME_CHECK(ctx, sbuf.ensure((size_t) cap * 8 * kVoxRec));
+        ME_CHECK(ctx, c.vox_rec_cnt.ensure(kVoxCounterBytes));
+        cnt = c.vox_rec_cnt.as<unsigned int>();
+        ME_CHECK(ctx, hipMemsetAsync(kbuf.p, 0xFF, (size_t) cap * 8, ctx->stream));  // kVoxEmptySlot
+        ME_CHECK(ctx, hipMemsetAsync(cnt, 0, kVoxCounterBytes, ctx->stream));
         ME_CHECK(ctx, ibuf.ensure((size_t) cap * 12));      // rec_n | compacted slot indices | sorted slot indices
-        ME_CHECK(ctx, mbuf.ensure((size_t) cap * 8 + 64));  // flags | positions
-        unsigned long long *slot_key_w = kbuf.as<unsigned long long>();
-        int *rec_n_w = ibuf.as<int>();
-        ME_CHECK(ctx, hipMemsetAsync(slot_key_w, 0xFF, (size_t) cap * 8, ctx->stream));  // kVoxEmptySlot
-        ME_CHECK(ctx, hipMemsetAsync(d_err, 0, 8, ctx->stream));
-        {
-            TimerScope ts(ctx, "voxel");
-            hipLaunchKernelGGL(k_vox_records, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sp, n, vp, c.slab, slot_key_w, rec_n_w, sbuf.as<double>(),
-                               d_cnt, (unsigned int) nw, (unsigned int) cap, d_err);
-        }
-        unsigned int h_cnt = 0;
-        int h_err = 0;
-        {
-            MailGuard mg(ctx);
-            ME_TRY(mail_post(ctx, &h_cnt, d_cnt, 4));
-            ME_TRY(mail_post(ctx, &h_err, d_err, 4));
-            ME_TRY(mg.sync());
-        }
-        if (h_err) return ctx->fail(ME_ERR_ARG, "voxel index out of range (|floor(p/voxel_size)| must be < 2^20)");
-        S = 2 * nw + (long long) h_cnt;  // slots in use (with holes: the unused second slots of the rows)
-        if (S <= cap) {
-            slot_key_src = kbuf.as<unsigned long long>();
-            rec_n_src = ibuf.as<int>();
-            rec_s_src = sbuf.as<double>();
-            break;
-        }
-        if (attempt == 1) return ctx->fail(ME_ERR_STATE, "voxel pass: record count changed between two passes");
-        cap = S;  // (rows with three and more runs all over: scattered outliers, a voxel smaller than a row's extent) once more
+        TimerScope ts(ctx, "voxel");
+        hipLaunchKernelGGL(k_vox_records, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sp, n, vp, c.slab, kbuf.as<unsigned long long>(),
+                           ibuf.as<int>(), sbuf.as<double>(), cnt + 2, (unsigned int) nw, (unsigned int) rsize, reinterpret_cast<int *>(cnt));
+        slot_key_src = kbuf.as<unsigned long long>();
+        rec_n_src = ibuf.as<int>();
+        rec_s_src = sbuf.as<double>();
+    }
+    ME_CHECK(ctx, kbuf.ensure((size_t) cap * 24));
+    ME_CHECK(ctx, ibuf.ensure((size_t) cap * 12));
+    ME_CHECK(ctx, mbuf.ensure((size_t) cap * 8 + 64));  // flags | positions
+    hipLaunchKernelGGL(k_vox_region_max, dim3(1), dim3(256), 0, ctx->stream, cnt);
+    {
+        unsigned int h2[2] = {0, 0};
+        MailGuard mg(ctx);
+        ME_TRY(mail_post(ctx, h2, cnt, 8));
+        ME_TRY(mg.sync());
+        if (h2[0]) return ctx->fail(ME_ERR_ARG, "voxel index out of range (|floor(p/voxel_size)| must be < 2^20)");
+        if ((long long) h2[1] > rsize) return 1;  // (a region overflowed: the caller takes the three-pass build)
     }
     unsigned long long *ckey = kbuf.as<unsigned long long>() + cap, *skey = ckey + cap;
     const unsigned long long *slot_key = slot_key_src;
@@ -931,7 +925,11 @@ int voxel_build(me_ctx *ctx, int slot, double voxel_size, bool raw) {
 #if ME_TUNE_VOX_ONEPASS
     {
         VoxPack vp;
-        if (vox_make_pack(c, voxel_size, n, vp)) return voxel_build_onepass(ctx, c, voxel_size, raw, vp, d_err);
+        if (vox_make_pack(c, voxel_size, n, vp)) {
+            const int rc1 = voxel_build_onepass(ctx, c, voxel_size, raw, vp, d_err);
+            if (rc1 <= 0) return rc1;  // (1: an overflow region was too small for this cloud — the three-pass build below)
+            ME_CHECK(ctx, hipMemsetAsync(d_err, 0, 8, ctx->stream));
+        }
     }
 #endif
     // --- runs per wavefront -> record offsets ---
