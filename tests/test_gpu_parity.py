@@ -205,6 +205,27 @@ def test_voxel_gaussians_parity(eng, campus):
     assert np.array_equal(ent[~big], oent[~big])
 
 
+def test_voxel_gaussians_of_scattered_points_take_the_three_pass_build(eng):
+    """Round 6: the one-pass voxel build gives a row of 64 sorted points two record slots and room for about as many further runs in
+    its overflow regions.  A cloud whose curve-neighbours all lie in different voxels — uniform points in a large box, a 1 m grid —
+    overflows them (~64 runs per row): the library must notice and take the three-pass build; keys, populations, means and covariances
+    against the oracle as for any other cloud, with mixed populations (a dense blob on top)."""
+    import oracle
+
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([rng.uniform(-60.0, 60.0, (150_000, 3)), rng.normal(0.0, 0.8, (60_000, 3)) + np.array([7.3, -2.1, 4.4])])
+    eng.upload(1, pts)
+    keys, n, mu, sig, ent = eng.voxel_gaussians(1, 1.0)
+    okeys, on, omu, osig, oent = oracle.VoxelMap(pts, 1.0).export()
+    assert np.array_equal(keys, okeys) and np.array_equal(n, on) and n.max() > 100 and (n == 1).sum() > 10_000
+    np.testing.assert_allclose(mu, omu, rtol=1e-13, atol=1e-13)
+    from tests._tol import assert_sigma_close
+
+    assert_sigma_close(sig, osig)
+    big = on > 10
+    np.testing.assert_allclose(ent[big], oent[big], rtol=0, atol=1e-8)
+
+
 @pytest.mark.parametrize("vs", [3.0, 0.5])
 def test_awd_cdf_scs_parity(eng, campus, cube, vs):
     import oracle
