@@ -394,6 +394,9 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
 #ifndef ME_TUNE_VOX_ONEPASS
 #define ME_TUNE_VOX_ONEPASS 1     // voxel tables from ONE pass over the sorted cloud (records about the voxel centres; 0: the three-pass build)
 #endif
+#ifndef ME_TUNE_SUITE_VOX_EARLY
+#define ME_TUNE_SUITE_VOX_EARLY 1  // me_run_suite_from, second lane: voxel tables whose run records the gather has emitted are finished BEFORE the reverse search (0: after it)
+#endif
 #ifndef ME_TUNE_SUITE_NN_FIRST
 #define ME_TUNE_SUITE_NN_FIRST 1  // me_run_suite_from, second lane: the reverse 1-NN search before the voxel tables (0: round 5's order)
 #endif

@@ -65,6 +65,8 @@ struct SuiteLane {
     bool finished = false;       // lane -> main: run() has returned (the lane touches nothing of this object afterwards)
     bool started = false;        // the worker has been handed this lane
     me_nn_partial back{};        // ground truth -> map partial sums
+    double back_sig[5] = {0, 0, 0, 0, 0};  // ... and the sigma numerators of its second pass
+    bool tables_ready = false;   // lane -> main: both voxel tables are complete (built from the gather's records, before the search)
     // Round 6: rocPRIM's onesweep radix pass uses decoupled lookback, and under a chip filled by the main lane's k_mme3 ONE pass of the
     // ground truth's sort took 12.8 ms instead of 0.3 (every other kernel of its index build ran at its normal speed beside the MME:
     // profiles/r06_timeline.txt) — the ground truth was indexed at 21.4 ms, the main lane waited 1 ms for it, and this lane's search
@@ -88,6 +90,10 @@ struct SuiteLane {
         cv.notify_all();
     }
     // false: aborted
+    bool is_set(bool SuiteLane::*flag) {
+        std::lock_guard<std::mutex> g(m);
+        return this->*flag;
+    }
     bool wait(bool SuiteLane::*flag) {
         std::unique_lock<std::mutex> g(m);
         cv.wait(g, [&] { return this->*flag || aborted; });
@@ -132,15 +138,33 @@ struct SuiteLane {
         set(&SuiteLane::sort_queued);  // (nothing to wait for any more, whatever happened above)
         set(&SuiteLane::gt_ready);
 #if ME_TUNE_SUITE_NN_FIRST
-        // Round 6: the reverse search FIRST, the voxel tables last.  The search is VALU-bound like the main lane's MME of the ground
-        // truth beside it — together they keep the vector unit busy —, and the two voxel tables (HBM-bound, 2.7 ms alone) then run
+        // Round 6: the reverse search before the voxel PASSES.  The search is VALU-bound like the main lane's MME of the ground
+        // truth beside it — together they keep the vector unit busy —, and three-pass voxel tables (HBM-bound, 2.7 ms alone) then run
         // under the main lane's own search.  In the other order the low-priority voxel passes starved under the MME (19 ms for 2.7 ms
         // of work), the reverse search started when the main lane's had finished, and for ~3 ms in between only HBM-bound kernels and
         // the octree tails were running (profiles/r05_timeline_two_lane.txt).
+        // A table whose run records the gather has already emitted (k_gather<VOX>) is another matter: what is left of it is ~40 launches
+        // of a few microseconds each (compaction, a merge sort of ~n / 60 records, one reduction) and three mailbox reads — 0.1 ms of
+        // work, 0.4 ms of latency.  After the searches that chain was the END of the step, on an idle chip (profiles/r06_timeline.txt:
+        // 43.0 -> 43.8 ms); here it hides under the MME kernels.
+        bool gt_table = false;
+#if ME_TUNE_SUITE_VOX_EARLY
+        if (t->cloud[ME_SLOT_GT].vox_rec_valid) {
+            ME_TRY(me::voxel_build(t, ME_SLOT_GT, p->vmd_voxel_size, false));
+            gt_table = true;
+        }
+#endif
         if (!wait(&SuiteLane::est_final)) return ME_OK;
+#if ME_TUNE_SUITE_VOX_EARLY
+        if (gt_table && !est_voxel_on_main && t->cloud[ME_SLOT_EST].vox_rec_valid && !est_voxel_taken.exchange(1)) {
+            ME_TRY(me::voxel_build(t, ME_SLOT_EST, p->vmd_voxel_size, false));
+            set(&SuiteLane::tables_ready);  // (both tables complete: voxel_build returns after its stream has drained)
+        }
+#endif
         ME_TRY(me::nn_search(t, ME_SLOT_GT, ME_SLOT_EST));
         ME_TRY(me::nn_partial(t, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &back));
-        ME_TRY(me::voxel_build(t, ME_SLOT_GT, p->vmd_voxel_size, false));
+        ME_TRY(back_sigma());
+        if (!gt_table) ME_TRY(me::voxel_build(t, ME_SLOT_GT, p->vmd_voxel_size, false));
         // the map's voxel table: whichever lane gets to it first (never both: same buffers) — the main lane claims it when its own
         // search is over and this lane is still busy with the ground truth's table
         if (!est_voxel_on_main && !est_voxel_taken.exchange(1)) ME_TRY(me::voxel_build(t, ME_SLOT_EST, p->vmd_voxel_size, false));
@@ -150,8 +174,16 @@ struct SuiteLane {
         if (!est_voxel_on_main) ME_TRY(me::voxel_build(t, ME_SLOT_EST, p->vmd_voxel_size, false));  // (never both lanes: same buffers)
         ME_TRY(me::nn_search(t, ME_SLOT_GT, ME_SLOT_EST));
         ME_TRY(me::nn_partial(t, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &back));
+        ME_TRY(back_sigma());
 #endif
         return ME_OK;
+    }
+    // second pass of the ground truth -> map statistics (map_eval.cpp:1132-1138) on THIS lane, as soon as its means exist: the main
+    // lane's own second pass and AWD / SCS run beside it instead of after it
+    int back_sigma() {
+        double mean[5];
+        for (int k = 0; k < 5; ++k) mean[k] = back.sum_d[k] / (double) back.n_corr;
+        return me::nn_sigma(t, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, mean, back_sig);
     }
     // waits until run() has returned; false: the lane failed
     bool join() {
@@ -242,17 +274,11 @@ bool index_fits_radius(const me::Cloud &c, double radius) {
     return c.index_valid && c.cell_h >= want_h && c.cell_h <= 1.5 * want_h;
 }
 
-int finish_stats(me_ctx *ctx, const me_suite_params *p, const me_nn_partial &pe, const me_nn_partial &pg, me_suite_out *out) {
-    // second pass: sigma needs the mean of every threshold (map_eval.cpp:1132-1138)
-    double mean[5], sig[5];
-    for (int k = 0; k < 5; ++k) mean[k] = pe.sum_d[k] / (double) pe.n_corr;
-    ME_TRY(me::nn_sigma(ctx, ME_SLOT_EST, p->icp_max_distance, p->gate_mode, mean, sig));
-    me_nn_finalize(&pe, sig, ctx->cloud[ME_SLOT_EST].n, &out->est_gt);
-    for (int k = 0; k < 5; ++k) mean[k] = pg.sum_d[k] / (double) pg.n_corr;
-    ME_TRY(me::nn_sigma(ctx, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, mean, sig));
-    me_nn_finalize(&pg, sig, ctx->cloud[ME_SLOT_GT].n, &out->gt_est);
-    out->full_chamfer = out->est_gt.mean_nn_dist + out->gt_est.mean_nn_dist;  // computeChamferDistance (:1429)
-    return ME_OK;
+// second pass of one direction: sigma needs the mean of every threshold (map_eval.cpp:1132-1138)
+int sigma_pass(me_ctx *ctx, int slot, const me_suite_params *p, const me_nn_partial &part, double *sig) {
+    double mean[5];
+    for (int k = 0; k < 5; ++k) mean[k] = part.sum_d[k] / (double) part.n_corr;
+    return me::nn_sigma(ctx, slot, p->icp_max_distance, p->gate_mode, mean, sig);
 }
 
 }  // namespace
@@ -455,23 +481,40 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
             t0 = Clock::now();
         }
 #endif
+        // the second pass of this lane's direction, and AWD / CDF / SCS (:85, :240-390) when the second lane has finished both voxel
+        // tables already: neither needs the other direction's search, which the second lane is finishing meanwhile.  (Not earlier:
+        // before this lane's search the chain of ~20 tiny launches waits behind the second lane's resident search waves — 3.7 ms —
+        // and the two searches no longer overlap: 44.9 ms per step against 44.0, scratch/tl.sh.)
+        double sig_e[5], sig_g[5];
+        ME_TRY(sigma_pass(ctx, ME_SLOT_EST, p, pe, sig_e));
+        out->stage_ms[3] = ms_since(t0);
+        int64_t n_rows = 0;
+        bool vmd_done = false;
+        auto vmd = [&]() -> int {
+            const auto tv = Clock::now();
+            ME_TRY(me_awd_scs(ctx, p->vmd_voxel_size, p->min_pts > 0 ? p->min_pts : 100, p->scs_radius > 0 ? p->scs_radius : 5, nullptr,
+                              nullptr, &n_rows, &out->awd, &out->scs, nullptr));
+            out->stage_ms[6] += ms_since(tv);
+            vmd_done = true;
+            return ME_OK;
+        };
+        if (overlap && lane.is_set(&SuiteLane::tables_ready)) ME_TRY(vmd());
+        t0 = Clock::now();
         if (overlap) {
             if (!lane.join()) return lane.rc.load();  // the second lane has searched the other direction meanwhile (and built both voxel tables)
             pg = lane.back;
+            for (int k = 0; k < 5; ++k) sig_g[k] = lane.back_sig[k];
         } else {
             ME_TRY(me::nn_search(ctx, ME_SLOT_GT, ME_SLOT_EST));
             ME_TRY(me::nn_partial(ctx, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &pg));
+            ME_TRY(sigma_pass(ctx, ME_SLOT_GT, p, pg, sig_g));
         }
         out->stage_ms[2] = ms_since(t0);
-        t0 = Clock::now();
-        ME_TRY(finish_stats(ctx, p, pe, pg, out));
-        out->stage_ms[3] = ms_since(t0);
-        // AWD / CDF / SCS (:85, :240-390); the voxel tables are cached on the clouds when the second lane built them
-        int64_t n_rows = 0;
-        t0 = Clock::now();
-        ME_TRY(me_awd_scs(ctx, p->vmd_voxel_size, p->min_pts > 0 ? p->min_pts : 100, p->scs_radius > 0 ? p->scs_radius : 5, nullptr,
-                          nullptr, &n_rows, &out->awd, &out->scs, nullptr));
-        out->stage_ms[6] += ms_since(t0);
+        me_nn_finalize(&pe, sig_e, ctx->cloud[ME_SLOT_EST].n, &out->est_gt);
+        me_nn_finalize(&pg, sig_g, ctx->cloud[ME_SLOT_GT].n, &out->gt_est);
+        out->full_chamfer = out->est_gt.mean_nn_dist + out->gt_est.mean_nn_dist;  // computeChamferDistance (:1429)
+        // (the voxel tables are cached on the clouds when the second lane built them)
+        if (!vmd_done) ME_TRY(vmd());
         out->n_w_voxels = n_rows;
         return ME_OK;
     };
