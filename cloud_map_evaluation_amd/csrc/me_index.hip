@@ -819,6 +819,69 @@ int transform_points_device(me_ctx *ctx, double *xyz_device, long long n, const 
     return ME_OK;
 }
 
+// --- sparse octree above the 1-NN cells (general 1-NN path: k_nn1 / k_nn_far, me_nn.hip) ---
+// small_top: the one-block kernel of the upper levels with four wavefronts instead of sixteen (a launch beside another lane's
+// full-chip kernels, see below)
+static int build_octree(me_ctx *ctx, Cloud &c, int nn_shift, bool small_top) {
+    const long long n = c.n;
+    OctView &v = c.oct;
+    int L = 0;
+    long long off = 0;
+    for (int k = nn_shift; k <= kMortonBits; ++k) {
+        if (L >= kMaxLevels) return ctx->fail(ME_ERR_ARG, "octree deeper than the level table (cloud extent / cell size too large)");
+        v.count[L] = c.level_unique[k];
+        v.off[L] = off;
+        off += v.count[L] + 1;
+        ++L;
+        if (c.level_unique[k] == 1) break;
+    }
+    v.n_levels = L;
+    ME_CHECK(ctx, c.oct_nodes.ensure((size_t) (off + kFan) * sizeof(ONode)));  // + slack for the 8-record burst
+    ME_CHECK(ctx, hipMemsetAsync(c.oct_nodes.as<ONode>() + off, 0, kFan * sizeof(ONode), ctx->stream));
+    ME_CHECK(ctx, c.oct_pbegin.ensure((size_t) (off + kFan + 1) * 4));
+    ME_CHECK(ctx, hipMemsetAsync(c.oct_pbegin.as<unsigned int>() + off, 0, (kFan + 1) * 4, ctx->stream));
+    v.nodes = c.oct_nodes.as<ONode>();
+    v.pbegin = c.oct_pbegin.as<unsigned int>();
+    ONode *nodes = c.oct_nodes.as<ONode>();
+    unsigned int *pbeg = c.oct_pbegin.as<unsigned int>();
+    hipLaunchKernelGGL(k_oct_leaves, dim3(grid_for((v.count[0] + 1) * 8)), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),
+                       c.nn_grid.cell_start, v.count[0], n, nodes, pbeg);
+    // prefix codes of the current level (level 0: the cell codes of the 1-NN grid), ping-pong
+    DevBuf &ca = ctx->tmp[2], &cb = ctx->tmp[3], &pos = ctx->tmp[1], &begin = ctx->tmp[4];
+    const unsigned long long *cur = c.nn_grid.cell_code;
+    for (int l = 0; l + 1 < L; ++l) {
+        const long long nc = v.count[l], np = v.count[l + 1];
+        if (nc <= kOctTopMax) {  // everything from here up in ONE launch
+            ME_CHECK(ctx, begin.ensure((size_t) (np + 1) * 4));
+            ME_CHECK(ctx, ca.ensure((size_t) np * 8));
+            ME_CHECK(ctx, cb.ensure((size_t) np * 8));
+            // (`cur` may live in ca / cb: the kernel's first output buffer must be the other one)
+            unsigned long long *first = (cur == ca.as<unsigned long long>()) ? cb.as<unsigned long long>() : ca.as<unsigned long long>();
+            unsigned long long *second = (first == ca.as<unsigned long long>()) ? cb.as<unsigned long long>() : ca.as<unsigned long long>();
+            // (a twin lane runs beside the main lane's full-chip kernels: a 1024-thread block needs 16 free wave slots on ONE CU
+            // at the same moment and waited 10 ms for them under k_mme3 — profiles/r06_timeline.txt; four waves find room)
+            if (small_top)
+                hipLaunchKernelGGL((k_oct_top<256>), dim3(1), dim3(256), 0, ctx->stream, nodes, pbeg, v, l, cur, first, second,
+                                   begin.as<unsigned int>());
+            else
+                hipLaunchKernelGGL((k_oct_top<1024>), dim3(1), dim3(1024), 0, ctx->stream, nodes, pbeg, v, l, cur, first, second,
+                                   begin.as<unsigned int>());
+            break;
+        }
+        ME_CHECK(ctx, pos.ensure((size_t) nc * 4));
+        ME_CHECK(ctx, begin.ensure((size_t) (np + 1) * 4));
+        DevBuf &nxt = (l % 2 == 0) ? ca : cb;
+        ME_CHECK(ctx, nxt.ensure((size_t) np * 8));
+        ME_TRY(cell_start_ranks(ctx, cur, nc, 3, pos.as<unsigned int>()));
+        hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(nc)), dim3(256), 0, ctx->stream, cur, pos.as<unsigned int>(), nc, 3,
+                           nxt.as<unsigned long long>(), begin.as<unsigned int>());
+        hipLaunchKernelGGL(k_oct_up, dim3(grid_for(np + 1)), dim3(256), 0, ctx->stream, nodes + v.off[l], nc,
+                           begin.as<unsigned int>(), np, nodes + v.off[l + 1], pbeg + v.off[l], pbeg + v.off[l + 1]);
+        cur = nxt.as<unsigned long long>();
+    }
+    return ME_OK;
+}
+
 int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     Cloud &c = ctx->cloud[slot];
     ME_TRACE_POINT(ctx, slot == 0 ? "cloud_build_index(est): enter" : "cloud_build_index(gt): enter");
@@ -999,64 +1062,16 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
                 ++c.n_mid;
             }
         }
-        // --- sparse octree above the 1-NN cells (general 1-NN path) ---
-        {
-            OctView &v = c.oct;
-            int L = 0;
-            long long off = 0;
-            for (int k = nn_shift; k <= kMortonBits; ++k) {
-                if (L >= kMaxLevels) return ctx->fail(ME_ERR_ARG, "octree deeper than the level table (cloud extent / cell size too large)");
-                v.count[L] = c.level_unique[k];
-                v.off[L] = off;
-                off += v.count[L] + 1;
-                ++L;
-                if (c.level_unique[k] == 1) break;
-            }
-            v.n_levels = L;
-            ME_CHECK(ctx, c.oct_nodes.ensure((size_t) (off + kFan) * sizeof(ONode)));  // + slack for the 8-record burst
-            ME_CHECK(ctx, hipMemsetAsync(c.oct_nodes.as<ONode>() + off, 0, kFan * sizeof(ONode), ctx->stream));
-            ME_CHECK(ctx, c.oct_pbegin.ensure((size_t) (off + kFan + 1) * 4));
-            ME_CHECK(ctx, hipMemsetAsync(c.oct_pbegin.as<unsigned int>() + off, 0, (kFan + 1) * 4, ctx->stream));
-            v.nodes = c.oct_nodes.as<ONode>();
-            v.pbegin = c.oct_pbegin.as<unsigned int>();
-            ONode *nodes = c.oct_nodes.as<ONode>();
-            unsigned int *pbeg = c.oct_pbegin.as<unsigned int>();
-            hipLaunchKernelGGL(k_oct_leaves, dim3(grid_for((v.count[0] + 1) * 8)), dim3(256), 0, ctx->stream, c.sp.as<SPoint>(),
-                               c.nn_grid.cell_start, v.count[0], n, nodes, pbeg);
-            // prefix codes of the current level (level 0: the cell codes of the 1-NN grid), ping-pong
-            DevBuf &ca = ctx->tmp[2], &cb = ctx->tmp[3], &pos = ctx->tmp[1], &begin = ctx->tmp[4];
-            const unsigned long long *cur = c.nn_grid.cell_code;
-            for (int l = 0; l + 1 < L; ++l) {
-                const long long nc = v.count[l], np = v.count[l + 1];
-                if (nc <= kOctTopMax) {  // everything from here up in ONE launch
-                    ME_CHECK(ctx, begin.ensure((size_t) (np + 1) * 4));
-                    ME_CHECK(ctx, ca.ensure((size_t) np * 8));
-                    ME_CHECK(ctx, cb.ensure((size_t) np * 8));
-                    // (`cur` may live in ca / cb: the kernel's first output buffer must be the other one)
-                    unsigned long long *first = (cur == ca.as<unsigned long long>()) ? cb.as<unsigned long long>() : ca.as<unsigned long long>();
-                    unsigned long long *second = (first == ca.as<unsigned long long>()) ? cb.as<unsigned long long>() : ca.as<unsigned long long>();
-                    // (a twin lane runs beside the main lane's full-chip kernels: a 1024-thread block needs 16 free wave slots on ONE CU
-                    // at the same moment and waited 10 ms for them under k_mme3 — profiles/r06_timeline.txt; four waves find room)
-                    if (ctx->is_twin)
-                        hipLaunchKernelGGL((k_oct_top<256>), dim3(1), dim3(256), 0, ctx->stream, nodes, pbeg, v, l, cur, first, second,
-                                           begin.as<unsigned int>());
-                    else
-                        hipLaunchKernelGGL((k_oct_top<1024>), dim3(1), dim3(1024), 0, ctx->stream, nodes, pbeg, v, l, cur, first, second,
-                                           begin.as<unsigned int>());
-                    break;
-                }
-                ME_CHECK(ctx, pos.ensure((size_t) nc * 4));
-                ME_CHECK(ctx, begin.ensure((size_t) (np + 1) * 4));
-                DevBuf &nxt = (l % 2 == 0) ? ca : cb;
-                ME_CHECK(ctx, nxt.ensure((size_t) np * 8));
-                ME_TRY(cell_start_ranks(ctx, cur, nc, 3, pos.as<unsigned int>()));
-                hipLaunchKernelGGL(k_cell_scatter, dim3(grid_for(nc)), dim3(256), 0, ctx->stream, cur, pos.as<unsigned int>(), nc, 3,
-                                   nxt.as<unsigned long long>(), begin.as<unsigned int>());
-                hipLaunchKernelGGL(k_oct_up, dim3(grid_for(np + 1)), dim3(256), 0, ctx->stream, nodes + v.off[l], nc,
-                                   begin.as<unsigned int>(), np, nodes + v.off[l + 1], pbeg + v.off[l], pbeg + v.off[l + 1]);
-                cur = nxt.as<unsigned long long>();
-            }
-        }
+        // --- sparse octree above the 1-NN cells ---
+        // Nothing but the 1-NN fallback walks it (k_nn1 / k_nn_far): a caller that runs other passes first (me_run_suite_from: the MME
+        // needs the cell tables only) asks for the octree later, cloud_finish_octree — 1.2 ms of launch-sized kernels that otherwise
+        // stand between the cell tables and the first full-chip kernel of the step.
+        c.oct_deferred = false;
+        c.oct_nn_shift = nn_shift;
+        if (ctx->defer_octree)
+            c.oct_deferred = true;
+        else
+            ME_TRY(build_octree(ctx, c, nn_shift, ctx->is_twin));
     }
     ME_CHECK(ctx, hipGetLastError());
     // The index is COMPLETE on the device when this returns ("every call is synchronous on return", mapeval_hip.h).  Through round 4
@@ -1068,6 +1083,21 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
     ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     c.index_valid = true;
     ME_TRACE_POINT(ctx, "cloud_build_index: done (host side)");
+    return ME_OK;
+}
+
+// the octree of a cloud indexed with ctx->defer_octree: built now, complete on the device on return (no-op otherwise)
+int cloud_finish_octree(me_ctx *ctx, int slot) {
+    Cloud &c = ctx->cloud[slot];
+    if (!c.oct_deferred || !c.index_valid) return ME_OK;  // (no index: the next build decides again)
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    {
+        TimerScope ts(ctx, "cells");
+        ME_TRY(build_octree(ctx, c, c.oct_nn_shift, true));
+    }
+    ME_CHECK(ctx, hipGetLastError());
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    c.oct_deferred = false;
     return ME_OK;
 }
 

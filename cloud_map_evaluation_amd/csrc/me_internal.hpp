@@ -178,6 +178,8 @@ struct Cloud {
     DevBuf sp;     // SPoint[n] sorted
     // sparse octree (general 1-NN path)
     OctView oct{};
+    bool oct_deferred = false;  // the index is valid but its octree is still to be built (cloud_finish_octree)
+    int oct_nn_shift = 0;       // level of the octree's leaves (the 1-NN grid's)
     DevBuf oct_nodes;
     DevBuf oct_pbegin;
     // cell tables: `grid` at the radius level (MME), `nn_grid` at the level whose occupied cells hold ~16 points
@@ -272,6 +274,7 @@ struct me_ctx {
     bool borrow_device_input = false;   // me_create flag ME_FLAG_BORROW_DEVICE_INPUT
     bool morton_order = false;          // me_create flag ME_FLAG_MORTON_ORDER: points sorted along the Z curve instead of the Hilbert curve
     me::SlabView slab{-1, 0, 0, 0, 0};  // applied to the next uploads
+    bool defer_octree = false;          // index builds leave the octree to cloud_finish_octree (me_run_suite_from)
     double vox_hint = 0;                // > 0: index builds also emit the voxel run records for this voxel size (me_run_suite_from)
     // instrumentation
     bool timers_on = false;
@@ -394,6 +397,9 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
 #ifndef ME_TUNE_VOX_ONEPASS
 #define ME_TUNE_VOX_ONEPASS 1     // voxel tables from ONE pass over the sorted cloud (records about the voxel centres; 0: the three-pass build)
 #endif
+#ifndef ME_TUNE_SUITE_DEFER_OCTREE
+#define ME_TUNE_SUITE_DEFER_OCTREE 1  // me_run_suite_from: the octrees are built after the first MME has been queued, not inside the index build
+#endif
 #ifndef ME_TUNE_SUITE_VOX_EARLY
 #define ME_TUNE_SUITE_VOX_EARLY 1  // me_run_suite_from, second lane: voxel tables whose run records the gather has emitted are finished BEFORE the reverse search (0: after it)
 #endif
@@ -442,6 +448,7 @@ int select_flagged_u32(me_ctx *ctx, const unsigned char *flags, long long n, uns
 int cloud_upload(me_ctx *ctx, int slot, const double *src, bool src_on_device, long long n, const double *T,
                  double cell_size, bool prefiltered = false);
 int cloud_build_index(me_ctx *ctx, int slot, double cell_size);
+int cloud_finish_octree(me_ctx *ctx, int slot);
 int cloud_finish(me_ctx *ctx, int slot, bool bbox_ready = false);
 int cloud_transform(me_ctx *ctx, int slot, const double *T);
 int voxel_downsample(me_ctx *ctx, int slot, double voxel_size, long long *n_out);

@@ -1131,6 +1131,7 @@ int nn_search(me_ctx *ctx, int qslot, int rslot) {
     if (!q.uploaded || !r.uploaded || (!slab && (!q.index_valid || !r.index_valid)))
         return ctx->fail(ME_ERR_STATE, "me_nn1: upload both clouds first");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
+    ME_TRY(cloud_finish_octree(ctx, rslot));  // (an index built with ctx->defer_octree; me_run_suite_from has done this already)
     q.nn_ref_slot = rslot;
     ME_TRACE_POINT(ctx, "nn_search: enter");
     q.n_unres = 0;
@@ -1264,6 +1265,7 @@ int nn_points(me_ctx *ctx, int rslot, const double *xyz_device, long long m, dou
     if (!r.uploaded) return ctx->fail(ME_ERR_STATE, "me_nn_points: reference cloud not uploaded");
     if (m == 0) return ME_OK;
     ME_CHECK(ctx, hipSetDevice(ctx->device));
+    ME_TRY(cloud_finish_octree(ctx, rslot));
     const unsigned int nb = (unsigned int) ((m + 255) / 256);
     if (r.n == 0) {
         if (!bounded) hipLaunchKernelGGL(k_fill_f64, dim3(nb), dim3(256), 0, ctx->stream, d2_device, m, (double) INFINITY);
@@ -1408,6 +1410,7 @@ int nn_cross_answer(me_ctx *ctx, const double *gathered_device, int world, long 
         axis > 2)
         return ctx->fail(ME_ERR_ARG, "me_nn_cross_answer: bad argument");
     ME_CHECK(ctx, hipSetDevice(ctx->device));
+    for (int slot = 0; slot < 2; ++slot) ME_TRY(cloud_finish_octree(ctx, slot));
     CrossCuts cc;
     for (int k = 0; k <= world; ++k) cc.c[k] = cuts_host[k];
     const long long m = (long long) world * cap;

@@ -489,6 +489,7 @@ int need_plain_cloud(me_ctx *ctx, int slot, const char *who, bool need_index) {
     if (!c.uploaded) return ctx->fail(ME_ERR_STATE, std::string(who) + ": cloud not uploaded");
     if (c.slab.axis >= 0) return ctx->fail(ME_ERR_STATE, std::string(who) + ": not available in slab mode");
     if (need_index && !c.index_valid) return ctx->fail(ME_ERR_STATE, std::string(who) + ": cloud has no index");
+    if (need_index) ME_TRY(cloud_finish_octree(ctx, slot));
     return ME_OK;
 }
 

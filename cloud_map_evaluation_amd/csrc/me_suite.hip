@@ -66,6 +66,8 @@ struct SuiteLane {
     bool started = false;        // the worker has been handed this lane
     me_nn_partial back{};        // ground truth -> map partial sums
     double back_sig[5] = {0, 0, 0, 0, 0};  // ... and the sigma numerators of its second pass
+    bool est_tree = false;       // main -> lane: the map's octree is complete (it is built after the map's MME)
+    bool gt_tree = false;        // lane -> main: the ground truth's octree is complete (built after gt_ready)
     bool tables_ready = false;   // lane -> main: both voxel tables are complete (built from the gather's records, before the search)
     // Round 6: rocPRIM's onesweep radix pass uses decoupled lookback, and under a chip filled by the main lane's k_mme3 ONE pass of the
     // ground truth's sort took 12.8 ms instead of 0.3 (every other kernel of its index build ran at its normal speed beside the MME:
@@ -89,11 +91,11 @@ struct SuiteLane {
         }
         cv.notify_all();
     }
-    // false: aborted
     bool is_set(bool SuiteLane::*flag) {
         std::lock_guard<std::mutex> g(m);
         return this->*flag;
     }
+    // false: aborted
     bool wait(bool SuiteLane::*flag) {
         std::unique_lock<std::mutex> g(m);
         cv.wait(g, [&] { return this->*flag || aborted; });
@@ -112,6 +114,7 @@ struct SuiteLane {
         {   // gt_ready: a failed lane must not leave the main lane waiting; finished: last touch of this object
             std::lock_guard<std::mutex> g(m);
             gt_ready = true;
+            gt_tree = true;
             sort_queued = true;
             finished = true;
         }
@@ -137,6 +140,9 @@ struct SuiteLane {
         }
         set(&SuiteLane::sort_queued);  // (nothing to wait for any more, whatever happened above)
         set(&SuiteLane::gt_ready);
+        // (the main lane's MME of the ground truth starts on the cell tables; the octree is for the tails of the searches)
+        ME_TRY(me::cloud_finish_octree(t, ME_SLOT_GT));
+        set(&SuiteLane::gt_tree);
 #if ME_TUNE_SUITE_NN_FIRST
         // Round 6: the reverse search before the voxel PASSES.  The search is VALU-bound like the main lane's MME of the ground
         // truth beside it — together they keep the vector unit busy —, and three-pass voxel tables (HBM-bound, 2.7 ms alone) then run
@@ -161,6 +167,7 @@ struct SuiteLane {
             set(&SuiteLane::tables_ready);  // (both tables complete: voxel_build returns after its stream has drained)
         }
 #endif
+        if (!wait(&SuiteLane::est_tree)) return ME_OK;
         ME_TRY(me::nn_search(t, ME_SLOT_GT, ME_SLOT_EST));
         ME_TRY(me::nn_partial(t, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &back));
         ME_TRY(back_sigma());
@@ -172,6 +179,7 @@ struct SuiteLane {
         ME_TRY(me::voxel_build(t, ME_SLOT_GT, p->vmd_voxel_size, false));
         if (!wait(&SuiteLane::est_final)) return ME_OK;
         if (!est_voxel_on_main) ME_TRY(me::voxel_build(t, ME_SLOT_EST, p->vmd_voxel_size, false));  // (never both lanes: same buffers)
+        if (!wait(&SuiteLane::est_tree)) return ME_OK;
         ME_TRY(me::nn_search(t, ME_SLOT_GT, ME_SLOT_EST));
         ME_TRY(me::nn_partial(t, ME_SLOT_GT, p->icp_max_distance, p->gate_mode, p->trunc, &back));
         ME_TRY(back_sigma());
@@ -355,18 +363,30 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     const auto t_all = Clock::now();
     // the index builds of this call also emit the voxel run records for vmd_voxel_size (me_index.hip: k_gather<VOX>), on both lanes
+    // ... and leave the octrees to cloud_finish_octree when an MME pass comes first (it needs the cell tables only)
     struct VoxHint {
         me_ctx *a, *b = nullptr;
-        VoxHint(me_ctx *c, double v) : a(c) { a->vox_hint = v; }
+        bool defer;
+        VoxHint(me_ctx *c, double v, bool d) : a(c), defer(d) {
+            a->vox_hint = v;
+            a->defer_octree = d;
+        }
         void also(me_ctx *t, double v) {
             b = t;
-            if (b) b->vox_hint = v;
+            if (b) {
+                b->vox_hint = v;
+                b->defer_octree = defer;
+            }
         }
         ~VoxHint() {
             a->vox_hint = 0;
-            if (b) b->vox_hint = 0;
+            a->defer_octree = false;
+            if (b) {
+                b->vox_hint = 0;
+                b->defer_octree = false;
+            }
         }
-    } vox_hint(ctx, upload ? p->vmd_voxel_size : 0.0);
+    } vox_hint(ctx, upload ? p->vmd_voxel_size : 0.0, ME_TUNE_SUITE_DEFER_OCTREE && upload && p->evaluate_mme);
 
     if (!upload) {
         // Resident clouds: with two lanes both start at once on the SAME two Cloud objects, and a stage that finds a
@@ -445,6 +465,10 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
             out->stage_ms[0] += ms_since(t0);
             if (overlap) lane.set(&SuiteLane::est_final);
         }
+        // the map's octree, left out of its index build: the MME above started that much earlier, and this lane would now wait for the
+        // ground truth's cell tables anyway
+        ME_TRY(me::cloud_finish_octree(ctx, ME_SLOT_EST));
+        if (overlap) lane.set(&SuiteLane::est_tree);
         if (overlap && upload && !on_device) {
             // host input: the ground truth is still crossing PCIe (the map's index + MME are shorter than its copy) and this lane would
             // idle until it is indexed — the map's voxel table is built here instead of on the second lane after the ground truth's
@@ -469,6 +493,12 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
         // AC / COM both directions (:1213-1242) + full CD (:1398-1431) from the same two searches
         me_nn_partial pe{}, pg{};
         t0 = Clock::now();
+        if (overlap) {
+            lane.wait(&SuiteLane::gt_tree);
+            if (lane.rc.load() != ME_OK) return lane.rc.load();
+        } else {
+            ME_TRY(me::cloud_finish_octree(ctx, ME_SLOT_GT));
+        }
         ME_TRY(me::nn_search(ctx, ME_SLOT_EST, ME_SLOT_GT));
         ME_TRY(me::nn_partial(ctx, ME_SLOT_EST, p->icp_max_distance, p->gate_mode, p->trunc, &pe));
         out->stage_ms[1] = ms_since(t0);
