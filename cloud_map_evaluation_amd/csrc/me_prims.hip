@@ -159,14 +159,19 @@ int select_flagged_u32(me_ctx *ctx, const unsigned char *flags, long long n, uns
 }
 
 // (nine bits per onesweep pass — four passes over a 36-bit key instead of five — does not build: rocPRIM's rank table for 512 digits
-// needs 524 KB of LDS)
+// needs 524 KB of LDS with `match`, 262 KB with `basic`.)  Block shape: rocPRIM has no tuned onesweep entry for gfx950; of the shapes
+// that fit (profiles/ubench/sort_cfg.hip, 50 M words, 36 key bits) 1024 threads x 8 keys sorts in 1.39 ms against the default's 1.56.
+using SortKeysConfig = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 8, rocprim::block_radix_rank_algorithm::match>>;
+
 int sort_keys_u64(me_ctx *ctx, const unsigned long long *in, unsigned long long *out, long long n, int begin_bit, int end_bit) {
     if (n <= 0) return ME_OK;
     size_t bytes = 0;
-    ME_CHECK(ctx, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, ctx->stream));
+    ME_CHECK(ctx, rocprim::radix_sort_keys<SortKeysConfig>(nullptr, bytes, in, out, (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, ctx->stream));
     ME_CHECK(ctx, ctx->tmp[5].ensure(bytes));
     TimerScope ts(ctx, "sort");
-    ME_CHECK(ctx, rocprim::radix_sort_keys(ctx->tmp[5].p, bytes, in, out, (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, ctx->stream));
+    ME_CHECK(ctx, rocprim::radix_sort_keys<SortKeysConfig>(ctx->tmp[5].p, bytes, in, out, (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, ctx->stream));
     return ME_OK;
 }
 
