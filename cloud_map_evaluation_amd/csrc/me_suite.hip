@@ -10,18 +10,23 @@
 //
 //   main lane (ctx, highest stream priority)            second lane (twin, lowest priority)
 //   ---------------------------------------            ----------------------------------------------------------------
-//   upload + index the map                              [host input: wait until the map has crossed the link]
-//   (the gathers also emit the voxel run records        upload + index the ground truth  (its radix sort BEFORE the map's MME
-//    for vmd_voxel_size: me_vox_rows.hpp)                starts: onesweep crawls beside a full chip; the rest under that MME)
-//   wait: ground truth's sort queued (event)
-//   MME of the map            (VALU-bound)              wait: map final
-//   [T: transform + re-index the map, :1206]            1-NN ground truth -> map + partial sums
-//   [host input: voxel Gaussians of the map]            voxel Gaussians of the ground truth (sort + reduce of its records)
-//   wait: ground truth indexed                          voxel Gaussians of the map, unless the main lane got there first
-//   MME of the ground truth
-//   1-NN map -> ground truth + partial sums
-//   voxel Gaussians of the map, unless the second lane got there first
-//   join; sigma passes; AWD / CDF / SCS
+//   upload + index the map, WITHOUT its octree          [host input: wait until the map has crossed the link]
+//   (the gathers also emit the voxel run records        upload + index the ground truth, without its octree (its radix sort
+//    for vmd_voxel_size: me_vox_rows.hpp)                BEFORE the map's MME starts: onesweep crawls beside a full chip; the
+//   wait: ground truth's sort queued (event)             rest under that MME)
+//   MME of the map            (VALU-bound)              -> "ground truth indexed"; its octree (cloud_finish_octree)
+//   [T: transform + re-index the map, :1206]            voxel Gaussians of the ground truth, then of the map, from the gathers'
+//   the map's octree (cloud_finish_octree)               records (~40 launch-sized kernels each: they hide under the MMEs)
+//   [host input: voxel Gaussians of the map]            wait: map's octree
+//   wait: ground truth indexed                          1-NN ground truth -> map + partial sums + ITS sigma pass
+//   MME of the ground truth                             [no records (three-pass build): the voxel tables here, after the search;
+//   wait: ground truth's octree                          the map's by whichever lane gets to it first]
+//   1-NN map -> ground truth + partial sums + ITS sigma pass
+//   AWD / CDF / SCS if both tables are ready (beside the second lane's tail); join; [AWD / CDF / SCS otherwise]
+//
+// Measured on the 50 M + 50 M bench pair (profiles/EXPERIMENTS.md "Round 6"): the step is the SUM of its kernels' work on the vector
+// unit whatever the order — what the order decides is how much launch-latency-bound work (octrees, voxel tables, sigma, AWD) is left
+// standing alone at either end of the step.
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
