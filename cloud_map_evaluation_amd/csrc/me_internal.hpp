@@ -385,6 +385,9 @@ struct TimerScope {  // (scopes do not nest: a scope that calls into another tim
 #ifndef ME_TUNE_NN_FAR_LEAF
 #define ME_TUNE_NN_FAR_LEAF 1024  // points a node may hold for k_nn_far to scan it whole instead of descending further
 #endif
+#ifndef ME_TUNE_MME_WAVES
+#define ME_TUNE_MME_WAVES 8  // k_mme3: wavefronts per SIMD the kernel is compiled for (measured 3 / 4 / 6 / 8: profiles/EXPERIMENTS.md "Round 6")
+#endif
 #ifndef ME_TUNE_MME_REFINE_COND
 #define ME_TUNE_MME_REFINE_COND 1.8e-6  // k_mme3 flags a neighbourhood whose smallest covariance eigenvalue is below ~this x cell_h^2 for k_mme_refine (0: never)
 #endif

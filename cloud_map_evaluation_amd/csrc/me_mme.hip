@@ -722,7 +722,7 @@ int mme_run(me_ctx *ctx, int slot, double radius, int min_k, double *entropies, 
 #ifdef ME_AB
 #include "me_mme_dispatch_ab.inc"
 #else
-        ME_LAUNCH_MME3(32, 8, ME_MME_DBG);
+        ME_LAUNCH_MME3(32, ME_TUNE_MME_WAVES, ME_MME_DBG);
 #endif
 #undef ME_LAUNCH_MME3
         ts.end();
