@@ -521,6 +521,21 @@ int me_halo_pack_tagged_device(me_ctx *ctx, const double *xyz_device, int64_t n,
     return rc;
 }
 
+int me_lattice_histograms_device(me_ctx *ctx, const double *xyz_device, int64_t n, int e0, int32_t *level, int64_t origin_bin[3],
+                                 int64_t neg_inf[3], uint32_t *hist_device) {
+    if (!ctx) return ME_ERR_ARG;
+    int lv = 0;
+    long long o[3] = {0, 0, 0}, ni[3] = {0, 0, 0};
+    if (!level || !origin_bin || !neg_inf) return ctx->fail(ME_ERR_ARG, "me_lattice_histograms_device: NULL output");
+    const int rc = me::lattice_histograms(ctx, xyz_device, n, e0, &lv, o, ni, hist_device);
+    *level = lv;
+    for (int a = 0; a < 3; ++a) {
+        origin_bin[a] = o[a];
+        neg_inf[a] = ni[a];
+    }
+    return rc;
+}
+
 int me_voxel_partial_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, int64_t capacity, int64_t *n_rows) {
     if (!ctx) return ME_ERR_ARG;
     long long n = 0;

@@ -146,6 +146,145 @@ int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, cons
     return ME_OK;
 }
 
+// ---- marginal histograms on an absolute power-of-two lattice (the lean exchange of dist.py) ----
+// A rank that knows, for every rank's part of a cloud, how many points fall into every bin [i w, (i + 1) w) of every axis can compute
+// the slab cuts (at bin edges), the halo (a whole number of bins) AND the exact size of every message of the halo exchange by itself:
+// one all-gather of these histograms replaces the sample gather, the count all-to-all and three host reads.  w is a power of two and
+// the lattice is absolute (bin = floor(x / w)), so that k_halo_split's comparisons v >= lo, v < hi against lo, hi = (whole number) * w
+// decide exactly what the bins say: x / w, floor and (whole number) * w are all exact in fp64.
+constexpr long long kLatClamp = 1LL << 60;
+
+__device__ __forceinline__ long long lattice_bin(double v, double inv_w) {
+    const double f = floor(v * inv_w);
+    return f >= (double) kLatClamp ? kLatClamp : (f <= -(double) kLatClamp ? -kLatClamp : (long long) f);
+}
+
+// range[0..2] = min, range[3..5] = max of the level-0 bin over the FINITE coordinates of every axis; range[6..8] = how many are -inf
+// (k_halo_split gives those to rank 0: -inf >= -inf; NaN and +inf satisfy no slab's test and are dropped by the exchange)
+__global__ void __launch_bounds__(256)
+k_lattice_range(const double *__restrict__ xyz, long long n, double inv_w, long long *__restrict__ range) {
+    long long mn[3] = {kLatClamp, kLatClamp, kLatClamp}, mx[3] = {-kLatClamp, -kLatClamp, -kLatClamp}, ni[3] = {0, 0, 0};
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; ++a) {
+            const double v = xyz[3 * i + a];
+            if (isfinite(v)) {
+                const long long b = lattice_bin(v, inv_w);
+                mn[a] = min(mn[a], b);
+                mx[a] = max(mx[a], b);
+            } else if (v < 0) {
+                ++ni[a];
+            }
+        }
+    __shared__ long long sm[9][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int a = 0; a < 3; ++a) {
+        long long lo = mn[a], hi = mx[a], c = ni[a];
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, (long long) __shfl_xor(lo, o, 64));
+            hi = max(hi, (long long) __shfl_xor(hi, o, 64));
+            c += (long long) __shfl_xor(c, o, 64);
+        }
+        if (lane == 0) {
+            sm[a][wv] = lo;
+            sm[3 + a][wv] = hi;
+            sm[6 + a][wv] = c;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const int r = threadIdx.x;
+        long long v = sm[r][0];
+        for (int w = 1; w < 4; ++w) v = r < 3 ? min(v, sm[r][w]) : (r < 6 ? max(v, sm[r][w]) : v + sm[r][w]);
+        if (r < 3) atomicMin(&range[r], v);
+        else if (r < 6) atomicMax(&range[r], v);
+        else if (v) atomicAdd(reinterpret_cast<unsigned long long *>(&range[r]), (unsigned long long) v);
+    }
+}
+
+struct LatOrigin {
+    long long o[3];
+};
+
+// hist[a * bins + (floor(x_a / w) - origin_a)] += 1 for every finite coordinate (the caller chose w and the origin so that all fit);
+// block-private counts in LDS, one global atomic per touched bin and block
+template <int BINS>
+__global__ void __launch_bounds__(256)
+k_lattice_hist(const double *__restrict__ xyz, long long n, double inv_w, LatOrigin org, unsigned int *__restrict__ hist,
+               unsigned int *__restrict__ outside) {
+    __shared__ unsigned int sh[3 * BINS];
+    for (int i = threadIdx.x; i < 3 * BINS; i += 256) sh[i] = 0;
+    __syncthreads();
+    unsigned int out = 0;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; ++a) {
+            const double v = xyz[3 * i + a];
+            if (!isfinite(v)) continue;
+            const long long b = lattice_bin(v, inv_w) - org.o[a];
+            if (b >= 0 && b < BINS) atomicAdd(&sh[a * BINS + (int) b], 1u);
+            else ++out;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * BINS; i += 256)
+        if (sh[i]) atomicAdd(&hist[i], sh[i]);
+    if (out) atomicAdd(outside, out);
+}
+
+int lattice_histograms(me_ctx *ctx, const double *xyz_device, long long n, int e0, int *level, long long origin_bin[3], long long neg_inf[3],
+                       unsigned int *hist_device) {
+    if ((n > 0 && !xyz_device) || n < 0 || e0 < -40 || e0 > 40 || !level || !origin_bin || !neg_inf || !hist_device)
+        return ctx->fail(ME_ERR_ARG, "me_lattice_histograms_device: bad argument (-40 <= e0 <= 40)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    constexpr int B = ME_LATTICE_BINS;
+    *level = 0;
+    for (int a = 0; a < 3; ++a) origin_bin[a] = neg_inf[a] = 0;
+    ME_CHECK(ctx, hipMemsetAsync(hist_device, 0, (size_t) 3 * B * 4, ctx->stream));
+    if (n == 0) {
+        ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return ME_OK;
+    }
+    TimerScope ts(ctx, "halo_pack");
+    ME_CHECK(ctx, ctx->red.ensure(16 * 8));
+    long long *d_range = ctx->red.as<long long>();
+    long long init[10] = {kLatClamp, kLatClamp, kLatClamp, -kLatClamp, -kLatClamp, -kLatClamp, 0, 0, 0, 0};
+    ME_CHECK(ctx, hipMemcpyAsync(d_range, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned int grid = (unsigned int) std::min<long long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_lattice_range, dim3(grid), dim3(256), 0, ctx->stream, xyz_device, n, std::ldexp(1.0, -e0), d_range);
+    long long h[9];
+    {
+        MailGuard mg(ctx);
+        ME_TRY(mail_post(ctx, h, d_range, sizeof h));
+        ME_TRY(mg.sync());
+    }
+    for (int a = 0; a < 3; ++a) neg_inf[a] = h[6 + a];
+    bool any = false;
+    for (int a = 0; a < 3; ++a) any = any || h[a] <= h[3 + a];
+    if (any) {
+        int L = 0;
+        auto fits = [&](int l) {
+            for (int a = 0; a < 3; ++a)
+                if (h[a] <= h[3 + a] && (h[3 + a] >> l) - (h[a] >> l) + 1 > (long long) B) return false;
+            return true;
+        };
+        while (L < 62 && !fits(L)) ++L;
+        *level = L;
+        LatOrigin org{};
+        for (int a = 0; a < 3; ++a) org.o[a] = origin_bin[a] = (h[a] <= h[3 + a]) ? (h[a] >> L) : 0;
+        unsigned int *d_out = reinterpret_cast<unsigned int *>(d_range + 9);
+        hipLaunchKernelGGL((k_lattice_hist<B>), dim3(std::min(grid, 256u)), dim3(256), 0, ctx->stream, xyz_device, n, std::ldexp(1.0, -(e0 + L)), org,
+                           hist_device, d_out);
+        unsigned int outside = 0;
+        {
+            MailGuard mg(ctx);
+            ME_TRY(mail_post(ctx, &outside, d_out, 4));
+            ME_TRY(mg.sync());
+        }
+        if (outside) return ctx->fail(ME_ERR_STATE, "me_lattice_histograms_device: points outside the window the range pass chose");
+    }
+    ME_CHECK(ctx, hipGetLastError());
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
 // ---- voxel partial rows: [kx, ky, kz, n, mu(3), M2(9)] = 16 doubles per voxel ----
 constexpr int kRow = 16;
 

@@ -531,6 +531,21 @@ class Engine:
         out = out[:total]
         return out, [int(x) for x in counts]
 
+    def lattice_histograms(self, xyz, e0: int):
+        """Marginal histograms of a raw cuda (n,3) float64 buffer on the absolute lattice of bin width 2^(e0 + level):
+        (level, origin_bin int64[3], neg_inf int64[3], hist (3, ME_LATTICE_BINS) cuda int32).  me_lattice_histograms_device."""
+        import torch
+
+        assert xyz.is_cuda and xyz.dtype == torch.float64 and xyz.is_contiguous()
+        torch.cuda.current_stream(xyz.device).synchronize()
+        hist = torch.empty((3, _lib.ME_LATTICE_BINS), dtype=torch.int32, device=xyz.device)
+        level = C.c_int32(0)
+        origin = (C.c_int64 * 3)()
+        ninf = (C.c_int64 * 3)()
+        self._ck(self._L.me_lattice_histograms_device(self._ctx, xyz.data_ptr(), int(xyz.shape[0]), int(e0), C.byref(level), origin, ninf,
+                                                      hist.data_ptr()))
+        return int(level.value), np.array(list(origin), dtype=np.int64), np.array(list(ninf), dtype=np.int64), hist
+
     def voxel_partial_rows(self, slot: int, voxel_size: float):
         """This rank's voxel partials as a (V,16) cuda tensor [kx,ky,kz,n,mu(3),M2(9)] (no host copy)."""
         import torch

@@ -200,6 +200,16 @@ int me_halo_pack_device(me_ctx *ctx, const double *xyz_device, int64_t n, int ax
  * (the C++ host's per-point outputs: map_entropy.pcd, raw_rendered_dis_map.pcd, map_eval.cpp:485-495, 686-736). */
 int me_halo_pack_tagged_device(me_ctx *ctx, const double *xyz_device, int64_t n, int axis, const double *cuts, int world, double halo,
                                double *out_device, int64_t *tags_device, int64_t tag_base, int64_t capacity, int64_t *counts);
+/* The lean exchange (no reference counterpart; dist.py `lattice_plan`): the marginal histograms of a rank's part of a cloud on an
+ * ABSOLUTE power-of-two lattice.  Bin i of axis a counts the finite coordinates with floor(x_a / w) == origin_bin[a] + i,
+ * w = 2^(e0 + *level); *level is the smallest one for which every axis of this buffer fits ME_LATTICE_BINS bins.  neg_inf[a]
+ * counts the coordinates that are -inf (me_halo_pack_device hands those to rank 0; NaN and +inf satisfy no slab's test).
+ * hist_device: 3 x ME_LATTICE_BINS uint32, axis-major.  With the histograms of every rank's parts (one all-gather) each rank computes
+ * the slab cuts AT BIN EDGES, a halo of whole bins and the exact size of every message of the halo exchange — x / w, floor and
+ * (whole number) * w are exact in fp64, so me_halo_pack_device's comparisons against such cuts decide exactly what the bins say. */
+#define ME_LATTICE_BINS 4096
+int me_lattice_histograms_device(me_ctx *ctx, const double *xyz_device, int64_t n, int e0, int32_t *level, int64_t origin_bin[3],
+                                 int64_t neg_inf[3], uint32_t *hist_device);
 int me_voxel_partial_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, int64_t capacity, int64_t *n_rows);
 int me_voxel_merge_device(me_ctx *ctx, int slot, double voxel_size, const double *rows_device, int64_t n_rows);
 

@@ -470,6 +470,26 @@ def test_a_failure_on_the_second_lane_surfaces_and_does_not_hang():
 # ---------------------------------------------------------------------------------------------------------------
 # distributed input (suite_step_dist): every rank starts with 1/world of each cloud, one all-to-all halo exchange
 # ---------------------------------------------------------------------------------------------------------------
+def numpy_lattice_histograms(p, e0):
+    """me_lattice_histograms_device restated in numpy (csrc/me_dist.hip: k_lattice_range + k_lattice_hist)."""
+    import torch
+    from cloud_map_evaluation_amd.dist import LATTICE_BINS as B
+
+    fin = np.isfinite(p)
+    ninf = np.array([int(np.sum(np.isneginf(p[:, a]))) for a in range(3)], dtype=np.int64)
+    level, origin = 0, np.zeros(3, np.int64)
+    hist = np.zeros((3, B), np.int32)
+    if fin.any():
+        b0 = [np.floor(p[fin[:, a], a] * 2.0 ** -e0).astype(np.int64) for a in range(3)]
+        while any(len(b) and (b.max() >> level) - (b.min() >> level) + 1 > B for b in b0):
+            level += 1
+        for a in range(3):
+            if len(b0[a]):
+                origin[a] = b0[a].min() >> level
+                hist[a] = np.bincount((b0[a] >> level) - origin[a], minlength=B)
+    return level, origin, ninf, torch.from_numpy(hist)
+
+
 class OracleDistEngine(OracleSlabEngine):
     """Stand-in for Engine with the distributed-input primitives restated in numpy (host tensors, gloo collectives)."""
 
@@ -494,6 +514,9 @@ class OracleDistEngine(OracleSlabEngine):
             segs.append(p[keep])
             counts.append(int(keep.sum()))
         return torch.from_numpy(np.concatenate(segs) if segs else np.zeros((0, 3))), counts
+
+    def lattice_histograms(self, xyz, e0):
+        return numpy_lattice_histograms(xyz.numpy(), e0)
 
     def upload(self, slot, xyz, T=None, cell_size=0.0):
         super().upload(slot, xyz.numpy() if hasattr(xyz, "numpy") else xyz, T, cell_size)
@@ -528,6 +551,8 @@ def _dist_worker(rank, world, port, est, gt, T, q):
     os.environ["MASTER_PORT"] = str(port)
     if os.environ.get("ME_TEST_CROSS_CAP"):  # force the overflow path of the folded cross-rank all-gather
         medist._CROSS_CAP = int(os.environ["ME_TEST_CROSS_CAP"])
+    if os.environ.get("ME_TEST_VOX_CAP"):  # ... and of the folded statistics gather
+        medist._VOX_CAP = int(os.environ["ME_TEST_VOX_CAP"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         P = Param(icp_max_distance_=1.0, nn_radius_=0.1, trunc_dist_=TRUNC, vmd_voxel_size_=0.5, initial_matrix_=T)
@@ -545,15 +570,21 @@ def _dist_worker(rank, world, port, est, gt, T, q):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,cap", [(2, 0), (3, 0), (2, 5)])
-def test_distributed_input_suite_gloo_equals_single_process_oracle(world, cap, monkeypatch):
-    """1/world of each cloud per rank -> slab cuts from two collectives -> all-to-all halo exchange -> local passes ->
-    batched cross-rank resolve (one fixed-capacity all-gather with the counts in-band; cap = 5 forces its overflow fallback)
-    -> merged voxel tables: every rank ends with the single-process oracle's answer."""
+@pytest.mark.parametrize("world,cap,protocol", [(2, 0, "lean"), (3, 0, "lean"), (2, 5, "lean"), (3, 0, "lean_vox_overflow"), (2, 0, "classic"), (3, 5, "classic")])
+def test_distributed_input_suite_gloo_equals_single_process_oracle(world, cap, protocol, monkeypatch):
+    """1/world of each cloud per rank -> lean: cuts, halo and every message size from ONE gather of lattice histograms (classic,
+    ME_DIST_LEAN=0: a gathered sample + a count all-to-all) -> all-to-all halo exchange -> local passes -> batched cross-rank resolve
+    (one fixed-capacity all-gather with the counts in-band; cap = 5 forces its overflow fallback) -> partial sums and voxel rows in one
+    fixed-capacity gather (lean_vox_overflow: capacity 3 forces the exact-size gather) -> merged voxel tables: every rank ends with
+    the single-process oracle's answer."""
     import torch.multiprocessing as mp
 
     if cap:
         monkeypatch.setenv("ME_TEST_CROSS_CAP", str(cap))
+    if protocol == "classic":
+        monkeypatch.setenv("ME_DIST_LEAN", "0")
+    if protocol == "lean_vox_overflow":
+        monkeypatch.setenv("ME_TEST_VOX_CAP", "3")
 
     import oracle
     from cloud_map_evaluation_amd import synth
@@ -616,3 +647,59 @@ def test_dist_slab_cuts_single_process_are_balanced_and_ascending():
     same = torch.ones((100, 3), dtype=torch.float64)
     _, c = medist.dist_slab_cuts(same, None, torch.device("cpu"), 3)
     assert all(c[i] < c[i + 1] for i in range(3))
+
+
+def _plan_for(parts_by_rank, halo):
+    """lattice_plan on numpy parts [[est_r, gt_r] per rank] -> (axis, cuts, halo_eff, counts, totals)."""
+    import torch
+
+    from cloud_map_evaluation_amd import dist as medist
+
+    e0 = medist.lattice_e0(halo)
+    eng = OracleDistEngine()
+    msgs = [medist.lattice_message(eng, [torch.from_numpy(np.ascontiguousarray(c)) for c in parts], e0) for parts in parts_by_rank]
+    return medist.lattice_plan(torch.stack(msgs), len(parts_by_rank), halo, e0)
+
+
+def _membership_counts(parts_by_rank, axis, cuts, halo):
+    eng = OracleDistEngine()
+    import torch
+
+    return np.array([[eng.halo_pack(torch.from_numpy(np.ascontiguousarray(c)), axis, cuts, halo)[1] for c in parts] for parts in parts_by_rank])
+
+
+@pytest.mark.parametrize("case", ["uniform", "negative_and_edges", "separated_parts", "huge_extent", "nonfinite_and_empty", "degenerate"])
+def test_lattice_plan_predicts_every_message_of_the_halo_exchange(case):
+    """The lean exchange: cuts at bin edges of an absolute power-of-two lattice, a halo of whole bins, and the per-destination counts
+    of every source rank computed from the gathered histograms alone — equal, number for number, to what halo_pack's comparisons
+    (me_set_slab's filter) select with those cuts."""
+    rng = np.random.default_rng(7)
+    world, halo = 4, 0.3
+    if case == "uniform":
+        parts = [[rng.uniform(-3, 9, (4000, 3)) * [1, 0.3, 0.1], rng.uniform(-3, 9, (3500, 3)) * [1, 0.3, 0.1]] for _ in range(world)]
+    elif case == "negative_and_edges":
+        w = 2.0 ** -6  # (a multiple of every bin width up to 2^-6: coordinates ON bin edges)
+        parts = [[np.round(rng.uniform(-20, -5, (3000, 3)) / w) * w, np.round(rng.uniform(-20, -5, (2500, 3)) / w) * w] for _ in range(world)]
+    elif case == "separated_parts":  # every rank's piece is compact and far from the others: the combined window is coarsened
+        parts = [[rng.uniform(0, 60, (2000, 3)) + [400.0 * r, 0, 0], rng.uniform(0, 60, (2000, 3)) + [400.0 * r, 0, 0]] for r in range(world)]
+    elif case == "huge_extent":
+        parts = [[rng.uniform(-4000, 9000, (3000, 3)), rng.uniform(-4000, 9000, (3000, 3))] for _ in range(world)]
+    elif case == "nonfinite_and_empty":
+        a = rng.uniform(0, 10, (2000, 3))
+        a[5, 0], a[6, 0], a[7, 0], a[8, 1] = -np.inf, np.inf, np.nan, -np.inf
+        parts = [[a, rng.uniform(0, 10, (1500, 3))], [np.zeros((0, 3)), rng.uniform(0, 10, (900, 3))], [rng.uniform(0, 10, (10, 3)), np.zeros((0, 3))],
+                 [np.zeros((0, 3)), np.zeros((0, 3))]]
+    else:  # all points in one bin of the slab axis
+        parts = [[np.tile([[1.0, 2.0, 3.0]], (500, 1)) + [0, 1e-3 * r, 0], np.tile([[1.0, 2.0, 3.0]], (400, 1))] for r in range(world)]
+    axis, cuts, halo_eff, counts, totals = _plan_for(parts, halo)
+    assert len(cuts) == world + 1 and cuts[0] == -np.inf and cuts[-1] == np.inf
+    assert all(cuts[k] < cuts[k + 1] for k in range(world))
+    assert halo_eff >= halo
+    if case in ("uniform", "negative_and_edges", "nonfinite_and_empty", "degenerate"):
+        assert halo_eff <= halo * 17 / 16 + 1e-12  # the finest lattice: whole bins of at most halo / 16
+    assert totals == [sum(len(p[c]) for p in parts) for c in range(2)]
+    assert np.array_equal(counts, _membership_counts(parts, axis, cuts, halo_eff))
+    if case == "uniform":
+        assert axis == 0
+        owned = np.array([sum(int(((p[c][:, axis] >= cuts[k]) & (p[c][:, axis] < cuts[k + 1])).sum()) for p in parts for c in range(2)) for k in range(world)])
+        assert owned.max() - owned.min() <= 0.02 * owned.sum()  # equal counts of both clouds together, to a bin's worth

@@ -48,6 +48,43 @@ def test_halo_pack_is_the_numpy_multi_split():
         assert counts == [77] and np.array_equal(out.cpu().numpy(), p[:77])
 
 
+def test_lattice_histograms_and_the_plan_they_give_against_numpy_and_halo_pack():
+    """me_lattice_histograms_device == its numpy restatement (tests/test_dist_gloo.py) on ragged inputs — negative coordinates, points
+    ON bin edges, extents that force a coarser level, -inf / +inf / NaN, an empty buffer — and the lean exchange's promise on the
+    device: the per-destination counts lattice_plan predicts from the histograms are what me_halo_pack_device packs with the plan's cuts."""
+    import torch
+
+    from cloud_map_evaluation_amd import dist as medist
+    from cloud_map_evaluation_amd.engine import Engine
+    from test_dist_gloo import numpy_lattice_histograms
+
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda", 0)
+    w = 2.0 ** -6
+    a = rng.uniform(-40, 90, (200_003, 3)) * [1, 0.2, 0.05]
+    a[:5000] = np.round(a[:5000] / w) * w
+    a[7, 0], a[8, 0], a[9, 0], a[10, 2] = -np.inf, np.inf, np.nan, -np.inf
+    clouds = {"mixed": a, "huge": rng.uniform(-7000, 12000, (50_000, 3)), "empty": np.zeros((0, 3)), "one": np.array([[0.5, -0.25, 3.0]])}
+    with Engine(0) as eng:
+        for name, p in clouds.items():
+            for e0 in (-4, -8, 1):
+                level, origin, ninf, hist = eng.lattice_histograms(torch.from_numpy(p).to(dev), e0)
+                l2, o2, n2, h2 = numpy_lattice_histograms(p, e0)
+                assert (level, list(origin), list(ninf)) == (l2, list(o2), list(n2)), (name, e0)
+                assert np.array_equal(hist.cpu().numpy(), h2.numpy()), (name, e0)
+                assert int(hist.sum()) == int(np.isfinite(p).sum())
+        # four ranks' parts of two clouds -> plan -> what halo_pack really packs
+        world, halo = 4, 0.3
+        parts = [[torch.from_numpy(rng.uniform(-3, 9, (30_000 + 1000 * r, 3)) * [1, 0.3, 0.1]).to(dev) for _ in range(2)] for r in range(world)]
+        e0 = medist.lattice_e0(halo)
+        allm = torch.stack([medist.lattice_message(eng, pr, e0) for pr in parts])
+        axis, cuts, halo_eff, counts, totals = medist.lattice_plan(allm, world, halo, e0)
+        assert axis == 0 and halo <= halo_eff <= halo * 17 / 16 and totals == [sum(int(pr[c].shape[0]) for pr in parts) for c in range(2)]
+        for r in range(world):
+            for c in range(2):
+                assert eng.halo_pack(parts[r][c], axis, cuts, halo_eff)[1] == [int(x) for x in counts[r][c]]
+
+
 def test_transform_points_device_is_the_upload_transform():
     import torch
 
