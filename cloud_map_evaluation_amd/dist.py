@@ -674,7 +674,7 @@ def _hp_stream(device):
 
 _CROSS_CAP = 4096  # open queries per direction and rank the folded all-gather carries (overflow: exact-size fallback)
 _VOX_CAP = 4096    # voxel partial rows per cloud and rank the folded statistics gather carries (overflow: exact-size gather)
-_FOLD_HEAD = 3     # header rows of that message: VEC_LEN partial sums + the two row counts in 3 x 16 doubles
+_FOLD_HEAD = 3     # header rows of that message: VEC_LEN partial sums, the two row counts, the open-query counts and cloud sizes in 3 x 16 doubles
 
 
 def _pad_rows(t, rows: int, width: int, device, bound_pad: bool = False):
@@ -731,6 +731,10 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     # engine offers them — the ~60 small tensor operations of the round-4 form (two exports, padding, concatenation, per-direction
     # slicing, staging copies, two searches and two patches) were most of this phase's 2 ms at 8 ranks.
     lean = (not single) and hasattr(eng, "nn_cross_message") and cuts is not None and len(cuts) == world + 1
+    # Round 6 (lean step): with those calls the gathered message is answered, min-reduced and patched WITHOUT reading its header on
+    # the host — every rank's open-query counts travel once more in the header of the statistics gather below (one host read for both),
+    # and a rank with more than `cap` open queries (rare) sends everybody through the exact-size path and a second statistics gather then.
+    optimistic = _LEAN and lean
     mineq = None
     if lean:
         msg, _ = eng.nn_cross_message(cap, n_loc[0], n_loc[1])
@@ -741,6 +745,7 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         wdev = next((t.device for t in mineq if t is not None), comm_device)
         head = torch.zeros((1, 4), dtype=torch.float64, device=comm_device)
         head[0] = torch.tensor([cnt[0], cnt[1], n_loc[0], n_loc[1]], dtype=torch.float64)
+    table = None
     if single:
         table = head.to(torch.int64).cpu()
         allq = None
@@ -750,38 +755,55 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         parts = [torch.empty_like(msg) for _ in range(world)]
         dist.all_gather(parts, msg)
         allq = torch.stack(parts)                                 # (world, 1 + 2 cap, 4)
-        table = allq[:, 0, :].to(torch.int64).cpu()               # the ONE host read of the cross-rank step
-    n_e, n_g = int(table[:, 2].sum()), int(table[:, 3].sum())
+        if not optimistic:
+            table = allq[:, 0, :].to(torch.int64).cpu()           # the host read of the cross-rank step
     tr.mark("counts")
-    n_cross = int(table[:, 0].sum() + table[:, 1].sum())
-    if not single and n_cross > 0:
+
+    def cross_exact(table):
+        """More than `cap` open queries on some rank: the exact-size gather of round 2, answered rank by rank."""
+        nonlocal mineq
+        cmax = [int(table[:, 0].max()), int(table[:, 1].max())]
+        if mineq is None:
+            mineq = [eng.nn_unresolved(q, with_d2=True) if cnt[i] else None for i, (q, r) in enumerate(dirs)]
+        msg = torch.cat([_pad_rows(mineq[i], cmax[i], 4, comm_device) for i in range(2)])
+        parts = [torch.empty_like(msg) for _ in range(world)]
+        dist.all_gather(parts, msg)
+        allx = torch.stack(parts)
+        offs = [0, cmax[0]]
+        d2 = torch.full(allx.shape[:2], float("inf"), dtype=torch.float64, device=comm_device)
+        for i, (q, r) in enumerate(dirs):
+            base = offs[i]
+            sel = [(k, int(table[k, i])) for k in range(world) if k != rank and int(table[k, i]) > 0]
+            if sel:
+                qs = torch.cat([allx[k, base:base + c] for k, c in sel])
+                ans = eng.nn_points(r, qs[:, :3].contiguous().to(wdev), bound=qs[:, 3].contiguous().to(wdev)).to(comm_device)
+                o = 0
+                for k, c in sel:
+                    d2[k, base:base + c] = ans[o:o + c]
+                    o += c
+            if cnt[i]:
+                d2[rank, base:base + cnt[i]] = allx[rank, base:base + cnt[i], 3]  # the owner's own search is its answer
+        dist.all_reduce(d2, op=dist.ReduceOp.MIN)
+        for i, (q, r) in enumerate(dirs):
+            if cnt[i]:
+                eng.nn_patch(q, d2[rank, offs[i]:offs[i] + cnt[i]].contiguous().to(wdev))
+
+    n_cross = None
+    if optimistic:
+        d2 = _comm(eng.nn_cross_answer(allq, cap, rank, 3, int(slab[0]), cuts, float(slab[3])), comm_device)
+        dist.all_reduce(d2, op=dist.ReduceOp.MIN)
+        eng.nn_cross_patch(d2, cap, rank)
+    else:
+        n_cross = int(table[:, 0].sum() + table[:, 1].sum())
+    if table is not None and not single and n_cross > 0:
         cmax = [int(table[:, 0].max()), int(table[:, 1].max())]
         if lean and max(cmax) <= cap:
             mask = (1 if int(table[:, 0].sum()) - cnt[0] > 0 else 0) | (2 if int(table[:, 1].sum()) - cnt[1] > 0 else 0)
             d2 = _comm(eng.nn_cross_answer(allq, cap, rank, mask, int(slab[0]), cuts, float(slab[3])), comm_device)
             dist.all_reduce(d2, op=dist.ReduceOp.MIN)
             eng.nn_cross_patch(d2, cap, rank)
-        elif max(cmax) > cap:  # overflow: the exact-size gather of round 2, answered rank by rank
-            if mineq is None:
-                mineq = [eng.nn_unresolved(q, with_d2=True) if cnt[i] else None for i, (q, r) in enumerate(dirs)]
-            msg = torch.cat([_pad_rows(mineq[i], cmax[i], 4, comm_device) for i in range(2)])
-            parts = [torch.empty_like(msg) for _ in range(world)]
-            dist.all_gather(parts, msg)
-            allq = torch.stack(parts)
-            offs = [0, cmax[0]]
-            d2 = torch.full(allq.shape[:2], float("inf"), dtype=torch.float64, device=comm_device)
-            for i, (q, r) in enumerate(dirs):
-                base = offs[i]
-                sel = [(k, int(table[k, i])) for k in range(world) if k != rank and int(table[k, i]) > 0]
-                if sel:
-                    qs = torch.cat([allq[k, base:base + c] for k, c in sel])
-                    ans = eng.nn_points(r, qs[:, :3].contiguous().to(wdev), bound=qs[:, 3].contiguous().to(wdev)).to(comm_device)
-                    o = 0
-                    for k, c in sel:
-                        d2[k, base:base + c] = ans[o:o + c]
-                        o += c
-                if cnt[i]:
-                    d2[rank, base:base + cnt[i]] = allq[rank, base:base + cnt[i], 3]  # the owner's own search is its answer
+        elif max(cmax) > cap:
+            cross_exact(table)
         else:
             # Round 4: every slot of the fixed-capacity message is answered in ONE call per direction — the padding and the rank's
             # own rows carry the bound -1, which no squared distance beats: their walks end at the root of the tree — instead of
@@ -811,7 +833,6 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
                 ans = ans.view(world, cap)
                 ans[rank] = blk[rank, :, 3]
                 d2[:, base:base + cap] = ans
-        if not (lean and max(cmax) <= cap):
             dist.all_reduce(d2, op=dist.ReduceOp.MIN)
             for i, (q, r) in enumerate(dirs):
                 if cnt[i]:
@@ -819,6 +840,9 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     tr.mark("cross_rank_nn")
     parts = [eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_) for q, r in dirs]
     tr.mark("nn_sums")
+    n_e = n_g = None
+    if table is not None:
+        n_e, n_g = int(table[:, 2].sum()), int(table[:, 3].sum())
     # --- everything below that does not need the MME sums runs BEFORE the other lane is joined (round 3): the voxel partial
     #     rows of the owned points (they need the index only: the other lane builds them before its MME passes), the statistics
     #     collectives and the voxel gather / merge / AWD are latency-bound host + small-kernel work, and they hide under the
@@ -835,15 +859,26 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         #     first _FOLD_HEAD rows of a rank's message carry its partial sums and its two row counts; the sums are added up in rank
         #     order on the device (any order is exact for the counts; the fp sums agree with an all-reduce to the last bits).  A rank
         #     with more than _VOX_CAP rows of a cloud (the header says so, to everybody) sends everybody to the exact-size gather. ---
-        hv = np.zeros(_FOLD_HEAD * 16)
-        hv[:VEC_LEN] = pack_partials(parts, m_e, m_g)
-        hv[VEC_LEN], hv[VEC_LEN + 1] = rows[0].shape[0], rows[1].shape[0]
-        head = torch.from_numpy(hv.reshape(_FOLD_HEAD, 16)).to(comm_device)
-        msg = torch.cat([head, _pad_rows(rows[0][:_VOX_CAP], _VOX_CAP, 16, comm_device), _pad_rows(rows[1][:_VOX_CAP], _VOX_CAP, 16, comm_device)])
-        gparts = [torch.empty_like(msg) for _ in range(world)]
-        dist.all_gather(gparts, msg)
-        allr = torch.stack(gparts)                                    # (world, _FOLD_HEAD + 2 _VOX_CAP, 16)
-        heads = allr[:, :_FOLD_HEAD].reshape(world, -1).cpu().numpy()  # the host read of this phase
+        def stats_gather(parts):
+            hv = np.zeros(_FOLD_HEAD * 16)
+            hv[:VEC_LEN] = pack_partials(parts, m_e, m_g)
+            hv[VEC_LEN:VEC_LEN + 6] = [rows[0].shape[0], rows[1].shape[0], cnt[0], cnt[1], n_loc[0], n_loc[1]]
+            head = torch.from_numpy(hv.reshape(_FOLD_HEAD, 16)).to(comm_device)
+            msg = torch.cat([head, _pad_rows(rows[0][:_VOX_CAP], _VOX_CAP, 16, comm_device), _pad_rows(rows[1][:_VOX_CAP], _VOX_CAP, 16, comm_device)])
+            gparts = [torch.empty_like(msg) for _ in range(world)]
+            dist.all_gather(gparts, msg)
+            allr = torch.stack(gparts)                                    # (world, _FOLD_HEAD + 2 _VOX_CAP, 16)
+            return allr, allr[:, :_FOLD_HEAD].reshape(world, -1).cpu().numpy()  # the host read of this phase
+
+        allr, heads = stats_gather(parts)
+        xt = heads[:, VEC_LEN + 2:VEC_LEN + 6].astype(np.int64)           # per rank: open queries of both directions, points held
+        if optimistic and int(xt[:, :2].max()) > cap:
+            cross_exact(xt)
+            parts = [eng.nn_partial_sums(q, P.icp_max_distance_, ME_GATE_LE_UNSQUARED, P.trunc_dist_) for q, r in dirs]
+            allr, heads = stats_gather(parts)
+        if n_cross is None:
+            n_cross = int(xt[:, :2].sum())
+            n_e, n_g = int(xt[:, 2].sum()), int(xt[:, 3].sum())
         vec = heads[:, :VEC_LEN].sum(0) if world > 1 else heads[0, :VEC_LEN]
         vrows = np.concatenate([heads[:, VEC_LEN], heads[:, VEC_LEN + 1]])
     else:

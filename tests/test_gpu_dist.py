@@ -162,6 +162,10 @@ def _worker(rank, world, port, est, gt, T, q, overlap, backend="gloo"):
     os.environ["MASTER_PORT"] = str(port)
     if backend == "nccl":
         os.environ["ME_FORCE_COLLECTIVES"] = "1"  # one rank, but every collective of the step goes through RCCL
+    if os.environ.get("ME_TEST_CROSS_CAP"):  # force the overflow path of the cross-rank message (lean step: the redo after the statistics gather)
+        medist._CROSS_CAP = int(os.environ["ME_TEST_CROSS_CAP"])
+    if os.environ.get("ME_TEST_VOX_CAP"):
+        medist._VOX_CAP = int(os.environ["ME_TEST_VOX_CAP"])
     torch.cuda.set_device(0)
     dist.init_process_group(backend, rank=rank, world_size=world)
     try:
@@ -206,9 +210,18 @@ def _check_against_oracle(results, est, gt, T, world, min_cross):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_process_distributed_suite_matches_oracle(overlap):
+@pytest.mark.parametrize("overlap,variant", [(False, "lean"), (True, "lean"), (True, "lean_overflows"), (True, "classic")])
+def test_two_process_distributed_suite_matches_oracle(overlap, variant, monkeypatch):
+    """lean: the round-6 step (lattice plan -> halo all-to-all -> cross message gather, answered without a host read -> min-reduce ->
+    statistics + voxel rows in one gather -> last all-reduce); lean_overflows: 16 open queries / 8 voxel rows per message, so that the
+    exact-size cross-rank path AND the exact-size voxel gather run after the optimistic ones; classic: ME_DIST_LEAN=0, rounds 2 - 5."""
     import torch.multiprocessing as mp
+
+    if variant == "lean_overflows":
+        monkeypatch.setenv("ME_TEST_CROSS_CAP", "16")
+        monkeypatch.setenv("ME_TEST_VOX_CAP", "8")
+    if variant == "classic":
+        monkeypatch.setenv("ME_DIST_LEAN", "0")
 
     est, gt = _scene(100_000)
     est = np.concatenate([est, est[:150] + np.array([2.0, 0.0, 30.0])])  # far points: the cross-rank 1-NN step
