@@ -31,7 +31,7 @@ SYMBOLS = [
     "me_set_normals", "me_get_normals", "me_estimate_normals", "me_gicp_covariances", "me_get_covariances", "me_icp_lsq_sums",
     "me_nn1", "me_icp_p2p_sums", "me_render_distance", "me_render_entropy", "me_nn_stats", "me_nn_partial_sums", "me_nn_sigma_sums", "me_nn_finalize", "me_chamfer",
     "me_mme", "me_voxel_gaussians", "me_awd_scs", "me_w2_batch", "me_scs_table", "me_run_suite", "me_run_suite_from", "me_mme_fetch",
-    "me_timers_enable", "me_timers_reset", "me_timer_get",
+    "me_set_voxel_hint", "me_timers_enable", "me_timers_reset", "me_timer_get",
 ]
 
 
@@ -165,6 +165,8 @@ def load():
     L.me_voxel_merge_device.argtypes = [vp, C.c_int, C.c_double, dp, C.c_int64]
     for f in ("me_transform_points_device", "me_upload_slab_device", "me_halo_pack_device", "me_voxel_partial_rows_device", "me_voxel_merge_device"):
         getattr(L, f).restype = C.c_int
+    L.me_set_voxel_hint.argtypes = [vp, C.c_double]
+    L.me_set_voxel_hint.restype = C.c_int
     L.me_voxel_downsample.argtypes = [vp, C.c_int, C.c_double, C.POINTER(C.c_int64)]
     L.me_transform_cloud.argtypes = [vp, C.c_int, dp]
     L.me_upload_cloud.argtypes = [vp, C.c_int, dp, C.c_int64, dp, C.c_double]

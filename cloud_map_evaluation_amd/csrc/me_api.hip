@@ -170,6 +170,7 @@ me_ctx *me_twin(me_ctx *ctx) {
     t->borrow_device_input = ctx->borrow_device_input;
     t->morton_order = ctx->morton_order;
     t->slab = ctx->slab;
+    t->vox_hint = ctx->vox_hint;
     if (hipStreamCreateWithPriority(&t->stream, hipStreamNonBlocking, stream_priority_for(false)) != hipSuccess) {
         delete t;
         ctx->fail(ME_ERR_HIP, "me_twin: hipStreamCreate failed");
@@ -564,6 +565,15 @@ int me_w2_batch(me_ctx *ctx, const double *mu1, const double *sigma1, const int3
 int me_scs_table(me_ctx *ctx, const int32_t *keys, const double *w, int64_t n, int scs_radius, double *scs) {
     if (!ctx) return ME_ERR_ARG;
     return me::scs_table(ctx, keys, w, n, scs_radius, scs);
+}
+
+int me_set_voxel_hint(me_ctx *ctx, double voxel_size) {
+    if (!ctx) return ME_ERR_ARG;
+    if (!(voxel_size >= 0)) return ctx->fail(ME_ERR_ARG, "me_set_voxel_hint: voxel_size must be >= 0 (0: off)");
+    me_ctx *primary = ctx;
+    primary->vox_hint = voxel_size;
+    if (primary->twin) primary->twin->vox_hint = voxel_size;
+    return ME_OK;
 }
 
 int me_timers_enable(me_ctx *ctx, int on) {

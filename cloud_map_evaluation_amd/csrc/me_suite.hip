@@ -369,25 +369,27 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
     const auto t_all = Clock::now();
     // the index builds of this call also emit the voxel run records for vmd_voxel_size (me_index.hip: k_gather<VOX>), on both lanes
     // ... and leave the octrees to cloud_finish_octree when an MME pass comes first (it needs the cell tables only)
-    struct VoxHint {
+    struct VoxHint {  // (what me_set_voxel_hint had set comes back when the call is over)
         me_ctx *a, *b = nullptr;
         bool defer;
-        VoxHint(me_ctx *c, double v, bool d) : a(c), defer(d) {
+        double keep_a, keep_b = 0;
+        VoxHint(me_ctx *c, double v, bool d) : a(c), defer(d), keep_a(c->vox_hint) {
             a->vox_hint = v;
             a->defer_octree = d;
         }
         void also(me_ctx *t, double v) {
             b = t;
             if (b) {
+                keep_b = b->vox_hint;
                 b->vox_hint = v;
                 b->defer_octree = defer;
             }
         }
         ~VoxHint() {
-            a->vox_hint = 0;
+            a->vox_hint = keep_a;
             a->defer_octree = false;
             if (b) {
-                b->vox_hint = 0;
+                b->vox_hint = keep_b;
                 b->defer_octree = false;
             }
         }

@@ -630,6 +630,30 @@ def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, wor
     T = np.asarray(P.initial_matrix_, dtype=np.float64)
     if not np.array_equal(T, np.eye(4)):
         est_part = eng.transform_points(est_part.clone(), T)  # (:1206) before the exchange: slabs are cut in the map frame
+    with _voxel_hint(eng, P.vmd_voxel_size_):  # (round 6: the index builds emit the voxel run records, me_set_voxel_hint)
+        return _suite_step_dist_body(eng, dist, comm_device, est_part, gt_part, P, rank, world, evaluate_gt_mme, halo, two_lanes, tr)
+
+
+class _voxel_hint:
+    """me_set_voxel_hint for the duration of a step, where the engine offers it: the gathers of the step's index builds also emit the
+    voxel run records, and the voxel tables / partial rows of the step have no pass over the cloud left."""
+
+    def __init__(self, eng, voxel_size):
+        self.eng = eng if hasattr(eng, "set_voxel_hint") else None
+        self.vs = float(voxel_size)
+
+    def __enter__(self):
+        if self.eng is not None:
+            self.eng.set_voxel_hint(self.vs)
+        return self
+
+    def __exit__(self, *exc):
+        if self.eng is not None:
+            self.eng.set_voxel_hint(0.0)
+        return False
+
+
+def _suite_step_dist_body(eng, dist, comm_device, est_part, gt_part, P, rank, world, evaluate_gt_mme, halo, two_lanes, tr):
     if _LEAN and world > 1 and hasattr(eng, "lattice_histograms"):
         axis, cuts, halo, (est_r, gt_r) = plan_and_exchange(eng, dist, comm_device, est_part, gt_part, world, rank, halo)
         tr.mark("halo_exchange")
@@ -1105,13 +1129,14 @@ def suite_step(eng, dist, device, est, gt, P, evaluate_gt_mme: bool = True, uplo
         lane = _Lane(eng, gt, P, True, after_est=os.environ.get("ME_LANE_AFTER_EST", "1" if host_input else "0") == "1",
                      nn_back=os.environ.get("ME_LANE_NN_BACK", "1") == "1")
     try:
-        if upload:
-            eng.upload(ME_SLOT_EST, est, T=np.asarray(P.initial_matrix_, dtype=np.float64), cell_size=P.nn_radius_)
-            if lane is None:
-                eng.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
-        if lane is not None:
-            lane.est_ready.set()
-        res = _suite_after_upload(eng, dist, device, P, evaluate_gt_mme, lane)
+        with _voxel_hint(eng if upload else None, P.vmd_voxel_size_):
+            if upload:
+                eng.upload(ME_SLOT_EST, est, T=np.asarray(P.initial_matrix_, dtype=np.float64), cell_size=P.nn_radius_)
+                if lane is None:
+                    eng.upload(ME_SLOT_GT, gt, cell_size=P.nn_radius_)
+            if lane is not None:
+                lane.est_ready.set()
+            res = _suite_after_upload(eng, dist, device, P, evaluate_gt_mme, lane)
     except BaseException:
         if lane is not None:
             lane.abort()

@@ -531,6 +531,10 @@ class Engine:
         out = out[:total]
         return out, [int(x) for x in counts]
 
+    def set_voxel_hint(self, voxel_size: float):
+        """Index builds from now on also emit the voxel run records for this voxel size (0: off): me_set_voxel_hint."""
+        self._ck(self._L.me_set_voxel_hint(self._ctx, float(voxel_size)))
+
     def lattice_histograms(self, xyz, e0: int):
         """Marginal histograms of a raw cuda (n,3) float64 buffer on the absolute lattice of bin width 2^(e0 + level):
         (level, origin_bin int64[3], neg_inf int64[3], hist (3, ME_LATTICE_BINS) cuda int32).  me_lattice_histograms_device."""

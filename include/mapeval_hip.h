@@ -200,6 +200,12 @@ int me_halo_pack_device(me_ctx *ctx, const double *xyz_device, int64_t n, int ax
  * (the C++ host's per-point outputs: map_entropy.pcd, raw_rendered_dis_map.pcd, map_eval.cpp:485-495, 686-736). */
 int me_halo_pack_tagged_device(me_ctx *ctx, const double *xyz_device, int64_t n, int axis, const double *cuts, int world, double halo,
                                double *out_device, int64_t *tags_device, int64_t tag_base, int64_t capacity, int64_t *counts);
+/* voxel_size > 0: every index build of this context (and of its twin) from now on also emits the voxel run records of
+ * VoxelCalculator::buildVoxelMap for that voxel size (voxel_calculator.cpp:21-56) while it gathers the sorted cloud; a later
+ * me_voxel_gaussians / me_voxel_partials / me_voxel_partial_rows_device / me_awd_scs with the SAME size then has no pass over the cloud
+ * left (a sort and a reduction of ~n / 60 records).  Results as without the hint (keys and populations exact, sums to 1e-9 of their
+ * scale).  0: off (the default).  me_run_suite_from does this by itself for the duration of the call. */
+int me_set_voxel_hint(me_ctx *ctx, double voxel_size);
 /* The lean exchange (no reference counterpart; dist.py `lattice_plan`): the marginal histograms of a rank's part of a cloud on an
  * ABSOLUTE power-of-two lattice.  Bin i of axis a counts the finite coordinates with floor(x_a / w) == origin_bin[a] + i,
  * w = 2^(e0 + *level); *level is the smallest one for which every axis of this buffer fits ME_LATTICE_BINS bins.  neg_inf[a]

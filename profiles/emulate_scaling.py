@@ -6,7 +6,7 @@ what the other ranks DID contribute in an untimed recording pass of every rank's
 rank's own message, which made every rank search its own open queries world - 1 more times in the cross-rank step: queries next
 to its own slab, the ones its tree cannot prune, instead of the other ranks' which it mostly prunes at the root), so a rank's
 time is the compute + host work it would spend between collectives.  RCCL latency of
-the ~10 small collectives (~0.3-0.5 ms per step) and the halo payload (2 x 24 B x N / world^2 per link: < 0.3 ms at 8 ranks
+the 6 collectives of the lean step (round 6; ~0.2-0.3 ms per step) and the halo payload (2 x 24 B x N / world^2 per link: < 0.3 ms at 8 ranks
 over xGMI) are NOT included.  usage: python profiles/emulate_scaling.py [points] [--workload campus|c4_multisession] [--worlds 1,2,4,8]"""
 import json
 import sys
@@ -23,10 +23,11 @@ class FakeDist:
     class ReduceOp:
         SUM, MAX, MIN = "sum", "max", "min"
 
-    def __init__(self, world, rank, recv_counts=None, recv_points=None, record=None, replay=None):
+    def __init__(self, world, rank, recv_counts=None, recv_points=None, record=None, replay=None, preset=None):
         self.world, self.rank = world, rank
         self.recv_counts, self.recv_points = recv_counts, recv_points
         self.record, self.replay = record, replay  # {gather index within the step: {rank: message}}
+        self.preset = preset or {}                 # gathers whose messages are known beforehand (round 6: index 0, the lattice histograms)
         self.n_gather = 0
 
     def is_initialized(self):
@@ -48,7 +49,9 @@ class FakeDist:
             self.record.setdefault(idx, {})[self.rank] = buf.clone()
         for k, p in enumerate(parts):
             src = buf
-            if self.replay is not None and k != self.rank:
+            if idx in self.preset and k != self.rank:
+                src = self.preset[idx][k]
+            elif self.replay is not None and k != self.rank:
                 r = self.replay.get(idx, {}).get(k)
                 if r is not None and r.shape == buf.shape and r.dtype == buf.dtype:
                     src = r  # (a message of another shape — a rank whose step took another branch — falls back to the own copy)
@@ -79,9 +82,13 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
                   for r in range(world)]
         per_rank, detail = [], []
         if world > 1:
-            # what the halo exchange delivers to every rank (untimed): the cuts are those every rank computes
-            axis, cuts = medist.dist_slab_cuts(gt, None, dev, world, est_part=est)
-            packs = [[eng.halo_pack(p, axis, cuts, halo) for p in pc] for pc in pieces]  # [src][cloud] -> (points, counts)
+            # what the halo exchange delivers to every rank (untimed).  Round 6, the lean step: every rank's lattice histograms are
+            # computed beforehand and handed to each emulated rank as the result of its first all-gather, so that every rank plans
+            # the exchange the real job would run (same cuts, same split sizes: dist.lattice_plan checks them against halo_pack)
+            e0 = medist.lattice_e0(halo)
+            msgs = [medist.lattice_message(eng, list(pc), e0) for pc in pieces]
+            axis, cuts, halo_eff, _, _ = medist.lattice_plan(torch.stack(msgs), world, halo, e0)
+            packs = [[eng.halo_pack(p, axis, cuts, halo_eff) for p in pc] for pc in pieces]  # [src][cloud] -> (points, counts)
         recorded = {}
 
         def make_fd(rank, record, replay):
@@ -92,11 +99,9 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
                     pts, cnts = packs[s][c]
                     o = sum(cnts[:rank])
                     segs.append(pts[o:o + cnts[rank]])
-            return FakeDist(world, rank, rc, torch.cat(segs), record=record, replay=replay)
+            return FakeDist(world, rank, rc, torch.cat(segs), record=record, replay=replay, preset={0: {k: msgs[k] for k in range(world)}})
 
         if world > 1:
-            GLOBAL["cuts"] = (axis, cuts)
-            medist.dist_slab_cuts = _patched_cuts
             for rank in range(world):
                 fd = make_fd(rank, recorded, None)
                 medist.suite_step_dist(eng, fd, dev, pieces[rank][0], pieces[rank][1], P, rank, world, True, halo=halo, overlap=OVERLAP)
@@ -106,8 +111,6 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
                 fd, args = None, None
             else:
                 fd = make_fd(rank, None, recorded)
-                GLOBAL["cuts"] = (axis, cuts)
-                medist.dist_slab_cuts = _patched_cuts
             best, best_t = 1e9, None
             for rep in range(3):
                 eng.timers_enable(rep == 2)
@@ -139,7 +142,6 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
             best_t["open_queries"] = int(res.get("n_cross_rank_queries", 0)) if isinstance(res, dict) else 0
             for k in ("nn1_opened", "nn1_scans", "nn1_max_opened", "nn1_far", "nn1_far_opened", "nn1_far_points", "nn1_far_max"):  # (main lane's walks)
                 best_t[k] = int(eng.timer(k)[1])
-            medist.dist_slab_cuts = _orig_cuts
             per_rank.append(best * 1e3)
             detail.append(best_t)
         worst = max(range(world), key=lambda r: per_rank[r])
@@ -154,16 +156,7 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
                       "per_world": out, "speedup_vs_1": {w: base / v["max_ms"] for w, v in out.items()}}))
 
 
-_orig_cuts = medist.dist_slab_cuts
-GLOBAL = {}
 OVERLAP = __import__("os").environ.get("ME_EMU_OVERLAP", "1") != "0"  # 0: one lane (what the phases cost without the other lane)
-
-
-def _patched_cuts(gt_part, d, cd, w, sample=16384, est_part=None):
-    """Collective 1 repeats the rank's own sample here, so a rank alone would cut by its OWN quantiles: do the same device work, then
-    hand back the global cuts (those the precomputed exchange was made for)."""
-    _orig_cuts(gt_part, None, cd, w, sample, est_part=est_part)
-    return GLOBAL["cuts"]
 
 
 if __name__ == "__main__":
