@@ -606,7 +606,16 @@ def _upload_received(eng, slot, pts, P):
 def suite_step_dist(eng, dist, comm_device, est_part, gt_part, P, rank: int, world: int, evaluate_gt_mme: bool = True,
                     halo: float = 1.0, overlap: bool = True):
     """Full suite from DISTRIBUTED input: est_part / gt_part are this rank's 1/world of each cloud (device tensors; any
-    split, e.g. a contiguous piece of the file).  Returns the same dict as suite_step on every rank."""
+    split, e.g. a contiguous piece of the file).  Returns the same dict as suite_step on every rank.
+
+    Collectives of the lean step (round 6, the default; ME_DIST_LEAN=0: the eight of rounds 2 - 5), in dependency order:
+      1  all_gather   lattice histograms of every rank's two pieces  -> cuts, halo, every split size   (lattice_plan: host read 1)
+      2  all_to_all   the halo exchange (both clouds in one message)
+      3  all_gather   the fixed-capacity cross-rank message (open queries of both directions + bounds)
+      4  all_reduce   MIN of the answers
+      5  all_gather   partial sums + open-query counts + both clouds' voxel partial rows, fixed capacity       (host read 2)
+      6  all_reduce   sigma numerators + the other lane's MME sums                                            (the result)
+    Overflows (more than _CROSS_CAP open queries or _VOX_CAP voxel rows on some rank) add their exact-size collectives."""
     import torch
 
     two_lanes = overlap and hasattr(eng, "twin")
