@@ -590,7 +590,7 @@ def plan_and_exchange(eng, dist, comm_device, est_part, gt_part, world: int, ran
         dist.all_gather(parts, buf)
         allm = torch.stack(parts)
     axis, cuts, halo_eff, counts, _ = lattice_plan(allm, world, halo, e0)
-    recv = halo_exchange_planned(eng, dist, comm_device, [est_part, gt_part], axis, cuts, halo_eff, counts, rank if not _single(dist) or world > 1 else 0)
+    recv = halo_exchange_planned(eng, dist, comm_device, [est_part, gt_part], axis, cuts, halo_eff, counts, rank)
     return axis, cuts, halo_eff, recv
 
 
@@ -663,7 +663,7 @@ class _voxel_hint:
 
 
 def _suite_step_dist_body(eng, dist, comm_device, est_part, gt_part, P, rank, world, evaluate_gt_mme, halo, two_lanes, tr):
-    if _LEAN and world > 1 and hasattr(eng, "lattice_histograms"):
+    if _LEAN and (world > 1 or not _single(dist)) and hasattr(eng, "lattice_histograms"):  # (one rank with forced collectives: the RCCL test)
         axis, cuts, halo, (est_r, gt_r) = plan_and_exchange(eng, dist, comm_device, est_part, gt_part, world, rank, halo)
         tr.mark("halo_exchange")
     else:
