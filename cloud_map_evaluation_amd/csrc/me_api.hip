@@ -537,6 +537,12 @@ int me_lattice_histograms_device(me_ctx *ctx, const double *xyz_device, int64_t 
     return rc;
 }
 
+int me_lattice_plan_device(me_ctx *ctx, const int64_t *msgs_device, int world, int clouds, double halo, int e0, int64_t *out) {
+    if (!ctx) return ME_ERR_ARG;
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64_t is long long here");
+    return me::lattice_plan(ctx, reinterpret_cast<const long long *>(msgs_device), world, clouds, halo, e0, reinterpret_cast<long long *>(out));
+}
+
 int me_voxel_partial_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, int64_t capacity, int64_t *n_rows) {
     if (!ctx) return ME_ERR_ARG;
     long long n = 0;

@@ -285,6 +285,235 @@ int lattice_histograms(me_ctx *ctx, const double *xyz_device, long long n, int e
     return ME_OK;
 }
 
+// ---- the plan of the lean exchange from the gathered histogram messages (dist.lattice_plan restated on the device) ----
+// msgs: world x clouds rows of [level, origin_x, origin_y, origin_z, n, neg_inf_x, neg_inf_y, neg_inf_z | 3 x BINS counts] (int64).
+// Every step mirrors dist.lattice_plan (the torch form the CPU tests run) number for number.
+constexpr int kPlanG = 2 * ME_LATTICE_BINS;  // bins of the combined window
+constexpr int kPlanRow = 8 + 3 * ME_LATTICE_BINS;
+struct PlanHead {  // written by k_plan_extents, read by the two kernels after it
+    long long K, e, g0[3], axis, m, any_ref;
+};
+
+__global__ void __launch_bounds__(256)
+k_plan_extents(const long long *__restrict__ msgs, int world, int clouds, double halo, int e0, long long *__restrict__ rowext /* [rows][3][2] */,
+               PlanHead *__restrict__ head) {
+    constexpr int B = ME_LATTICE_BINS;
+    const int rows = world * clouds;
+    __shared__ int s_lo[4], s_hi[4];
+    // first / last occupied bin of every (row, axis)
+    for (int ra = 0; ra < rows * 3; ++ra) {
+        const long long *h = msgs + (long long) (ra / 3) * kPlanRow + 8 + (long long) (ra % 3) * B;
+        int lo = B, hi = -1;
+        for (int i = threadIdx.x; i < B; i += 256)
+            if (h[i] > 0) {
+                lo = min(lo, i);
+                hi = max(hi, i);
+            }
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o, 64));
+            hi = max(hi, __shfl_xor(hi, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_lo[threadIdx.x >> 6] = lo;
+            s_hi[threadIdx.x >> 6] = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            rowext[ra * 2] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+            rowext[ra * 2 + 1] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    long long K = 0;
+    for (int r = 0; r < rows; ++r) K = max(K, msgs[(long long) r * kPlanRow]);
+    const long long big = 1LL << 61;
+    long long amin[3], amax[3], gmin[3], gmax[3];  // occupied stretch per axis at level K: all rows / the ground truth's rows
+    bool any_gt = false;
+    for (int a = 0; a < 3; ++a) {
+        amin[a] = gmin[a] = big;
+        amax[a] = gmax[a] = -big;
+    }
+    for (int r = 0; r < rows; ++r) {
+        const long long *mr = msgs + (long long) r * kPlanRow;
+        const long long sh = K - mr[0];
+        for (int a = 0; a < 3; ++a) {
+            const long long lo = rowext[(r * 3 + a) * 2], hi = rowext[(r * 3 + a) * 2 + 1];
+            if (hi < 0) continue;
+            const long long alo = (mr[1 + a] + lo) >> sh, ahi = (mr[1 + a] + hi) >> sh;
+            amin[a] = min(amin[a], alo);
+            amax[a] = max(amax[a], ahi);
+            if (r % clouds == clouds - 1) {  // the ground truth's pieces
+                gmin[a] = min(gmin[a], alo);
+                gmax[a] = max(gmax[a], ahi);
+                any_gt = true;
+            }
+        }
+    }
+    // the slab axis: the longest occupied stretch of the ground truth (of everything when no rank holds any of it); an axis without an
+    // occupied bin in that set: -1 - G, as dist.lattice_plan's masked max - min gives
+    long long rlo[3], rhi[3];
+    for (int a = 0; a < 3; ++a) {
+        rlo[a] = any_gt ? gmin[a] : amin[a];
+        rhi[a] = any_gt ? gmax[a] : amax[a];
+    }
+    long long span = 1;
+    for (int a = 0; a < 3; ++a) {
+        if (amin[a] > amax[a]) amin[a] = amax[a] = 0;  // (an axis nobody has a finite coordinate on)
+        span = max(span, amax[a] - amin[a] + 1);
+    }
+    long long e = 0;
+    while (e < 50 && ((long long) (kPlanG - 1) << e) < span) ++e;  // (2^13 << 49 < 2^63; bins are clamped to +-2^60)
+    for (int it = 0; it < 2; ++it) {
+        long long se = 0;
+        for (int a = 0; a < 3; ++a) se = max(se, (amax[a] >> e) - (amin[a] >> e) + 1);
+        if (se > kPlanG) ++e;
+    }
+    long long best = 0, best_ext = 0;
+    for (int a = 0; a < 3; ++a) {
+        const long long ext = rlo[a] <= rhi[a] ? (rhi[a] >> e) - (rlo[a] >> e) : (long long) (-1 - kPlanG);
+        if (a == 0 || ext > best_ext) {
+            best = a;
+            best_ext = ext;
+        }
+    }
+    head->K = K;
+    head->e = e;
+    for (int a = 0; a < 3; ++a) head->g0[a] = amin[a] >> e;
+    head->axis = best;
+    const double mm = ceil(halo * ldexp(1.0, -(int) (K + e + e0)));
+    head->m = mm < 1.0 ? 1 : (long long) mm;
+    head->any_ref = any_gt ? 1 : 0;
+}
+
+// one block per (rank, cloud): its histogram of the slab axis re-binned into the combined window -> exclusive prefix P[0 .. G]
+__global__ void __launch_bounds__(256)
+k_plan_prefix(const long long *__restrict__ msgs, const PlanHead *__restrict__ head, long long *__restrict__ P /* [rows][G + 1] */) {
+    constexpr int B = ME_LATTICE_BINS, G = kPlanG;
+    __shared__ unsigned long long sh[G];
+    __shared__ unsigned long long part[256];
+    const int r = blockIdx.x;
+    const long long *mr = msgs + (long long) r * kPlanRow;
+    const int axis = (int) head->axis;
+    const long long shf = head->K - mr[0], e = head->e, g0 = head->g0[axis], org = mr[1 + axis];
+    const long long *h = mr + 8 + (long long) axis * B;
+    for (int i = threadIdx.x; i < G; i += 256) sh[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const long long v = h[i];
+        if (v > 0) {
+            long long idx = (((org + i) >> shf) >> e) - g0;
+            idx = idx < 0 ? 0 : (idx > G - 1 ? G - 1 : idx);
+            atomicAdd(&sh[idx], (unsigned long long) v);
+        }
+    }
+    __syncthreads();
+    constexpr int PER = G / 256;
+    unsigned long long run = 0;
+    for (int j = 0; j < PER; ++j) run += sh[threadIdx.x * PER + j];
+    part[threadIdx.x] = run;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 0;
+        for (int t = 0; t < 256; ++t) {
+            const unsigned long long v = part[t];
+            part[t] = acc;
+            acc += v;
+        }
+    }
+    __syncthreads();
+    unsigned long long acc = part[threadIdx.x];
+    long long *Pr = P + (long long) r * (G + 1);
+    for (int j = 0; j < PER; ++j) {
+        Pr[threadIdx.x * PER + j] = (long long) acc;
+        acc += sh[threadIdx.x * PER + j];
+    }
+    if (threadIdx.x == 255) Pr[G] = (long long) acc;
+}
+
+// cuts at the k / world quantiles of all rows' counts, then every (source row, destination) count
+__global__ void __launch_bounds__(256)
+k_plan_cuts_counts(const long long *__restrict__ msgs, const PlanHead *__restrict__ head, const long long *__restrict__ P, int world, int clouds,
+                   long long *__restrict__ out) {
+    constexpr int G = kPlanG;
+    const int rows = world * clouds;
+    __shared__ long long s_c[kMaxWorld + 1], s_lo[kMaxWorld], s_hi[kMaxWorld];
+    auto cum = [&](int j) {  // points of all rows in bins [0, j]
+        long long t = 0;
+        for (int r = 0; r < rows; ++r) t += P[(long long) r * (G + 1) + j + 1];
+        return t;
+    };
+    const long long N = cum(G - 1);
+    if ((int) threadIdx.x < world - 1) {
+        const long long k = threadIdx.x + 1;
+        long long target = (N * k + world - 1) / world;
+        if (target < 1) target = 1;
+        int lo = 0, hi = G;  // first j with cum(j) >= target (G: none)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cum(mid) >= target) hi = mid;
+            else lo = mid + 1;
+        }
+        s_c[k] = lo + 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = -(1LL << 60);
+        for (int k = 1; k < world; ++k) {  // strictly ascending: cummax(c - step) + step
+            run = max(run, s_c[k] - (k - 1));
+            s_c[k] = run + (k - 1);
+        }
+        const long long m = head->m;
+        for (int k = 0; k < world; ++k) {
+            long long lo = k == 0 ? 0 : s_c[k] - m, hi = k == world - 1 ? G : s_c[k + 1] + m;
+            s_lo[k] = lo < 0 ? 0 : (lo > G ? G : lo);
+            s_hi[k] = hi < 0 ? 0 : (hi > G ? G : hi);
+        }
+        out[0] = head->axis;
+        out[1] = head->K + head->e;
+        out[2] = head->g0[head->axis];
+        out[3] = m;
+        for (int c = 0; c < clouds; ++c) {
+            long long t = 0;
+            for (int w = 0; w < world; ++w) t += msgs[(long long) (w * clouds + c) * kPlanRow + 4];
+            out[4 + c] = t;
+        }
+        for (int k = 1; k < world; ++k) out[4 + clouds + k - 1] = s_c[k];
+    }
+    __syncthreads();
+    const int axis = (int) head->axis;
+    for (int t = threadIdx.x; t < rows * world; t += 256) {
+        const int r = t / world, k = t % world;
+        long long v = P[(long long) r * (G + 1) + s_hi[k]] - P[(long long) r * (G + 1) + s_lo[k]];
+        if (v < 0) v = 0;
+        if (k == 0) v += msgs[(long long) r * kPlanRow + 5 + axis];
+        out[4 + clouds + world - 1 + t] = v;
+    }
+}
+
+int lattice_plan(me_ctx *ctx, const long long *msgs_device, int world, int clouds, double halo, int e0, long long *out_host) {
+    if (!msgs_device || world < 1 || world > kMaxWorld || clouds < 1 || clouds > 2 || !(halo > 0) || e0 < -40 || e0 > 40 || !out_host)
+        return ctx->fail(ME_ERR_ARG, "me_lattice_plan_device: bad argument (1 <= world <= 64, 1 <= clouds <= 2, halo > 0)");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    const int rows = world * clouds;
+    const size_t n_out = (size_t) 4 + clouds + (world - 1) + (size_t) rows * world;
+    DevBuf &ext = ctx->tmp[0], &pre = ctx->tmp[1], &outb = ctx->tmp[2];
+    ME_CHECK(ctx, ext.ensure((size_t) rows * 6 * 8 + sizeof(PlanHead)));
+    ME_CHECK(ctx, pre.ensure((size_t) rows * (kPlanG + 1) * 8));
+    ME_CHECK(ctx, outb.ensure(n_out * 8));
+    long long *d_ext = ext.as<long long>();
+    PlanHead *d_head = reinterpret_cast<PlanHead *>(d_ext + (size_t) rows * 6);
+    TimerScope ts(ctx, "halo_pack");
+    hipLaunchKernelGGL(k_plan_extents, dim3(1), dim3(256), 0, ctx->stream, msgs_device, world, clouds, halo, e0, d_ext, d_head);
+    hipLaunchKernelGGL(k_plan_prefix, dim3((unsigned int) rows), dim3(256), 0, ctx->stream, msgs_device, (const PlanHead *) d_head, pre.as<long long>());
+    hipLaunchKernelGGL(k_plan_cuts_counts, dim3(1), dim3(256), 0, ctx->stream, msgs_device, (const PlanHead *) d_head, (const long long *) pre.as<long long>(),
+                       world, clouds, outb.as<long long>());
+    ME_CHECK(ctx, hipGetLastError());
+    ME_TRY(copy_d2h(ctx, out_host, outb.p, n_out * 8));
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
 // ---- voxel partial rows: [kx, ky, kz, n, mu(3), M2(9)] = 16 doubles per voxel ----
 constexpr int kRow = 16;
 

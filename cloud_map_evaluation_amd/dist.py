@@ -480,13 +480,28 @@ def lattice_message(eng, parts, e0: int):
     return torch.stack(rows)
 
 
-def lattice_plan(allm, world: int, halo: float, e0: int):
+def _unpack_plan(flat, W: int, nc: int, world: int, e0: int):
+    axis_h, kk, g0_h, m_h = int(flat[0]), int(flat[1]), int(flat[2]), int(flat[3])
+    totals = [int(v) for v in flat[4:4 + nc]]
+    c_h = [int(v) for v in flat[4 + nc:4 + nc + world - 1]]
+    cnt = np.asarray(flat[4 + nc + world - 1:], dtype=np.int64).reshape(W, nc, world)
+    w = float(2.0 ** (e0 + kk))
+    inf = float("inf")
+    cuts = [-inf] + [float((g0_h + ck) * w) for ck in c_h] + [inf]
+    return axis_h, cuts, float(m_h * w), cnt, totals
+
+
+def lattice_plan(allm, world: int, halo: float, e0: int, eng=None):
     """allm: the gathered messages (world, clouds, 8 + 3 LATTICE_BINS), identical on every rank; the LAST cloud is the ground truth
-    (its extent picks the slab axis, as dist_slab_cuts does).  Everything is computed on allm's device with fixed shapes; ONE host read
-    returns (axis, cuts[world + 1], halo_eff, counts[src][cloud][dst], totals[cloud])."""
+    (its extent picks the slab axis, as dist_slab_cuts does).  ONE host read returns (axis, cuts[world + 1], halo_eff,
+    counts[src][cloud][dst], totals[cloud]).  With an engine that offers it the plan is three small kernels of the library
+    (me_lattice_plan_device: the ~45 tensor operations below cost the head of an 8-rank step 0.9 ms); the torch form is what the CPU
+    tests run, and the GPU tests hold the two equal number for number."""
     import torch
 
     W, nc = int(allm.shape[0]), int(allm.shape[1])
+    if eng is not None and hasattr(eng, "lattice_plan_raw") and W == world:
+        return _unpack_plan(eng.lattice_plan_raw(allm, halo, e0), W, nc, world, e0)
     B, G = LATTICE_BINS, _GLOBAL_BINS
     dev = allm.device
     meta = allm[:, :, :8]
@@ -503,7 +518,7 @@ def lattice_plan(allm, world: int, halo: float, e0: int):
     amin = torch.where(empty, torch.zeros_like(amin), amin)
     amax = torch.where(empty, torch.zeros_like(amax), amax)
     span = (amax - amin + 1).max()
-    e = torch.clamp(torch.ceil(torch.log2(span.double() / (G - 1))), min=0).to(torch.int64)
+    e = (torch.bitwise_left_shift(torch.full((50,), G - 1, dtype=torch.int64, device=dev), torch.arange(50, device=dev)) < span).sum()  # smallest e with (G - 1) 2^e >= span
     for _ in range(2):  # (the shifted window can be one bin longer than span / 2^e)
         s_e = (torch.bitwise_right_shift(amax, e) - torch.bitwise_right_shift(amin, e) + 1).max()
         e = torch.where(s_e > G, e + 1, e)
@@ -534,14 +549,7 @@ def lattice_plan(allm, world: int, halo: float, e0: int):
     counts = torch.clamp(counts, min=0)                                                      # (lo > hi cannot happen: c ascending, m >= 1)
     counts[:, :, 0] += ninf.index_select(2, axis.view(1)).squeeze(2)                         # -inf >= -inf: rank 0's
     flat = torch.cat([axis.view(1), KK.view(1), g0.index_select(0, axis.view(1)), m.view(1), npts.sum(0), c, counts.reshape(-1)]).cpu().tolist()
-    axis_h, kk, g0_h, m_h = int(flat[0]), int(flat[1]), int(flat[2]), int(flat[3])
-    totals = [int(v) for v in flat[4:4 + nc]]
-    c_h = [int(v) for v in flat[4 + nc:4 + nc + world - 1]]
-    cnt = np.asarray(flat[4 + nc + world - 1:], dtype=np.int64).reshape(W, nc, world)
-    w = float(2.0 ** (e0 + kk))
-    inf = float("inf")
-    cuts = [-inf] + [float((g0_h + ck) * w) for ck in c_h] + [inf]
-    return axis_h, cuts, float(m_h * w), cnt, totals
+    return _unpack_plan(flat, W, nc, world, e0)
 
 
 def halo_exchange_planned(eng, dist, comm_device, parts, axis: int, cuts, halo: float, counts, rank: int):
@@ -589,7 +597,7 @@ def plan_and_exchange(eng, dist, comm_device, est_part, gt_part, world: int, ran
         parts = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, buf)
         allm = torch.stack(parts)
-    axis, cuts, halo_eff, counts, _ = lattice_plan(allm, world, halo, e0)
+    axis, cuts, halo_eff, counts, _ = lattice_plan(allm, world, halo, e0, eng=eng)
     recv = halo_exchange_planned(eng, dist, comm_device, [est_part, gt_part], axis, cuts, halo_eff, counts, rank)
     return axis, cuts, halo_eff, recv
 
@@ -706,7 +714,7 @@ def _hp_stream(device):
 
 
 _CROSS_CAP = 4096  # open queries per direction and rank the folded all-gather carries (overflow: exact-size fallback)
-_VOX_CAP = 4096    # voxel partial rows per cloud and rank the folded statistics gather carries (overflow: exact-size gather)
+_VOX_CAP = 1024    # voxel partial rows per cloud and rank the folded statistics gather carries (overflow: exact-size gather)
 _FOLD_HEAD = 3     # header rows of that message: VEC_LEN partial sums, the two row counts, the open-query counts and cloud sizes in 3 x 16 doubles
 
 
@@ -896,11 +904,16 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
             hv = np.zeros(_FOLD_HEAD * 16)
             hv[:VEC_LEN] = pack_partials(parts, m_e, m_g)
             hv[VEC_LEN:VEC_LEN + 6] = [rows[0].shape[0], rows[1].shape[0], cnt[0], cnt[1], n_loc[0], n_loc[1]]
-            head = torch.from_numpy(hv.reshape(_FOLD_HEAD, 16)).to(comm_device)
-            msg = torch.cat([head, _pad_rows(rows[0][:_VOX_CAP], _VOX_CAP, 16, comm_device), _pad_rows(rows[1][:_VOX_CAP], _VOX_CAP, 16, comm_device)])
-            gparts = [torch.empty_like(msg) for _ in range(world)]
-            dist.all_gather(gparts, msg)
-            allr = torch.stack(gparts)                                    # (world, _FOLD_HEAD + 2 _VOX_CAP, 16)
+            # (one buffer, written in place, gathered into the slices of one tensor: the message is built with five small operations —
+            # the first version padded, concatenated and stacked 2 MB per rank and cost the step more than the collective it saved)
+            msg = torch.zeros((_FOLD_HEAD + 2 * _VOX_CAP, 16), dtype=torch.float64, device=comm_device)
+            msg[:_FOLD_HEAD] = torch.from_numpy(hv.reshape(_FOLD_HEAD, 16))
+            for c in range(2):
+                k = min(int(rows[c].shape[0]), _VOX_CAP)
+                if k:
+                    msg[_FOLD_HEAD + c * _VOX_CAP:_FOLD_HEAD + c * _VOX_CAP + k] = rows[c][:k]
+            allr = torch.empty((world,) + tuple(msg.shape), dtype=torch.float64, device=comm_device)
+            dist.all_gather(list(allr.unbind(0)), msg)                    # (world, _FOLD_HEAD + 2 _VOX_CAP, 16)
             return allr, allr[:, :_FOLD_HEAD].reshape(world, -1).cpu().numpy()  # the host read of this phase
 
         allr, heads = stats_gather(parts)

@@ -531,6 +531,18 @@ class Engine:
         out = out[:total]
         return out, [int(x) for x in counts]
 
+    def lattice_plan_raw(self, allm, halo: float, e0: int):
+        """The plan of the lean exchange from the gathered messages (world, clouds, 8 + 3 ME_LATTICE_BINS) int64 cuda tensor:
+        me_lattice_plan_device's output vector as numpy int64 (dist.lattice_plan unpacks it)."""
+        import torch
+
+        g = allm.to(torch.device("cuda", self.device), torch.int64).contiguous()
+        world, clouds = int(g.shape[0]), int(g.shape[1])
+        out = np.zeros(4 + clouds + world - 1 + world * clouds * world, np.int64)
+        torch.cuda.current_stream(g.device).synchronize()
+        self._ck(self._L.me_lattice_plan_device(self._ctx, g.data_ptr(), world, clouds, float(halo), int(e0), out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
     def set_voxel_hint(self, voxel_size: float):
         """Index builds from now on also emit the voxel run records for this voxel size (0: off): me_set_voxel_hint."""
         self._ck(self._L.me_set_voxel_hint(self._ctx, float(voxel_size)))

@@ -83,6 +83,25 @@ def test_lattice_histograms_and_the_plan_they_give_against_numpy_and_halo_pack()
         for r in range(world):
             for c in range(2):
                 assert eng.halo_pack(parts[r][c], axis, cuts, halo_eff)[1] == [int(x) for x in counts[r][c]]
+        # me_lattice_plan_device (what the step runs on the GPU) == dist.lattice_plan's torch form (what the CPU tests run), on ragged sets
+        from test_dist_gloo import numpy_lattice_histograms as nlh  # noqa: F401
+
+        def both(parts_np, world, halo):
+            e0 = medist.lattice_e0(halo)
+            allm = torch.stack([medist.lattice_message(eng, [torch.from_numpy(np.ascontiguousarray(c)).to(dev) for c in pr], e0) for pr in parts_np])
+            a = medist.lattice_plan(allm, world, halo, e0)
+            b = medist.lattice_plan(allm, world, halo, e0, eng=eng)
+            assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and np.array_equal(a[3], b[3]) and a[4] == b[4], (a[:3], b[:3])
+
+        both([[p.cpu().numpy() for p in pr] for pr in parts], 4, 0.3)
+        a = rng.uniform(0, 10, (2000, 3))
+        a[5, 0], a[6, 0], a[7, 0], a[8, 1] = -np.inf, np.inf, np.nan, -np.inf
+        both([[a, rng.uniform(0, 10, (1500, 3))], [np.zeros((0, 3)), rng.uniform(0, 10, (900, 3))], [rng.uniform(0, 10, (10, 3)), np.zeros((0, 3))],
+              [np.zeros((0, 3)), np.zeros((0, 3))]], 4, 0.3)
+        both([[rng.uniform(0, 60, (2000, 3)) + [0, 400.0 * r, 0], rng.uniform(0, 60, (2000, 3)) + [0, 400.0 * r, 0]] for r in range(8)], 8, 1.0)
+        both([[rng.uniform(-4000, 9000, (3000, 3)), np.zeros((0, 3))] for _ in range(3)], 3, 0.11)   # no ground truth anywhere
+        both([[np.tile([[1.0, 2.0, 3.0]], (500, 1)), np.tile([[1.0, 2.0, 3.0]], (400, 1))] for _ in range(5)], 5, 0.3)
+        both([[rng.uniform(0, 5, (100, 3)), rng.uniform(0, 5, (80, 3))]], 1, 0.3)
 
 
 def test_transform_points_device_is_the_upload_transform():
