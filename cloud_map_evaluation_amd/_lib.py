@@ -25,7 +25,7 @@ ME_LATTICE_BINS = 4096  # bins per axis of me_lattice_histograms_device
 SYMBOLS = [
     "me_create", "me_destroy", "me_twin", "me_last_error", "me_version", "me_set_shard", "me_set_slab",
     "me_nn_unresolved", "me_nn_points", "me_nn_points_bounded", "me_nn_points_covered", "me_nn_cross_message", "me_nn_cross_answer", "me_nn_cross_patch", "me_nn_patch", "me_nn_fetch", "me_slab_points", "me_set_mme_result", "me_set_nn_result", "me_voxel_partials",
-    "me_transform_points_device", "me_upload_slab_device", "me_halo_pack_device", "me_halo_pack_tagged_device", "me_lattice_histograms_device", "me_lattice_plan_device", "me_voxel_partial_rows_device", "me_voxel_merge_device",
+    "me_transform_points_device", "me_upload_slab_device", "me_halo_pack_device", "me_halo_pack_tagged_device", "me_lattice_histograms_device", "me_lattice_messages_device", "me_lattice_plan_device", "me_voxel_partial_rows_device", "me_voxel_merge_device",
     "me_upload_cloud", "me_upload_cloud_device", "me_cloud_size", "me_download_cloud", "me_voxel_downsample",
     "me_transform_cloud",
     "me_set_normals", "me_get_normals", "me_estimate_normals", "me_gicp_covariances", "me_get_covariances", "me_icp_lsq_sums",
@@ -161,6 +161,8 @@ def load():
     L.me_halo_pack_tagged_device.restype = C.c_int
     L.me_lattice_histograms_device.argtypes = [vp, dp, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]
     L.me_lattice_histograms_device.restype = C.c_int
+    L.me_lattice_messages_device.argtypes = [vp, dp, C.c_int64, dp, C.c_int64, C.c_int, C.c_int, vp]
+    L.me_lattice_messages_device.restype = C.c_int
     L.me_lattice_plan_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int64)]
     L.me_lattice_plan_device.restype = C.c_int
     L.me_voxel_partial_rows_device.argtypes = [vp, C.c_int, C.c_double, dp, C.c_int64, C.POINTER(C.c_int64)]

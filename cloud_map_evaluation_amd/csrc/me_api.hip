@@ -537,6 +537,14 @@ int me_lattice_histograms_device(me_ctx *ctx, const double *xyz_device, int64_t 
     return rc;
 }
 
+int me_lattice_messages_device(me_ctx *ctx, const double *xyz_a_device, int64_t n_a, const double *xyz_b_device, int64_t n_b, int clouds, int e0,
+                               int64_t *msg_device) {
+    if (!ctx) return ME_ERR_ARG;
+    const double *x[2] = {xyz_a_device, xyz_b_device};
+    const long long n[2] = {(long long) n_a, (long long) n_b};
+    return me::lattice_messages(ctx, x, n, clouds, e0, reinterpret_cast<long long *>(msg_device));
+}
+
 int me_lattice_plan_device(me_ctx *ctx, const int64_t *msgs_device, int world, int clouds, double halo, int e0, int64_t *out) {
     if (!ctx) return ME_ERR_ARG;
     static_assert(sizeof(long long) == sizeof(int64_t), "int64_t is long long here");

@@ -285,6 +285,78 @@ int lattice_histograms(me_ctx *ctx, const double *xyz_device, long long n, int e
     return ME_OK;
 }
 
+// ... and the two pieces of a rank at once, as the rows of its gather message (header included): two launches per piece, ONE host read
+// (both ranges) and one stream synchronisation for both — what dist.lattice_message costs at the head of every step
+template <int BINS>
+__global__ void __launch_bounds__(256)
+k_lattice_row(const double *__restrict__ xyz, long long n, double inv_w, LatOrigin org, long long level, const long long *__restrict__ range,
+              long long *__restrict__ row /* 8 + 3 BINS */) {
+    __shared__ unsigned int sh[3 * BINS];
+    for (int i = threadIdx.x; i < 3 * BINS; i += 256) sh[i] = 0;
+    __syncthreads();
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; ++a) {
+            const double v = xyz[3 * i + a];
+            if (!isfinite(v)) continue;
+            const long long b = lattice_bin(v, inv_w) - org.o[a];
+            if (b >= 0 && b < BINS) atomicAdd(&sh[a * BINS + (int) b], 1u);  // (always: the window was chosen from the range of these points)
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * BINS; i += 256)
+        if (sh[i]) atomicAdd(reinterpret_cast<unsigned long long *>(row + 8 + i), (unsigned long long) sh[i]);
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        const int t = threadIdx.x;
+        row[t] = t == 0 ? level : (t < 4 ? org.o[t - 1] : (t == 4 ? n : range[6 + (t - 5)]));
+    }
+}
+
+int lattice_messages(me_ctx *ctx, const double *const xyz_device[2], const long long n[2], int clouds, int e0, long long *msg_device) {
+    if (clouds < 1 || clouds > 2 || !xyz_device || !n || e0 < -40 || e0 > 40 || !msg_device)
+        return ctx->fail(ME_ERR_ARG, "me_lattice_messages_device: bad argument (1 <= clouds <= 2, -40 <= e0 <= 40)");
+    for (int c = 0; c < clouds; ++c)
+        if (n[c] < 0 || (n[c] > 0 && !xyz_device[c])) return ctx->fail(ME_ERR_ARG, "me_lattice_messages_device: bad cloud");
+    ME_CHECK(ctx, hipSetDevice(ctx->device));
+    constexpr int B = ME_LATTICE_BINS;
+    constexpr size_t row_len = 8 + 3 * (size_t) B;
+    TimerScope ts(ctx, "halo_pack");
+    ME_CHECK(ctx, hipMemsetAsync(msg_device, 0, (size_t) clouds * row_len * 8, ctx->stream));
+    ME_CHECK(ctx, ctx->red.ensure(2 * 10 * 8));
+    long long *d_range = ctx->red.as<long long>();
+    long long init[20];
+    for (int c = 0; c < 2; ++c)
+        for (int k = 0; k < 10; ++k) init[c * 10 + k] = k < 3 ? kLatClamp : (k < 6 ? -kLatClamp : 0);
+    ME_CHECK(ctx, hipMemcpyAsync(d_range, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    for (int c = 0; c < clouds; ++c)
+        if (n[c] > 0)
+            hipLaunchKernelGGL(k_lattice_range, dim3((unsigned int) std::min<long long>((n[c] + 255) / 256, 1024)), dim3(256), 0, ctx->stream,
+                               xyz_device[c], n[c], std::ldexp(1.0, -e0), d_range + c * 10);
+    long long h[20];
+    {
+        MailGuard mg(ctx);
+        ME_TRY(mail_post(ctx, h, d_range, sizeof h));
+        ME_TRY(mg.sync());
+    }
+    for (int c = 0; c < clouds; ++c) {
+        const long long *hc = h + c * 10;
+        int L = 0;
+        auto fits = [&](int l) {
+            for (int a = 0; a < 3; ++a)
+                if (hc[a] <= hc[3 + a] && (hc[3 + a] >> l) - (hc[a] >> l) + 1 > (long long) B) return false;
+            return true;
+        };
+        while (L < 62 && !fits(L)) ++L;
+        LatOrigin org{};
+        for (int a = 0; a < 3; ++a) org.o[a] = (hc[a] <= hc[3 + a]) ? (hc[a] >> L) : 0;
+        // (an empty piece: one block writes the header — level 0, origin 0, n = 0 — and no counts)
+        const unsigned int grid = n[c] > 0 ? (unsigned int) std::min<long long>((n[c] + 255) / 256, 256) : 1u;
+        hipLaunchKernelGGL((k_lattice_row<B>), dim3(grid), dim3(256), 0, ctx->stream, xyz_device[c], n[c], std::ldexp(1.0, -(e0 + L)), org,
+                           (long long) L, (const long long *) (d_range + c * 10), msg_device + (size_t) c * row_len);
+    }
+    ME_CHECK(ctx, hipGetLastError());
+    ME_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ME_OK;
+}
+
 // ---- the plan of the lean exchange from the gathered histogram messages (dist.lattice_plan restated on the device) ----
 // msgs: world x clouds rows of [level, origin_x, origin_y, origin_z, n, neg_inf_x, neg_inf_y, neg_inf_z | 3 x BINS counts] (int64).
 // Every step mirrors dist.lattice_plan (the torch form the CPU tests run) number for number.
@@ -294,36 +366,37 @@ struct PlanHead {  // written by k_plan_extents, read by the two kernels after i
     long long K, e, g0[3], axis, m, any_ref;
 };
 
+// first / last occupied bin of one (row, axis) per block
 __global__ void __launch_bounds__(256)
-k_plan_extents(const long long *__restrict__ msgs, int world, int clouds, double halo, int e0, long long *__restrict__ rowext /* [rows][3][2] */,
-               PlanHead *__restrict__ head) {
+k_plan_rowext(const long long *__restrict__ msgs, long long *__restrict__ rowext /* [rows][3][2] */) {
     constexpr int B = ME_LATTICE_BINS;
-    const int rows = world * clouds;
-    __shared__ int s_lo[4], s_hi[4];
-    // first / last occupied bin of every (row, axis)
-    for (int ra = 0; ra < rows * 3; ++ra) {
-        const long long *h = msgs + (long long) (ra / 3) * kPlanRow + 8 + (long long) (ra % 3) * B;
-        int lo = B, hi = -1;
-        for (int i = threadIdx.x; i < B; i += 256)
-            if (h[i] > 0) {
-                lo = min(lo, i);
-                hi = max(hi, i);
-            }
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = min(lo, __shfl_xor(lo, o, 64));
-            hi = max(hi, __shfl_xor(hi, o, 64));
+    const int ra = blockIdx.x;
+    const long long *h = msgs + (long long) (ra / 3) * kPlanRow + 8 + (long long) (ra % 3) * B;
+    int lo = B, hi = -1;
+    for (int i = threadIdx.x; i < B; i += 256)
+        if (h[i] > 0) {
+            lo = min(lo, i);
+            hi = max(hi, i);
         }
-        if ((threadIdx.x & 63) == 0) {
-            s_lo[threadIdx.x >> 6] = lo;
-            s_hi[threadIdx.x >> 6] = hi;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            rowext[ra * 2] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
-            rowext[ra * 2 + 1] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
-        }
-        __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
     }
+    __shared__ int s_lo[4], s_hi[4];
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        rowext[ra * 2] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        rowext[ra * 2 + 1] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+    }
+}
+
+__global__ void k_plan_extents(const long long *__restrict__ msgs, int world, int clouds, double halo, int e0,
+                               const long long *__restrict__ rowext, PlanHead *__restrict__ head) {
+    const int rows = world * clouds;
     if (threadIdx.x != 0) return;
     long long K = 0;
     for (int r = 0; r < rows; ++r) K = max(K, msgs[(long long) r * kPlanRow]);
@@ -504,7 +577,8 @@ int lattice_plan(me_ctx *ctx, const long long *msgs_device, int world, int cloud
     long long *d_ext = ext.as<long long>();
     PlanHead *d_head = reinterpret_cast<PlanHead *>(d_ext + (size_t) rows * 6);
     TimerScope ts(ctx, "halo_pack");
-    hipLaunchKernelGGL(k_plan_extents, dim3(1), dim3(256), 0, ctx->stream, msgs_device, world, clouds, halo, e0, d_ext, d_head);
+    hipLaunchKernelGGL(k_plan_rowext, dim3((unsigned int) rows * 3), dim3(256), 0, ctx->stream, msgs_device, d_ext);
+    hipLaunchKernelGGL(k_plan_extents, dim3(1), dim3(1), 0, ctx->stream, msgs_device, world, clouds, halo, e0, (const long long *) d_ext, d_head);
     hipLaunchKernelGGL(k_plan_prefix, dim3((unsigned int) rows), dim3(256), 0, ctx->stream, msgs_device, (const PlanHead *) d_head, pre.as<long long>());
     hipLaunchKernelGGL(k_plan_cuts_counts, dim3(1), dim3(256), 0, ctx->stream, msgs_device, (const PlanHead *) d_head, (const long long *) pre.as<long long>(),
                        world, clouds, outb.as<long long>());

@@ -497,6 +497,7 @@ int mme_carry_in(me_ctx *ctx, int slot);   // ... and put it back in the new sor
 int halo_pack(me_ctx *ctx, const double *xyz_device, long long n, int axis, const double *cuts_host, int world, double halo,
               double *out_device, long long capacity, long long *counts_host, long long *tags_device = nullptr, long long tag_base = 0);
 int voxel_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, long long capacity, long long *n_rows);
+int lattice_messages(me_ctx *ctx, const double *const xyz_device[2], const long long n[2], int clouds, int e0, long long *msg_device);
 int lattice_plan(me_ctx *ctx, const long long *msgs_device, int world, int clouds, double halo, int e0, long long *out_host);
 int lattice_histograms(me_ctx *ctx, const double *xyz_device, long long n, int e0, int *level, long long origin_bin[3], long long neg_inf[3],
                        unsigned int *hist_device);

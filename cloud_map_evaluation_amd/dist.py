@@ -89,6 +89,28 @@ def _all_reduce(t, dist, comm_device, op=None):
     return c.to(src_device)
 
 
+_INTO_TENSOR = {}  # backend name -> does all_gather_into_tensor work there
+
+
+def _all_gather_stacked(msg, dist):
+    """all_gather of equal messages into ONE (world, ...) tensor.  all_gather_into_tensor where the backend has it (RCCL: one kernel,
+    no per-rank copies out of a flattened buffer); the list form writing into the slices of that tensor elsewhere (gloo)."""
+    import torch
+
+    world = dist.get_world_size()
+    out = torch.empty((world,) + tuple(msg.shape), dtype=msg.dtype, device=msg.device)
+    key = dist.get_backend() if hasattr(dist, "get_backend") else "?"
+    if hasattr(dist, "all_gather_into_tensor") and _INTO_TENSOR.get(key, True):
+        try:
+            dist.all_gather_into_tensor(out.view(-1), msg.contiguous().view(-1))
+            _INTO_TENSOR[key] = True
+            return out
+        except (RuntimeError, NotImplementedError):
+            _INTO_TENSOR[key] = False
+    dist.all_gather(list(out.unbind(0)), msg.contiguous())
+    return out
+
+
 def _all_gather_rows(t, rows_max: int, dist, comm_device, pad_value: float):
     """all_gather of a (rows, k) tensor padded to rows_max rows -> (world * rows_max, k) on t.device."""
     import torch
@@ -471,6 +493,8 @@ def lattice_message(eng, parts, e0: int):
     [level, origin_x, origin_y, origin_z, n, neg_inf_x, neg_inf_y, neg_inf_z | histogram, axis-major]."""
     import torch
 
+    if hasattr(eng, "lattice_messages") and 1 <= len(parts) <= 2:
+        return eng.lattice_messages(parts, e0)  # (one library call for both pieces, header included: no tensor operation here)
     rows = []
     for p in parts:
         level, origin, ninf, hist = eng.lattice_histograms(p, e0)
@@ -593,10 +617,7 @@ def plan_and_exchange(eng, dist, comm_device, est_part, gt_part, world: int, ran
     if _single(dist):
         allm = msg[None]
     else:
-        buf = _comm(msg, comm_device).contiguous()
-        parts = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
-        dist.all_gather(parts, buf)
-        allm = torch.stack(parts)
+        allm = _all_gather_stacked(_comm(msg, comm_device).contiguous(), dist)
     axis, cuts, halo_eff, counts, _ = lattice_plan(allm, world, halo, e0, eng=eng)
     recv = halo_exchange_planned(eng, dist, comm_device, [est_part, gt_part], axis, cuts, halo_eff, counts, rank)
     return axis, cuts, halo_eff, recv
@@ -793,9 +814,7 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     else:
         if not lean:
             msg = torch.cat([head] + [_pad_rows(mineq[i][:cap] if mineq[i] is not None else None, cap, 4, comm_device, bound_pad=True) for i in range(2)])
-        parts = [torch.empty_like(msg) for _ in range(world)]
-        dist.all_gather(parts, msg)
-        allq = torch.stack(parts)                                 # (world, 1 + 2 cap, 4)
+        allq = _all_gather_stacked(msg, dist)                     # (world, 1 + 2 cap, 4)
         if not optimistic:
             table = allq[:, 0, :].to(torch.int64).cpu()           # the host read of the cross-rank step
     tr.mark("counts")
@@ -912,9 +931,12 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
                 k = min(int(rows[c].shape[0]), _VOX_CAP)
                 if k:
                     msg[_FOLD_HEAD + c * _VOX_CAP:_FOLD_HEAD + c * _VOX_CAP + k] = rows[c][:k]
-            allr = torch.empty((world,) + tuple(msg.shape), dtype=torch.float64, device=comm_device)
-            dist.all_gather(list(allr.unbind(0)), msg)                    # (world, _FOLD_HEAD + 2 _VOX_CAP, 16)
-            return allr, allr[:, :_FOLD_HEAD].reshape(world, -1).cpu().numpy()  # the host read of this phase
+            tr.mark("stats_message")
+            allr = _all_gather_stacked(msg, dist)                         # (world, _FOLD_HEAD + 2 _VOX_CAP, 16)
+            tr.mark("stats_gather")
+            heads = allr[:, :_FOLD_HEAD].reshape(world, -1).cpu().numpy()  # the host read of this phase
+            tr.mark("stats_read")
+            return allr, heads
 
         allr, heads = stats_gather(parts)
         xt = heads[:, VEC_LEN + 2:VEC_LEN + 6].astype(np.int64)           # per rank: open queries of both directions, points held

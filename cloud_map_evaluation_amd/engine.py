@@ -531,6 +531,22 @@ class Engine:
         out = out[:total]
         return out, [int(x) for x in counts]
 
+    def lattice_messages(self, parts, e0: int):
+        """The rows of this rank's plan-gather message for its 1 or 2 pieces (cuda (n,3) float64 tensors): int64 (len(parts),
+        8 + 3 ME_LATTICE_BINS) on the device, header included — me_lattice_messages_device."""
+        import torch
+
+        dev = torch.device("cuda", self.device)
+        for p in parts:
+            assert p.is_cuda and p.dtype == torch.float64 and p.is_contiguous()
+        torch.cuda.current_stream(dev).synchronize()
+        msg = torch.empty((len(parts), 8 + 3 * _lib.ME_LATTICE_BINS), dtype=torch.int64, device=dev)
+        a = parts[0]
+        b = parts[1] if len(parts) > 1 else parts[0]
+        self._ck(self._L.me_lattice_messages_device(self._ctx, a.data_ptr(), int(a.shape[0]), b.data_ptr(), int(b.shape[0]) if len(parts) > 1 else 0,
+                                                    len(parts), int(e0), msg.data_ptr()))
+        return msg
+
     def lattice_plan_raw(self, allm, halo: float, e0: int):
         """The plan of the lean exchange from the gathered messages (world, clouds, 8 + 3 ME_LATTICE_BINS) int64 cuda tensor:
         me_lattice_plan_device's output vector as numpy int64 (dist.lattice_plan unpacks it)."""

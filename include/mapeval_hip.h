@@ -216,12 +216,17 @@ int me_set_voxel_hint(me_ctx *ctx, double voxel_size);
 #define ME_LATTICE_BINS 4096
 int me_lattice_histograms_device(me_ctx *ctx, const double *xyz_device, int64_t n, int e0, int32_t *level, int64_t origin_bin[3],
                                  int64_t neg_inf[3], uint32_t *hist_device);
+/* me_lattice_histograms_device for a rank's `clouds` (1 or 2) pieces at once, written as the rows of its gather message:
+ * msg_device = clouds x (8 + 3 ME_LATTICE_BINS) int64, row = [level, origin_bin x y z, n, neg_inf x y z | the counts, axis-major] —
+ * what me_lattice_plan_device reads.  Two launches per piece, one host read and one stream synchronisation for both. */
+int me_lattice_messages_device(me_ctx *ctx, const double *xyz_a_device, int64_t n_a, const double *xyz_b_device, int64_t n_b, int clouds, int e0,
+                               int64_t *msg_device);
 /* The plan of the lean exchange from the gathered messages of all ranks: msgs_device = world x clouds rows (rank-major; the LAST cloud is
  * the ground truth, whose extent picks the slab axis) of 8 + 3 ME_LATTICE_BINS int64: [level, origin_bin x y z, n, neg_inf x y z |
  * me_lattice_histograms_device's counts, axis-major].  out (host, 4 + clouds + world - 1 + world * clouds * world int64):
  * [axis, level of the combined window, its first bin on that axis, halo in bins, points per cloud, the cut edges c_1 .. c_{world-1}
  * (bins from the window's first), then counts[source rank][cloud][destination rank]] — cut k = (first bin + c_k) * 2^(e0 + level),
- * halo = (halo in bins) * 2^(e0 + level).  Three small kernels; the same arithmetic, number for number, as dist.lattice_plan. */
+ * halo = (halo in bins) * 2^(e0 + level).  Four small kernels; the same arithmetic, number for number, as dist.lattice_plan. */
 int me_lattice_plan_device(me_ctx *ctx, const int64_t *msgs_device, int world, int clouds, double halo, int e0, int64_t *out);
 int me_voxel_partial_rows_device(me_ctx *ctx, int slot, double voxel_size, double *rows_device, int64_t capacity, int64_t *n_rows);
 int me_voxel_merge_device(me_ctx *ctx, int slot, double voxel_size, const double *rows_device, int64_t n_rows);

@@ -29,6 +29,7 @@ class FakeDist:
         self.record, self.replay = record, replay  # {gather index within the step: {rank: message}}
         self.preset = preset or {}                 # gathers whose messages are known beforehand (round 6: index 0, the lattice histograms)
         self.n_gather = 0
+        self.cache = {}
 
     def is_initialized(self):
         return True
@@ -56,6 +57,27 @@ class FakeDist:
                 if r is not None and r.shape == buf.shape and r.dtype == buf.dtype:
                     src = r  # (a message of another shape — a rank whose step took another branch — falls back to the own copy)
             p.copy_(src)
+
+    def get_backend(self):
+        return "emulated"
+
+    def all_gather_into_tensor(self, out, msg):
+        """One kernel in the real job: here one copy of the other ranks' (recorded / preset) messages, stacked once and cached, and
+        one of the rank's own."""
+        idx = self.n_gather
+        self.n_gather += 1
+        n = msg.numel()
+        if self.record is not None:
+            self.record.setdefault(idx, {})[self.rank] = msg.clone()
+        src = self.preset.get(idx) or (self.replay or {}).get(idx)
+        if src is not None and all(k in src and src[k].numel() == n and src[k].dtype == msg.dtype for k in range(self.world)):
+            key = ("stacked", idx)
+            if key not in self.cache:
+                self.cache[key] = torch.cat([src[k].reshape(-1) for k in range(self.world)])
+            out.copy_(self.cache[key])
+        else:
+            out.copy_(msg.repeat(self.world))
+        out[self.rank * n:(self.rank + 1) * n].copy_(msg)
 
     def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
         if out.dtype == torch.int64:

@@ -73,6 +73,14 @@ def test_lattice_histograms_and_the_plan_they_give_against_numpy_and_halo_pack()
                 assert (level, list(origin), list(ninf)) == (l2, list(o2), list(n2)), (name, e0)
                 assert np.array_equal(hist.cpu().numpy(), h2.numpy()), (name, e0)
                 assert int(hist.sum()) == int(np.isfinite(p).sum())
+        # the two-piece form (what the step calls): the same rows, header included
+        for pa, pb in ((clouds["mixed"], clouds["huge"]), (clouds["empty"], clouds["one"]), (clouds["one"], clouds["empty"])):
+            ta, tb = torch.from_numpy(pa).to(dev), torch.from_numpy(pb).to(dev)
+            got = eng.lattice_messages([ta, tb], -4).cpu().numpy()
+            for row, p in zip(got, (pa, pb)):
+                l2, o2, n2, h2 = numpy_lattice_histograms(p, -4)
+                assert list(row[:8]) == [l2, *o2, len(p), *n2] and np.array_equal(row[8:], h2.numpy().reshape(-1))
+            assert np.array_equal(eng.lattice_messages([ta], -4).cpu().numpy()[0], got[0])
         # four ranks' parts of two clouds -> plan -> what halo_pack really packs
         world, halo = 4, 0.3
         parts = [[torch.from_numpy(rng.uniform(-3, 9, (30_000 + 1000 * r, 3)) * [1, 0.3, 0.1]).to(dev) for _ in range(2)] for r in range(world)]
