@@ -313,8 +313,11 @@ int MapEval::processDist(double t_loaded) {
     if (exchangeCloud(gt_3d_->points_, g0, g1, nullptr, axis, cuts, halo, recv_g, tags_g, &got_g) != 0) return -1;
     mark("halo_exchange");
     DIST_TRY(me_set_slab(ctx_, axis, cuts[(size_t) rank], cuts[(size_t) rank + 1], halo));
+    // (round 6: the index builds also emit the voxel run records, so that the voxel partial rows below have no pass over the slab left)
+    DIST_TRY(me_set_voxel_hint(ctx_, param_.vmd_voxel_size_));
     DIST_TRY(me_upload_slab_device(ctx_, ME_SLOT_EST, recv_e.as<double>(), got_e, param_.nn_radius_));
     DIST_TRY(me_upload_slab_device(ctx_, ME_SLOT_GT, recv_g.as<double>(), got_g, param_.nn_radius_));
+    DIST_TRY(me_set_voxel_hint(ctx_, 0.0));
     mark("index");
     if (rank == 0)
         std::cout << "INFO: multi-GPU run: " << world << " rank(s) over " << comm_->name() << ", slabs along axis " << axis << ", halo "
