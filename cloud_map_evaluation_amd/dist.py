@@ -735,7 +735,14 @@ def _hp_stream(device):
 
 
 _CROSS_CAP = 4096  # open queries per direction and rank the folded all-gather carries (overflow: exact-size fallback)
-_VOX_CAP = 1024    # voxel partial rows per cloud and rank the folded statistics gather carries (overflow: exact-size gather)
+_VOX_CAP = None    # voxel partial rows per cloud and rank the folded statistics gather carries (overflow: exact-size gather); None: by world size
+
+
+def _vox_cap(world: int) -> int:
+    """Rows per cloud of the statistics gather: a slab holds ~1 / world of the voxels, so the capacity shrinks with the job (every rank
+    computes the same number; 8192 / world: 1024 at 8 ranks = 256 KB per message)."""
+    return int(_VOX_CAP) if _VOX_CAP is not None else max(512, 8192 // max(1, int(world)))
+
 _FOLD_HEAD = 3     # header rows of that message: VEC_LEN partial sums, the two row counts, the open-query counts and cloud sizes in 3 x 16 doubles
 
 
@@ -919,18 +926,20 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
         #     first _FOLD_HEAD rows of a rank's message carry its partial sums and its two row counts; the sums are added up in rank
         #     order on the device (any order is exact for the counts; the fp sums agree with an all-reduce to the last bits).  A rank
         #     with more than _VOX_CAP rows of a cloud (the header says so, to everybody) sends everybody to the exact-size gather. ---
+        vcap = _vox_cap(world)
+
         def stats_gather(parts):
             hv = np.zeros(_FOLD_HEAD * 16)
             hv[:VEC_LEN] = pack_partials(parts, m_e, m_g)
             hv[VEC_LEN:VEC_LEN + 6] = [rows[0].shape[0], rows[1].shape[0], cnt[0], cnt[1], n_loc[0], n_loc[1]]
             # (one buffer, written in place, gathered into the slices of one tensor: the message is built with five small operations —
             # the first version padded, concatenated and stacked 2 MB per rank and cost the step more than the collective it saved)
-            msg = torch.zeros((_FOLD_HEAD + 2 * _VOX_CAP, 16), dtype=torch.float64, device=comm_device)
+            msg = torch.zeros((_FOLD_HEAD + 2 * vcap, 16), dtype=torch.float64, device=comm_device)
             msg[:_FOLD_HEAD] = torch.from_numpy(hv.reshape(_FOLD_HEAD, 16))
             for c in range(2):
-                k = min(int(rows[c].shape[0]), _VOX_CAP)
+                k = min(int(rows[c].shape[0]), vcap)
                 if k:
-                    msg[_FOLD_HEAD + c * _VOX_CAP:_FOLD_HEAD + c * _VOX_CAP + k] = rows[c][:k]
+                    msg[_FOLD_HEAD + c * vcap:_FOLD_HEAD + c * vcap + k] = rows[c][:k]
             tr.mark("stats_message")
             allr = _all_gather_stacked(msg, dist)                         # (world, _FOLD_HEAD + 2 _VOX_CAP, 16)
             tr.mark("stats_gather")
@@ -965,8 +974,8 @@ def _dist_after_upload(eng, dist, comm_device, P, rank, world, evaluate_gt_mme, 
     # --- collective 8: voxel partial rows of both clouds in one padded all-gather, merged on the device ---
     if single:
         gathered = rows
-    elif fold and max(int(vrows[:world].max()), int(vrows[world:].max())) <= _VOX_CAP:
-        gathered = [allr[:, _FOLD_HEAD:_FOLD_HEAD + _VOX_CAP].reshape(-1, 16), allr[:, _FOLD_HEAD + _VOX_CAP:].reshape(-1, 16)]
+    elif fold and max(int(vrows[:world].max()), int(vrows[world:].max())) <= vcap:
+        gathered = [allr[:, _FOLD_HEAD:_FOLD_HEAD + vcap].reshape(-1, 16), allr[:, _FOLD_HEAD + vcap:].reshape(-1, 16)]
     else:
         vmax = [max(int(vrows[:world].max()), 1), max(int(vrows[world:].max()), 1)]
         msg = torch.cat([_pad_rows(rows[0], vmax[0], 16, comm_device), _pad_rows(rows[1], vmax[1], 16, comm_device)])
