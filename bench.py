@@ -440,7 +440,7 @@ def main():
         suite_step(eng, dist, world, est_d, gt_d, P, evaluate_gt_mme, comm_dev)
         OVERLAP = not args.no_overlap
         fam = {}
-        for name in ("nn_grid", "nn_grid2", "nn1", "nn_far", "mme", "sort", "morton", "gather", "cells", "nn_stats", "slab_filter", "voxel",
+        for name in ("nn_grid", "nn_grid2", "nn1", "nn_far", "mme", "sort", "morton", "gather", "cells", "octree", "nn_stats", "slab_filter", "voxel",
                      "w2", "scs", "halo_pack"):
             ms, cnt = eng.timer(name)
             if cnt:

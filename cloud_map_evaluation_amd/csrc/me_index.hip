@@ -1068,10 +1068,13 @@ int cloud_build_index(me_ctx *ctx, int slot, double cell_size) {
         // stand between the cell tables and the first full-chip kernel of the step.
         c.oct_deferred = false;
         c.oct_nn_shift = nn_shift;
-        if (ctx->defer_octree)
+        ts.end();  // ("cells": the tables the radius search and the 1-NN grid pass use; the octree has its own timer since round 6)
+        if (ctx->defer_octree) {
             c.oct_deferred = true;
-        else
+        } else {
+            TimerScope to(ctx, "octree");
             ME_TRY(build_octree(ctx, c, nn_shift, ctx->is_twin));
+        }
     }
     ME_CHECK(ctx, hipGetLastError());
     // The index is COMPLETE on the device when this returns ("every call is synchronous on return", mapeval_hip.h).  Through round 4
@@ -1092,7 +1095,7 @@ int cloud_finish_octree(me_ctx *ctx, int slot) {
     if (!c.oct_deferred || !c.index_valid) return ME_OK;  // (no index: the next build decides again)
     ME_CHECK(ctx, hipSetDevice(ctx->device));
     {
-        TimerScope ts(ctx, "cells");
+        TimerScope ts(ctx, "octree");
         ME_TRY(build_octree(ctx, c, c.oct_nn_shift, true));
     }
     ME_CHECK(ctx, hipGetLastError());

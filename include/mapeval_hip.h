@@ -434,7 +434,7 @@ int me_run_suite_from(me_ctx *ctx, const double *est, int64_t n_est, const doubl
 
 /* ---- instrumentation (bench.py roofline leg) ------------------------------------------------------------- */
 /* Average device time (ms, HIP events on the context's stream) and launch count of a named kernel family since
- * the last me_timers_reset: "nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells", "nn_stats", "voxel", "w2", "scs", "slab_filter", "halo_pack".  Enabled by me_timers_enable(1).
+ * the last me_timers_reset: "nn_grid", "nn1", "mme", "sort", "morton", "gather", "cells" (the cell tables), "octree", "nn_stats", "voxel", "w2", "scs", "slab_filter", "halo_pack".  Enabled by me_timers_enable(1).
  * Counters (total_ms = 0, value in *launches): "mme_pairs" (accepted (query, neighbour) pairs of the MME launches: the useful work of
  * the VALU-bound kernel, bench.py's roofline.valu), "mme_refined" (queries whose thin neighbourhood — smallest covariance eigenvalue below ~1.8e-6 cell^2 — the MME pass
  * recomputed two-pass about the query itself; counted whether or not timers are on), "nn_queries" / "nn_fallback_queries" (1-NN queries, and those that needed the

@@ -153,7 +153,7 @@ def main(points, workload, worlds=(1, 2, 4, 8)):
                     res = medist.suite_step_dist(eng, fd, dev, pieces[rank][0], pieces[rank][1], P, rank, world, True, halo=halo, overlap=OVERLAP)
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
-            names = ("mme", "nn_grid", "nn_grid2", "nn1", "nn_far", "nn1_cross", "sort", "morton", "gather", "cells", "voxel", "slab_filter", "halo_pack", "nn_stats")
+            names = ("mme", "nn_grid", "nn_grid2", "nn1", "nn_far", "nn1_cross", "sort", "morton", "gather", "cells", "octree", "voxel", "slab_filter", "halo_pack", "nn_stats")
             best_t = {}
             for e2 in ([eng] + ([eng.twin()] if OVERLAP else [])):  # (both lanes: each context keeps its own timers)
                 for k in names:
