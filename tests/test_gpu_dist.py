@@ -270,6 +270,31 @@ def test_two_process_distributed_suite_matches_oracle(overlap, variant, monkeypa
 
 
 @pytest.mark.timeout(600)
+def test_four_process_lean_step_matches_oracle():
+    """Four ranks sharing this GPU (gloo): three cuts, a count matrix of 4 x 2 x 4, slabs whose halo reaches more than one neighbour
+    where the scene is thin — the lean step's plan at a world size the two-process test cannot show."""
+    import torch.multiprocessing as mp
+
+    est, gt = _scene(100_000)
+    est = np.concatenate([est, est[:150] + np.array([2.0, 0.0, 30.0])])
+    rng = np.random.default_rng(19)
+    est, gt = est[rng.permutation(len(est))], gt[rng.permutation(len(gt))]
+    T = np.eye(4)
+    T[:3, 3] = [0.003, -0.002, 0.001]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, est, gt, T, q, True)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _check_against_oracle(results, est, gt, T, 4, 100)
+
+
+@pytest.mark.timeout(600)
 def test_one_rank_distributed_step_through_rccl_matches_oracle_and_plain_step():
     """One GPU: the RCCL calls cannot cross ranks, but a one-rank `nccl` group with ME_FORCE_COLLECTIVES=1 still sends the
     all-reduces, the all-to-alls and the all-gathers of the step through RCCL on device tensors."""
